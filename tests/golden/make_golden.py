@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the UNMODIFIED reference (oracle/_ref/libref_pcsr.so).
+
+Run in the build container where /root/reference exists:
+    make -C oracle && python tests/golden/make_golden.py
+Each fixture stores the update stream (data), checkpoint state digests and — for small cases — the
+raw expected edges[]/nodes[] state produced by the reference driven sequentially in stream order
+(SURVEY.md §8c).  Only inputs and expected outputs are stored; no reference source text.
+"""
+import hashlib
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle_lib import RefPCSR, ref_lib  # noqa: E402
+
+spec = importlib.util.spec_from_file_location("streams", os.path.join(ROOT, "parallel-packed-csr_amd", "streams.py"))
+streams = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(streams)
+
+
+def digest(items, nodes, geom):
+    h = hashlib.sha256()
+    h.update(np.array(geom, np.int64).tobytes())
+    h.update(np.ascontiguousarray(items).tobytes())
+    h.update(np.ascontiguousarray(nodes).tobytes())
+    return h.hexdigest()
+
+
+def run_case(name, n, ops, lock_search=True, checkpoints=8, raw=True, pre=None):
+    r = RefPCSR(n, lock_search=lock_search)
+    if pre:
+        pre(r)
+    cps = sorted(set(int(x) for x in np.linspace(0, len(ops), checkpoints + 1)[1:]))
+    digs, geoms, prev = [], [], 0
+    for c in cps:
+        r.apply(ops[prev:c])
+        prev = c
+        items, nodes = r.state()
+        g = r.geometry()
+        digs.append(digest(items, nodes, g))
+        geoms.append(g)
+    out = dict(n=np.int64(n), lock_search=np.int64(lock_search), ops=ops, checkpoints=np.array(cps, np.int64),
+               digests=np.array(digs), geoms=np.array(geoms, np.int64))
+    if raw:
+        out["items"], out["nodes"] = items, nodes
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: n={n} ops={len(ops)} final geom={geoms[-1]} -> {os.path.getsize(path)/1024:.0f} KiB")
+    r.close()
+
+
+def main():
+    # (1) DataStructureTest add_remove_edge_1E4_seq: 1e4 inserts on vertex 0 then 1e4 deletes
+    m = 10000
+    ins = np.stack([np.zeros(m), np.arange(1, m + 1), np.arange(1, m + 1)], 1).astype(np.uint32)
+    dele = np.stack([np.zeros(m), np.arange(1, m + 1), np.zeros(m)], 1).astype(np.uint32)
+    run_case("hub_1e4_insert_then_delete", 10, np.concatenate([ins, dele]), checkpoints=20, raw=True)
+    # (2) add_remove_edge_random_2E4_seq with a portable PRNG: 75 % add / 25 % delete, n = 1000
+    ops = streams.random_stream(1000, 20000, seed=7, p_delete=0.25)
+    ops[:, 2] = np.where(ops[:, 2] != 0, np.arange(1, 20001, dtype=np.uint32), 0)  # value = i as in the test
+    run_case("random_2e4_n1000", 1000, ops)
+    # (3) n = 2000: 50 k insert-only, and 50 k alternating add / delete-existing
+    core = streams.random_stream(2000, 50000, seed=11)
+    run_case("insert_50k_n2000", 2000, core)
+    fresh = streams.random_stream(2000, 25000, seed=12)
+    mixed = np.concatenate([core[:30000], streams.mixed_existing_stream(core[:30000], fresh, seed=13)])
+    run_case("mixed_existing_80k_n2000", 2000, mixed, raw=False)
+    # (4) RMAT scale-12 core + mixed updates (small cousin of configs #2/#3)
+    s, d = streams.rmat_edges(12, 60000, seed=1)
+    core = streams.adds(s, d)
+    s2, d2 = streams.rmat_edges(12, 20000, seed=2)
+    upd = streams.mixed_existing_stream(core, streams.adds(s2, d2), seed=3)
+    run_case("rmat12_core60k_mixed40k", 4096, np.concatenate([core, upd]), raw=False, checkpoints=10)
+    # (5) lock_search = false (-lock_free) differs only in the lock bookkeeping: min_node init
+    run_case("random_2e4_n1000_lockfree", 1000, streams.random_stream(1000, 20000, seed=17, p_delete=0.3),
+             lock_search=False, raw=False)
+    # (6) dense small-n stream that doubles and halves repeatedly
+    a = streams.random_stream(40, 30000, seed=21)
+    b = a.copy()
+    b[:, 2] = 0
+    run_case("dense_n40_grow_shrink", 40, np.concatenate([a, b[::-1]]), checkpoints=12)
+    # (7) add_node on an empty structure then edges (DataStructureTest add_node)
+    def pre(r):
+        for _ in range(5):
+            r.add_node()
+    ops = streams.random_stream(5, 300, seed=23, p_delete=0.2)
+    run_case("add_node_empty_then_edges", 0, ops, pre=pre, checkpoints=3)
+    # (8) PPPCSR P = 8 on n = 1000: per-partition state after the partition's subsequence
+    L = ref_lib()
+    ops = streams.random_stream(1000, 30000, seed=29, p_delete=0.2)
+    hp = L.refp_create(1000, 1000, 1, 1, 8)
+    part = np.array([L.refp_get_partition(hp, int(v)) for v in range(1000)], np.int64)
+    L.refp_destroy(hp)
+    starts = np.array([np.nonzero(part == k)[0][0] for k in range(8)], np.int64)
+    sizes = np.array([(part == k).sum() for k in range(8)], np.int64)
+    digs = []
+    for k in range(8):
+        sub = ops[part[ops[:, 0]] == k].copy()
+        sub[:, 0] -= np.uint32(starts[k])
+        r = RefPCSR(int(sizes[k]))
+        r.apply(sub)
+        items, nodes = r.state()
+        digs.append(digest(items, nodes, r.geometry()))
+        r.close()
+    np.savez_compressed(os.path.join(HERE, "pppcsr_p8_n1000.npz"), n=np.int64(1000), ops=ops, part_of_vertex=part,
+                        starts=starts, sizes=sizes, digests=np.array(digs))
+    print("pppcsr_p8_n1000: partitions", sizes.tolist())
+
+
+if __name__ == "__main__":
+    main()

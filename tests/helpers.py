@@ -1,0 +1,76 @@
+"""Shared test helpers: fixture loading, state digests, package loading."""
+import hashlib
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = os.path.join(HERE, "golden")
+PKG_DIR = os.path.join(ROOT, "parallel-packed-csr_amd")
+
+
+def _load(name, path):
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=[os.path.dirname(path)]
+                                                  if path.endswith("__init__.py") else None)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_streams():
+    return _load("ppcsr_streams", os.path.join(PKG_DIR, "streams.py"))
+
+
+def load_pkg():
+    """the product package (directory name has a hyphen, so it is loaded by path as `ppcsr_amd`)."""
+    return _load("ppcsr_amd", os.path.join(PKG_DIR, "__init__.py"))
+
+
+def digest(items, nodes, geom):
+    h = hashlib.sha256()
+    h.update(np.array(geom, np.int64).tobytes())
+    h.update(np.ascontiguousarray(items).tobytes())
+    h.update(np.ascontiguousarray(nodes).tobytes())
+    return h.hexdigest()
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+GOLDEN_SINGLE = [
+    "hub_1e4_insert_then_delete", "random_2e4_n1000", "insert_50k_n2000", "mixed_existing_80k_n2000",
+    "rmat12_core60k_mixed40k", "random_2e4_n1000_lockfree", "dense_n40_grow_shrink", "add_node_empty_then_edges",
+]
+
+
+def replay_golden(make_engine, name, check_every=True):
+    """Apply fixture `name` to make_engine(n, lock_search) checkpoint by checkpoint; return the engine.
+    Asserts geometry + digest at every checkpoint and the raw state when stored."""
+    g = golden(name)
+    n, lock = int(g["n"]), bool(int(g["lock_search"]))
+    eng = make_engine(n, lock)
+    if name == "add_node_empty_then_edges":
+        for _ in range(5):
+            eng.add_node()
+    ops, cps = g["ops"], g["checkpoints"]
+    prev = 0
+    for i, c in enumerate(cps):
+        eng.apply(ops[prev:c])
+        prev = int(c)
+        if check_every or i == len(cps) - 1:
+            geom = eng.geometry()
+            assert tuple(geom) == tuple(int(x) for x in g["geoms"][i]), f"{name}: geometry at op {c}: {geom} vs {g['geoms'][i]}"
+            items, nodes = eng.state()
+            assert digest(items, nodes, geom) == str(g["digests"][i]), f"{name}: state digest differs at checkpoint {i} (op {c})"
+    if "items" in g.files:
+        items, nodes = eng.state()
+        np.testing.assert_array_equal(items, g["items"])
+        np.testing.assert_array_equal(nodes, g["nodes"])
+    return eng
