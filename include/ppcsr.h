@@ -1,0 +1,131 @@
+/*
+ * ppcsr.h — C ABI of the MI355X-native packed-CSR update engine (libppcsr_hip.so).
+ *
+ * This is the drop-in boundary for the PMA insert/delete + rebalance hot path of
+ * domargan/parallel-packed-csr.  The reference has no FFI layer: its boundary is the C++ classes
+ * PCSR (src/pcsr/PCSR.h:64-202) and PPPCSR (src/pppcsr/PPPCSR.h:11-60) consumed by the thread
+ * pools (src/thread_pool/thread_pool.cpp:44-48, src/thread_pool_pppcsr/thread_pool_pppcsr.cpp:76-82).
+ * Every entry point below names the reference member it replaces.  All functions return 0 on success
+ * or a ppcsr_status code; none of them exits the process (the reference calls exit() on allocation
+ * failure, PCSR.cpp:49-54).  There is NO CPU fallback: without a visible MI355X ppcsr_create fails.
+ *
+ * Semantics: a batch is applied with the result of the reference driven in stream order on one thread
+ * (the only deterministic mode of the reference): identical N/logN/H, identical
+ * edges[] bytes, identical nodes[] triples.
+ *
+ * Preconditions inherited from the reference's sentinel encoding (PCSR.cpp:64): dst != 0xFFFFFFFF and
+ * edge value != 0xFFFFFFFF for user edges.
+ */
+#ifndef PPCSR_H
+#define PPCSR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ppcsr_engine *ppcsr_t;   /* one PCSR instance resident on one GPU            */
+typedef struct pppcsr_engine *pppcsr_t; /* vertex-range partitioned set of PCSRs (PPPCSR)   */
+
+/* reference edge_t (PCSR.h:30-35) and node_t (PCSR.h:18-23): same field order, same 12-byte layout */
+typedef struct { uint32_t src, dest, value; } ppcsr_edge;
+typedef struct { uint32_t beginning, end, num_neighbors; } ppcsr_node;
+/* one update of a stream: op == 0 deletes (src,dst); op != 0 adds (src,dst) with edge value = op
+ * (reference task record src/utility/task.h:10-15; the pools always add with value 1) */
+typedef struct { uint32_t src, dst, op; } ppcsr_op;
+
+typedef enum {
+  PPCSR_STATUS_OK = 0,
+  PPCSR_STATUS_EINVAL = 1,
+  PPCSR_STATUS_ENOMEM = 2,
+  PPCSR_STATUS_EHIP = 3,         /* HIP runtime error or no GPU */
+  PPCSR_STATUS_EUNSUPPORTED = 4, /* slide ran off both ends of the array (PCSR.cpp:347-351,378-383) */
+  PPCSR_STATUS_EINTERNAL = 5,
+  PPCSR_STATUS_ERANGE = 6        /* output buffer too small; *count holds the needed size */
+} ppcsr_status;
+
+typedef struct {
+  uint64_t N, n;
+  int32_t logN, H;
+  uint64_t rounds, committed, planned, exclusive_ops, round_syncs;
+  uint64_t redistribute_calls, redistribute_slots; /* what the reference's redistribute() would move */
+  uint64_t double_calls, half_calls, big_redistributes;
+  uint64_t not_found, duplicates, noops, slide_slots;
+  uint64_t ops_applied;
+  double last_batch_ms;     /* device-only time of the last batch (ops already in HBM)  */
+  double last_batch_h2d_ms; /* H2D time of the op array when it came from a host buffer */
+} ppcsr_stats_t;
+
+/* PCSR::PCSR(init_n, src_n, lock_search, domain)  — PCSR.cpp:775-838; `device` replaces the NUMA domain */
+int ppcsr_create(uint32_t init_n, uint32_t src_n, int lock_search, int device, ppcsr_t *out);
+/* PCSR::~PCSR — PCSR.cpp:840-851 */
+int ppcsr_destroy(ppcsr_t h);
+/* PCSR::add_edge — PCSR.cpp:706, 1374-1445 */
+int ppcsr_add_edge(ppcsr_t h, uint32_t src, uint32_t dst, uint32_t value);
+/* PCSR::remove_edge — PCSR.cpp:709-773 */
+int ppcsr_remove_edge(ppcsr_t h, uint32_t src, uint32_t dst);
+/* PCSR::add_node — PCSR.cpp:681-703 */
+int ppcsr_add_node(ppcsr_t h);
+/* the worker loop of ThreadPool::execute (thread_pool.cpp:28-61): everything submitted before start() is
+ * one batch; applied with sequential stream-order semantics.  Host buffer variant copies H2D first. */
+int ppcsr_apply_batch(ppcsr_t h, const ppcsr_op *ops, uint64_t n);
+/* same, ops already resident in this GPU's HBM (e.g. the output of the all-to-all exchange) */
+int ppcsr_apply_batch_device(ppcsr_t h, const ppcsr_op *d_ops, uint64_t n);
+/* PCSR::edge_exists — PCSR.cpp:860-869 */
+int ppcsr_edge_exists(ppcsr_t h, uint32_t src, uint32_t dst, int *exists);
+/* PCSR::get_n — PCSR.cpp:100 */
+int ppcsr_get_n(ppcsr_t h, uint64_t *n);
+/* PCSR::getNode — PCSR.h:118-124 */
+int ppcsr_get_node(ppcsr_t h, uint32_t v, ppcsr_node *out);
+/* edges.N / edges.logN / edges.H — PCSR.h:37-44 */
+int ppcsr_geometry(ppcsr_t h, uint64_t *N, int *logN, int *H);
+/* PCSR::get_neighbourhood — PCSR.cpp:901-912 (out may be NULL to query the count) */
+int ppcsr_get_neighbourhood(ppcsr_t h, int src, int *out, uint64_t cap, uint64_t *count);
+/* PCSR::read_neighbourhood — PCSR.cpp:892-899 */
+int ppcsr_read_neighbourhood(ppcsr_t h, int src);
+/* bulk neighbour scan: get_neighbourhood for every vertex at once as CSR (row_offsets[n+1], dests[total]) */
+int ppcsr_scan_all(ppcsr_t h, uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *total);
+/* raw state for parity checks: items[N], nodes[n] exactly as the reference holds them (PCSR.h:67,128) */
+int ppcsr_export_state(ppcsr_t h, ppcsr_edge *items, ppcsr_node *nodes);
+int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out);
+/* tuning knobs: "max_horizon", "min_horizon", "init_horizon", "rounds_per_sync" */
+int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value);
+/* debugging / measurement helpers */
+int ppcsr_check_invariants(ppcsr_t h, uint64_t *bad_leaves);
+int ppcsr_bench_scan_all(ppcsr_t h, double *ms, uint64_t *total);
+int ppcsr_bench_rebalance(ppcsr_t h, uint64_t window_slots, int iters, double *ms_per_call);
+const char *ppcsr_strerror(int status);
+const char *ppcsr_last_error(void); /* message of the last failing call on this thread */
+int ppcsr_device_count(void);
+
+/* ---- PPPCSR: vertex-range partitioning (PPPCSR.cpp:13-34, 58-66); one partition per GPU ------------------- */
+/* PPPCSR::PPPCSR(init_n, src_n, lock_search, numDomain, partitionsPerDomain, use_numa): partition p lives on
+ * devices[p % n_devices] (n_devices may be 1: all partitions on one GPU) */
+int pppcsr_create(uint32_t init_n, uint32_t src_n, int lock_search, int num_domains, int parts_per_domain,
+                  const int *devices, int n_devices, pppcsr_t *out);
+int pppcsr_destroy(pppcsr_t h);
+int pppcsr_num_partitions(pppcsr_t h, uint64_t *out);
+/* PPPCSR::get_partiton — PPPCSR.cpp:58-66 */
+int pppcsr_get_partition(pppcsr_t h, uint64_t vertex, uint64_t *part);
+int pppcsr_partition_start(pppcsr_t h, uint64_t part, uint64_t *first_vertex);
+int pppcsr_partition(pppcsr_t h, uint64_t part, ppcsr_t *out); /* borrowed handle */
+/* PPPCSR::add_edge / remove_edge / edge_exists / get_neighbourhood / getNode / get_n / add_node — PPPCSR.cpp:36-80 */
+int pppcsr_add_edge(pppcsr_t h, uint32_t src, uint32_t dst, uint32_t value);
+int pppcsr_remove_edge(pppcsr_t h, uint32_t src, uint32_t dst);
+int pppcsr_edge_exists(pppcsr_t h, uint32_t src, uint32_t dst, int *exists);
+int pppcsr_get_neighbourhood(pppcsr_t h, int src, int *out, uint64_t cap, uint64_t *count);
+int pppcsr_get_node(pppcsr_t h, uint32_t v, ppcsr_node *out);
+int pppcsr_get_n(pppcsr_t h, uint64_t *n);
+int pppcsr_add_node(pppcsr_t h);
+/* bucket a host stream by owner (stable: per-partition order == stream order, src made partition-local as in
+ * PPPCSR.cpp:46-52) and apply each bucket on its partition's GPU */
+int pppcsr_apply_batch(pppcsr_t h, const ppcsr_op *ops, uint64_t n);
+/* owner-bucketing primitive for the multi-process (one rank per GPU) path: counts[p] = ops owned by p,
+ * bucketed = ops stably grouped by owner with partition-local src.  Pure host routine. */
+int pppcsr_bucket_ops(uint32_t init_n, uint64_t n_parts, const ppcsr_op *ops, uint64_t n, ppcsr_op *bucketed,
+                      uint64_t *counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,313 @@
+"""ppcsr_amd — thin ctypes binding of the MI355X packed-CSR engine (libppcsr_hip.so, C ABI in include/ppcsr.h).
+
+The library is hand-written HIP for gfx950; there is NO CPU fallback: importing works anywhere, but creating
+an engine without the built library or without a GPU raises.  Classes mirror the reference's
+PCSR / PPPCSR method names (src/pcsr/PCSR.h:64-124, src/pppcsr/PPPCSR.h:11-60).
+
+(The directory name contains a hyphen, so load this package by path — see tests/helpers.py:load_pkg.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libppcsr_hip.so")
+
+c_vp, c_u32, c_u64, c_int, c_i64, c_dbl = (ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int,
+                                            ctypes.c_int64, ctypes.c_double)
+
+
+class PpcsrError(RuntimeError):
+    pass
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("N", c_u64), ("n", c_u64), ("logN", ctypes.c_int32), ("H", ctypes.c_int32),
+                ("rounds", c_u64), ("committed", c_u64), ("planned", c_u64), ("exclusive_ops", c_u64),
+                ("round_syncs", c_u64), ("redistribute_calls", c_u64), ("redistribute_slots", c_u64),
+                ("double_calls", c_u64), ("half_calls", c_u64), ("big_redistributes", c_u64),
+                ("not_found", c_u64), ("duplicates", c_u64), ("noops", c_u64), ("slide_slots", c_u64),
+                ("ops_applied", c_u64), ("last_batch_ms", c_dbl), ("last_batch_h2d_ms", c_dbl)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+EXPORTED = [
+    "ppcsr_create", "ppcsr_destroy", "ppcsr_add_edge", "ppcsr_remove_edge", "ppcsr_add_node", "ppcsr_apply_batch",
+    "ppcsr_apply_batch_device", "ppcsr_edge_exists", "ppcsr_get_n", "ppcsr_get_node", "ppcsr_geometry",
+    "ppcsr_get_neighbourhood", "ppcsr_read_neighbourhood", "ppcsr_scan_all", "ppcsr_export_state", "ppcsr_stats",
+    "ppcsr_set_option", "ppcsr_check_invariants", "ppcsr_bench_scan_all", "ppcsr_bench_rebalance", "ppcsr_strerror",
+    "ppcsr_last_error", "ppcsr_device_count", "pppcsr_create", "pppcsr_destroy", "pppcsr_num_partitions",
+    "pppcsr_get_partition", "pppcsr_partition_start", "pppcsr_partition", "pppcsr_add_edge", "pppcsr_remove_edge",
+    "pppcsr_edge_exists", "pppcsr_get_neighbourhood", "pppcsr_get_node", "pppcsr_get_n", "pppcsr_add_node",
+    "pppcsr_apply_batch", "pppcsr_bucket_ops",
+]
+
+_LIBS = {}
+
+
+def load_library(path=None):
+    """Load the engine library.  Default: the in-tree HIP build; raises if it has not been built."""
+    path = path or LIB_PATH
+    if path in _LIBS:
+        return _LIBS[path]
+    if not os.path.exists(path):
+        raise PpcsrError(f"{path} not found: build it with `python __graft_entry__.py` "
+                         "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = ctypes.CDLL(path)
+    L.ppcsr_create.argtypes = [c_u32, c_u32, c_int, c_int, ctypes.POINTER(c_vp)]
+    L.ppcsr_destroy.argtypes = [c_vp]
+    L.ppcsr_add_edge.argtypes = [c_vp, c_u32, c_u32, c_u32]
+    L.ppcsr_remove_edge.argtypes = [c_vp, c_u32, c_u32]
+    L.ppcsr_add_node.argtypes = [c_vp]
+    L.ppcsr_apply_batch.argtypes = [c_vp, c_vp, c_u64]
+    L.ppcsr_apply_batch_device.argtypes = [c_vp, c_vp, c_u64]
+    L.ppcsr_edge_exists.argtypes = [c_vp, c_u32, c_u32, ctypes.POINTER(c_int)]
+    L.ppcsr_get_n.argtypes = [c_vp, ctypes.POINTER(c_u64)]
+    L.ppcsr_get_node.argtypes = [c_vp, c_u32, c_vp]
+    L.ppcsr_geometry.argtypes = [c_vp, ctypes.POINTER(c_u64), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    L.ppcsr_get_neighbourhood.argtypes = [c_vp, c_int, c_vp, c_u64, ctypes.POINTER(c_u64)]
+    L.ppcsr_read_neighbourhood.argtypes = [c_vp, c_int]
+    L.ppcsr_scan_all.argtypes = [c_vp, c_vp, c_vp, c_u64, ctypes.POINTER(c_u64)]
+    L.ppcsr_export_state.argtypes = [c_vp, c_vp, c_vp]
+    L.ppcsr_stats.argtypes = [c_vp, ctypes.POINTER(Stats)]
+    L.ppcsr_set_option.argtypes = [c_vp, ctypes.c_char_p, c_i64]
+    L.ppcsr_check_invariants.argtypes = [c_vp, ctypes.POINTER(c_u64)]
+    L.ppcsr_bench_scan_all.argtypes = [c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_u64)]
+    L.ppcsr_bench_rebalance.argtypes = [c_vp, c_u64, c_int, ctypes.POINTER(c_dbl)]
+    L.ppcsr_strerror.restype = ctypes.c_char_p
+    L.ppcsr_strerror.argtypes = [c_int]
+    L.ppcsr_last_error.restype = ctypes.c_char_p
+    L.pppcsr_create.argtypes = [c_u32, c_u32, c_int, c_int, c_int, c_vp, c_int, ctypes.POINTER(c_vp)]
+    L.pppcsr_destroy.argtypes = [c_vp]
+    L.pppcsr_num_partitions.argtypes = [c_vp, ctypes.POINTER(c_u64)]
+    L.pppcsr_get_partition.argtypes = [c_vp, c_u64, ctypes.POINTER(c_u64)]
+    L.pppcsr_partition_start.argtypes = [c_vp, c_u64, ctypes.POINTER(c_u64)]
+    L.pppcsr_partition.argtypes = [c_vp, c_u64, ctypes.POINTER(c_vp)]
+    L.pppcsr_add_edge.argtypes = [c_vp, c_u32, c_u32, c_u32]
+    L.pppcsr_remove_edge.argtypes = [c_vp, c_u32, c_u32]
+    L.pppcsr_edge_exists.argtypes = [c_vp, c_u32, c_u32, ctypes.POINTER(c_int)]
+    L.pppcsr_get_neighbourhood.argtypes = [c_vp, c_int, c_vp, c_u64, ctypes.POINTER(c_u64)]
+    L.pppcsr_get_node.argtypes = [c_vp, c_u32, c_vp]
+    L.pppcsr_get_n.argtypes = [c_vp, ctypes.POINTER(c_u64)]
+    L.pppcsr_add_node.argtypes = [c_vp]
+    L.pppcsr_apply_batch.argtypes = [c_vp, c_vp, c_u64]
+    L.pppcsr_bucket_ops.argtypes = [c_u32, c_u64, c_vp, c_u64, c_vp, c_vp]
+    _LIBS[path] = L
+    return L
+
+
+def _ops(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    assert a.ndim == 2 and a.shape[1] == 3, "ops must be (n,3) uint32 rows of (src, dst, op)"
+    return a
+
+
+class PCSR:
+    """Mirror of the reference class PCSR (PCSR.h:64-124) on one GPU."""
+
+    def __init__(self, init_n, src_n=None, lock_search=True, device=0, lib=None, _handle=None):
+        self.L = lib or load_library()
+        self._own = _handle is None
+        if _handle is not None:
+            self.h = c_vp(_handle)
+        else:
+            self.h = c_vp()
+            self._chk(self.L.ppcsr_create(init_n, init_n if src_n is None else src_n, int(lock_search), device,
+                                          ctypes.byref(self.h)))
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PpcsrError(f"ppcsr status {rc} ({self.L.ppcsr_strerror(rc).decode()}): "
+                             f"{self.L.ppcsr_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None) and self._own and self.h.value:
+            self.L.ppcsr_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # reference API names
+    def add_edge(self, src, dest, value=1): self._chk(self.L.ppcsr_add_edge(self.h, src, dest, value))
+    def remove_edge(self, src, dest): self._chk(self.L.ppcsr_remove_edge(self.h, src, dest))
+    def add_node(self): self._chk(self.L.ppcsr_add_node(self.h))
+
+    def edge_exists(self, src, dest):
+        out = c_int()
+        self._chk(self.L.ppcsr_edge_exists(self.h, src, dest, ctypes.byref(out)))
+        return bool(out.value)
+
+    def get_n(self):
+        n = c_u64()
+        self._chk(self.L.ppcsr_get_n(self.h, ctypes.byref(n)))
+        return n.value
+
+    def getNode(self, v):
+        out = np.zeros(3, np.uint32)
+        self._chk(self.L.ppcsr_get_node(self.h, v, out.ctypes.data))
+        return tuple(int(x) for x in out)
+
+    def get_neighbourhood(self, src):
+        cnt = c_u64()
+        self._chk(self.L.ppcsr_get_neighbourhood(self.h, src, None, 0, ctypes.byref(cnt)))
+        out = np.empty(cnt.value, np.int32)
+        if cnt.value:
+            self._chk(self.L.ppcsr_get_neighbourhood(self.h, src, out.ctypes.data, cnt.value, ctypes.byref(cnt)))
+        return out
+
+    def read_neighbourhood(self, src): self._chk(self.L.ppcsr_read_neighbourhood(self.h, src))
+
+    # batch + state
+    def apply(self, ops):
+        a = _ops(ops)
+        if len(a):
+            self._chk(self.L.ppcsr_apply_batch(self.h, a.ctypes.data, len(a)))
+
+    def apply_device(self, dev_ptr, n):
+        self._chk(self.L.ppcsr_apply_batch_device(self.h, dev_ptr, n))
+
+    def geometry(self):
+        N, lg, H = c_u64(), c_int(), c_int()
+        self._chk(self.L.ppcsr_geometry(self.h, ctypes.byref(N), ctypes.byref(lg), ctypes.byref(H)))
+        return N.value, lg.value, H.value
+
+    def state(self):
+        N, _, _ = self.geometry()
+        n = self.get_n()
+        items = np.empty((N, 3), np.uint32)
+        nodes = np.empty((n, 3), np.uint32)
+        self._chk(self.L.ppcsr_export_state(self.h, items.ctypes.data, nodes.ctypes.data if n else None))
+        return items, nodes
+
+    def scan_all(self):
+        tot = c_u64()
+        n = self.get_n()
+        rows = np.zeros(n + 1, np.uint64)
+        rc = self.L.ppcsr_scan_all(self.h, rows.ctypes.data, None, 0, ctypes.byref(tot))
+        if rc not in (0, 6):
+            self._chk(rc)
+        dests = np.empty(tot.value, np.int32)
+        self._chk(self.L.ppcsr_scan_all(self.h, rows.ctypes.data, dests.ctypes.data, tot.value, ctypes.byref(tot)))
+        return rows, dests
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.ppcsr_stats(self.h, ctypes.byref(s)))
+        return s.as_dict()
+
+    def set_option(self, key, value): self._chk(self.L.ppcsr_set_option(self.h, key.encode(), int(value)))
+
+    def check_invariants(self):
+        bad = c_u64()
+        self._chk(self.L.ppcsr_check_invariants(self.h, ctypes.byref(bad)))
+        return bad.value
+
+    def bench_scan_all(self):
+        ms, tot = c_dbl(), c_u64()
+        self._chk(self.L.ppcsr_bench_scan_all(self.h, ctypes.byref(ms), ctypes.byref(tot)))
+        return ms.value, tot.value
+
+    def bench_rebalance(self, window_slots, iters=5):
+        ms = c_dbl()
+        self._chk(self.L.ppcsr_bench_rebalance(self.h, window_slots, iters, ctypes.byref(ms)))
+        return ms.value
+
+
+class PPPCSR:
+    """Mirror of the reference class PPPCSR (PPPCSR.h:11-60): vertex-range partitions, one per GPU."""
+
+    def __init__(self, init_n, src_n=None, lock_search=True, numDomain=1, partitionsPerDomain=1, use_numa=False,
+                 devices=None, lib=None):
+        self.L = lib or load_library()
+        self.h = c_vp()
+        devs = np.array(devices if devices else [0], np.int32)
+        rc = self.L.pppcsr_create(init_n, init_n if src_n is None else src_n, int(lock_search), numDomain,
+                                  partitionsPerDomain, devs.ctypes.data, len(devs), ctypes.byref(self.h))
+        if rc != 0:
+            raise PpcsrError(f"pppcsr_create: status {rc}: {self.L.ppcsr_last_error().decode()}")
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PpcsrError(f"ppcsr status {rc}: {self.L.ppcsr_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.pppcsr_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_partitions(self):
+        out = c_u64()
+        self._chk(self.L.pppcsr_num_partitions(self.h, ctypes.byref(out)))
+        return out.value
+
+    def get_partiton(self, v):  # sic: the reference's spelling (PPPCSR.h:27)
+        out = c_u64()
+        self._chk(self.L.pppcsr_get_partition(self.h, v, ctypes.byref(out)))
+        return out.value
+
+    def partition_start(self, k):
+        out = c_u64()
+        self._chk(self.L.pppcsr_partition_start(self.h, k, ctypes.byref(out)))
+        return out.value
+
+    def partition(self, k):
+        out = c_vp()
+        self._chk(self.L.pppcsr_partition(self.h, k, ctypes.byref(out)))
+        return PCSR(0, lib=self.L, _handle=out.value)
+
+    def add_edge(self, s, d, v=1): self._chk(self.L.pppcsr_add_edge(self.h, s, d, v))
+    def remove_edge(self, s, d): self._chk(self.L.pppcsr_remove_edge(self.h, s, d))
+    def add_node(self): self._chk(self.L.pppcsr_add_node(self.h))
+
+    def edge_exists(self, s, d):
+        out = c_int()
+        self._chk(self.L.pppcsr_edge_exists(self.h, s, d, ctypes.byref(out)))
+        return bool(out.value)
+
+    def get_n(self):
+        out = c_u64()
+        self._chk(self.L.pppcsr_get_n(self.h, ctypes.byref(out)))
+        return out.value
+
+    def getNode(self, v):
+        out = np.zeros(3, np.uint32)
+        self._chk(self.L.pppcsr_get_node(self.h, v, out.ctypes.data))
+        return tuple(int(x) for x in out)
+
+    def get_neighbourhood(self, src):
+        cnt = c_u64()
+        self._chk(self.L.pppcsr_get_neighbourhood(self.h, src, None, 0, ctypes.byref(cnt)))
+        out = np.empty(cnt.value, np.int32)
+        if cnt.value:
+            self._chk(self.L.pppcsr_get_neighbourhood(self.h, src, out.ctypes.data, cnt.value, ctypes.byref(cnt)))
+        return out
+
+    def apply(self, ops):
+        a = _ops(ops)
+        if len(a):
+            self._chk(self.L.pppcsr_apply_batch(self.h, a.ctypes.data, len(a)))
+
+
+def bucket_ops(init_n, n_parts, ops, lib=None):
+    """stable owner bucketing (PPPCSR.cpp:46-66 routing rule); returns (bucketed ops with local src, counts)"""
+    L = lib or load_library()
+    a = _ops(ops)
+    out = np.empty_like(a)
+    counts = np.zeros(n_parts, np.uint64)
+    rc = L.pppcsr_bucket_ops(init_n, n_parts, a.ctypes.data, len(a), out.ctypes.data, counts.ctypes.data)
+    if rc != 0:
+        raise PpcsrError(f"pppcsr_bucket_ops: status {rc}")
+    return out, counts

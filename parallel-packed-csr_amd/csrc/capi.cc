@@ -1,0 +1,277 @@
+// C ABI (include/ppcsr.h) over ppcsr::Engine.  No torch types, plain pointers and sizes.
+#include <string.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ppcsr.h"
+#include "engine.h"
+
+using ppcsr::Engine;
+
+static thread_local std::string g_last_error;
+
+struct ppcsr_engine {
+  Engine *e;
+};
+
+static int ret(Engine *e, int rc) {
+  if (rc != 0 && e) g_last_error = e->last_error();
+  return rc;
+}
+static int bad(const char *msg) {
+  g_last_error = msg;
+  return PPCSR_STATUS_EINVAL;
+}
+
+static_assert(sizeof(ppcsr_edge) == sizeof(ppcsr::Edge), "layout");
+static_assert(sizeof(ppcsr_node) == sizeof(ppcsr::Node), "layout");
+static_assert(sizeof(ppcsr_op) == sizeof(ppcsr::Op), "layout");
+
+extern "C" {
+
+int ppcsr_device_count(void) {
+  int n = 0;
+  if (gpu_device_count_for_capi(&n) != 0) return 0;
+  return n;
+}
+
+int ppcsr_create(uint32_t init_n, uint32_t src_n, int lock_search, int device, ppcsr_t *out) {
+  if (!out) return bad("null out");
+  *out = nullptr;
+  Engine *e = nullptr;
+  std::string msg;
+  int rc = Engine::create(init_n, src_n, lock_search, device, &e, &msg);
+  if (rc != 0) {
+    g_last_error = msg;
+    return rc;
+  }
+  *out = new ppcsr_engine{e};
+  return 0;
+}
+int ppcsr_destroy(ppcsr_t h) {
+  if (!h) return 0;
+  delete h->e;
+  delete h;
+  return 0;
+}
+#define H_CHECK() \
+  if (!h || !h->e) return bad("null handle")
+
+int ppcsr_add_edge(ppcsr_t h, uint32_t s, uint32_t d, uint32_t v) { H_CHECK(); return ret(h->e, h->e->add_edge(s, d, v)); }
+int ppcsr_remove_edge(ppcsr_t h, uint32_t s, uint32_t d) { H_CHECK(); return ret(h->e, h->e->remove_edge(s, d)); }
+int ppcsr_add_node(ppcsr_t h) { H_CHECK(); return ret(h->e, h->e->add_node()); }
+int ppcsr_apply_batch(ppcsr_t h, const ppcsr_op *ops, uint64_t n) {
+  H_CHECK();
+  return ret(h->e, h->e->apply_batch_host(reinterpret_cast<const ppcsr::Op *>(ops), n));
+}
+int ppcsr_apply_batch_device(ppcsr_t h, const ppcsr_op *ops, uint64_t n) {
+  H_CHECK();
+  return ret(h->e, h->e->apply_batch_device(reinterpret_cast<const ppcsr::Op *>(ops), n));
+}
+int ppcsr_edge_exists(ppcsr_t h, uint32_t s, uint32_t d, int *exists) {
+  H_CHECK();
+  if (!exists) return bad("null out");
+  return ret(h->e, h->e->edge_exists(s, d, exists));
+}
+int ppcsr_get_n(ppcsr_t h, uint64_t *n) {
+  H_CHECK();
+  *n = h->e->n();
+  return 0;
+}
+int ppcsr_get_node(ppcsr_t h, uint32_t v, ppcsr_node *out) {
+  H_CHECK();
+  return ret(h->e, h->e->get_node(v, reinterpret_cast<ppcsr::Node *>(out)));
+}
+int ppcsr_geometry(ppcsr_t h, uint64_t *N, int *logN, int *H) {
+  H_CHECK();
+  if (N) *N = h->e->N();
+  if (logN) *logN = h->e->logN();
+  if (H) *H = h->e->H();
+  return 0;
+}
+int ppcsr_get_neighbourhood(ppcsr_t h, int src, int *out, uint64_t cap, uint64_t *count) {
+  H_CHECK();
+  uint64_t c = 0;
+  int rc = h->e->get_neighbourhood(src, out, cap, &c);
+  if (count) *count = c;
+  if (rc == 0 && out && c > cap) return PPCSR_STATUS_ERANGE;
+  return ret(h->e, rc);
+}
+int ppcsr_read_neighbourhood(ppcsr_t h, int src) { H_CHECK(); return ret(h->e, h->e->read_neighbourhood(src)); }
+int ppcsr_scan_all(ppcsr_t h, uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *total) {
+  H_CHECK();
+  return ret(h->e, h->e->scan_all(row_offsets, dests, cap, total));
+}
+int ppcsr_export_state(ppcsr_t h, ppcsr_edge *items, ppcsr_node *nodes) {
+  H_CHECK();
+  return ret(h->e, h->e->export_state(reinterpret_cast<ppcsr::Edge *>(items), reinterpret_cast<ppcsr::Node *>(nodes)));
+}
+int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out) {
+  H_CHECK();
+  ppcsr::EngineStats s;
+  int rc = h->e->stats(&s);
+  if (rc != 0) return ret(h->e, rc);
+  out->N = s.N; out->n = s.n; out->logN = s.logN; out->H = s.H;
+  out->rounds = s.rounds; out->committed = s.committed; out->planned = s.planned;
+  out->exclusive_ops = s.exclusive_ops; out->round_syncs = s.round_syncs;
+  out->redistribute_calls = s.redistribute_calls; out->redistribute_slots = s.redistribute_slots;
+  out->double_calls = s.double_calls; out->half_calls = s.half_calls; out->big_redistributes = s.big_redistributes;
+  out->not_found = s.not_found; out->duplicates = s.duplicates; out->noops = s.noops; out->slide_slots = s.slide_slots;
+  out->ops_applied = s.ops_applied; out->last_batch_ms = s.last_batch_ms; out->last_batch_h2d_ms = s.last_batch_h2d_ms;
+  return 0;
+}
+int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value) { H_CHECK(); return ret(h->e, h->e->set_option(key, value)); }
+int ppcsr_check_invariants(ppcsr_t h, uint64_t *bad_leaves) { H_CHECK(); return ret(h->e, h->e->check_invariants(bad_leaves)); }
+int ppcsr_bench_scan_all(ppcsr_t h, double *ms, uint64_t *total) { H_CHECK(); return ret(h->e, h->e->scan_all_device(ms, total)); }
+int ppcsr_bench_rebalance(ppcsr_t h, uint64_t w, int iters, double *ms) { H_CHECK(); return ret(h->e, h->e->rebalance_bench(w, iters, ms)); }
+const char *ppcsr_strerror(int status) { return ppcsr::error_string(status); }
+const char *ppcsr_last_error(void) { return g_last_error.c_str(); }
+
+// ---- PPPCSR ----------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct pppcsr_engine {
+  std::vector<ppcsr_engine *> parts;
+  std::vector<uint64_t> distribution;  // first vertex of each partition (PPPCSR.h:57)
+  uint32_t init_n;
+};
+
+// PPPCSR.cpp:20-29: partitionSize = floor(init_n / P) (the std::ceil wraps an integer division); last takes the rest
+static void partition_layout(uint32_t init_n, uint64_t P, std::vector<uint64_t> *dist, std::vector<uint64_t> *sizes) {
+  dist->assign(P, 0);
+  sizes->assign(P, 0);
+  const uint64_t ps = init_n / P;
+  for (uint64_t k = 0; k < P; k++) {
+    if (k > 0) (*dist)[k] = (*dist)[k - 1] + ps;
+    (*sizes)[k] = (k == P - 1) ? (init_n - k * ps) : ps;
+  }
+}
+// PPPCSR.cpp:58-66
+static uint64_t owner_of(const std::vector<uint64_t> &dist, uint64_t v) {
+  for (size_t i = 1; i < dist.size(); i++)
+    if (dist[i] > v) return i - 1;
+  return dist.size() - 1;
+}
+
+extern "C" {
+
+int pppcsr_create(uint32_t init_n, uint32_t src_n, int lock_search, int num_domains, int parts_per_domain, const int *devices,
+                  int n_devices, pppcsr_t *out) {
+  (void)src_n;
+  if (!out || num_domains < 1 || parts_per_domain < 1) return bad("bad partition counts");
+  *out = nullptr;
+  const uint64_t P = (uint64_t)num_domains * (uint64_t)parts_per_domain;
+  std::unique_ptr<pppcsr_engine> pp(new pppcsr_engine());
+  pp->init_n = init_n;
+  std::vector<uint64_t> sizes;
+  partition_layout(init_n, P, &pp->distribution, &sizes);
+  for (uint64_t k = 0; k < P; k++) {
+    ppcsr_t h = nullptr;
+    const int dev = (devices && n_devices > 0) ? devices[k % (uint64_t)n_devices] : 0;
+    int rc = ppcsr_create((uint32_t)sizes[k], (uint32_t)sizes[k], lock_search, dev, &h);
+    if (rc != 0) {
+      for (auto *q : pp->parts) ppcsr_destroy(q);
+      return rc;
+    }
+    pp->parts.push_back(h);
+  }
+  *out = pp.release();
+  return 0;
+}
+int pppcsr_destroy(pppcsr_t h) {
+  if (!h) return 0;
+  for (auto *q : h->parts) ppcsr_destroy(q);
+  delete h;
+  return 0;
+}
+#define PP_CHECK() \
+  if (!h) return bad("null handle")
+int pppcsr_num_partitions(pppcsr_t h, uint64_t *out) { PP_CHECK(); *out = h->parts.size(); return 0; }
+int pppcsr_get_partition(pppcsr_t h, uint64_t v, uint64_t *part) { PP_CHECK(); *part = owner_of(h->distribution, v); return 0; }
+int pppcsr_partition_start(pppcsr_t h, uint64_t part, uint64_t *first) {
+  PP_CHECK();
+  if (part >= h->parts.size()) return bad("partition out of range");
+  *first = h->distribution[part];
+  return 0;
+}
+int pppcsr_partition(pppcsr_t h, uint64_t part, ppcsr_t *out) {
+  PP_CHECK();
+  if (part >= h->parts.size()) return bad("partition out of range");
+  *out = h->parts[part];
+  return 0;
+}
+int pppcsr_add_edge(pppcsr_t h, uint32_t s, uint32_t d, uint32_t v) {
+  PP_CHECK();
+  const uint64_t k = owner_of(h->distribution, s);
+  return ppcsr_add_edge(h->parts[k], (uint32_t)(s - h->distribution[k]), d, v);
+}
+int pppcsr_remove_edge(pppcsr_t h, uint32_t s, uint32_t d) {
+  PP_CHECK();
+  const uint64_t k = owner_of(h->distribution, s);
+  return ppcsr_remove_edge(h->parts[k], (uint32_t)(s - h->distribution[k]), d);
+}
+int pppcsr_edge_exists(pppcsr_t h, uint32_t s, uint32_t d, int *exists) {
+  PP_CHECK();
+  const uint64_t k = owner_of(h->distribution, s);
+  return ppcsr_edge_exists(h->parts[k], (uint32_t)(s - h->distribution[k]), d, exists);
+}
+int pppcsr_get_neighbourhood(pppcsr_t h, int src, int *out, uint64_t cap, uint64_t *count) {
+  PP_CHECK();
+  if (src < 0) { if (count) *count = 0; return 0; }
+  const uint64_t k = owner_of(h->distribution, (uint64_t)src);
+  return ppcsr_get_neighbourhood(h->parts[k], (int)((uint64_t)src - h->distribution[k]), out, cap, count);
+}
+int pppcsr_get_node(pppcsr_t h, uint32_t v, ppcsr_node *out) {
+  PP_CHECK();
+  const uint64_t k = owner_of(h->distribution, v);
+  return ppcsr_get_node(h->parts[k], (uint32_t)(v - h->distribution[k]), out);
+}
+int pppcsr_get_n(pppcsr_t h, uint64_t *n) {
+  PP_CHECK();
+  uint64_t t = 0;
+  for (auto *q : h->parts) { uint64_t x = 0; ppcsr_get_n(q, &x); t += x; }
+  *n = t;
+  return 0;
+}
+int pppcsr_add_node(pppcsr_t h) { PP_CHECK(); return ppcsr_add_node(h->parts.back()); }  // PPPCSR.cpp:44
+
+int pppcsr_bucket_ops(uint32_t init_n, uint64_t n_parts, const ppcsr_op *ops, uint64_t n, ppcsr_op *bucketed, uint64_t *counts) {
+  if (n_parts < 1 || (!ops && n) || !bucketed || !counts) return bad("bad arguments");
+  std::vector<uint64_t> dist, sizes;
+  partition_layout(init_n, n_parts, &dist, &sizes);
+  std::vector<uint64_t> off(n_parts + 1, 0);
+  for (uint64_t k = 0; k < n_parts; k++) counts[k] = 0;
+  std::vector<uint32_t> owner(n);
+  for (uint64_t i = 0; i < n; i++) {
+    owner[i] = (uint32_t)owner_of(dist, ops[i].src);
+    counts[owner[i]]++;
+  }
+  for (uint64_t k = 0; k < n_parts; k++) off[k + 1] = off[k] + counts[k];
+  std::vector<uint64_t> cur(off.begin(), off.end() - 1);
+  for (uint64_t i = 0; i < n; i++) {
+    ppcsr_op o = ops[i];
+    o.src = (uint32_t)(o.src - dist[owner[i]]);
+    bucketed[cur[owner[i]]++] = o;
+  }
+  return 0;
+}
+
+int pppcsr_apply_batch(pppcsr_t h, const ppcsr_op *ops, uint64_t n) {
+  PP_CHECK();
+  const uint64_t P = h->parts.size();
+  std::vector<ppcsr_op> b(n);
+  std::vector<uint64_t> counts(P);
+  int rc = pppcsr_bucket_ops(h->init_n, P, ops, n, b.data(), counts.data());
+  if (rc != 0) return rc;
+  uint64_t off = 0;
+  for (uint64_t k = 0; k < P; k++) {
+    rc = ppcsr_apply_batch(h->parts[k], b.data() + off, counts[k]);
+    if (rc != 0) return rc;
+    off += counts[k];
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,674 @@
+// Host-side driver of the PMA engine (see engine.h).  Compiled by hipcc into libppcsr_hip.so.
+#include "engine.h"
+
+#include <stdio.h>
+
+#include <algorithm>
+#include <chrono>
+
+#include "gpu_rt.h"
+#include "pma_kernels.h"
+
+namespace ppcsr {
+
+#define GCHK(expr)                                                                       \
+  do {                                                                                   \
+    int _e = (expr);                                                                     \
+    if (_e != 0) return fail(PPCSR_EHIP, std::string(#expr) + ": " + gpu::err_str(_e)); \
+  } while (0)
+
+const char *error_string(int code) {
+  switch (code) {
+    case PPCSR_OK: return "ok";
+    case PPCSR_EINVAL: return "invalid argument";
+    case PPCSR_ENOMEM: return "out of memory";
+    case PPCSR_EHIP: return "HIP runtime error";
+    case PPCSR_EUNSUPPORTED: return "unsupported rare path (slide ran off the end of the array)";
+    case PPCSR_EINTERNAL: return "internal error";
+    case PPCSR_ERANGE: return "output buffer too small";
+    default: return "unknown error";
+  }
+}
+
+struct Engine::Impl {
+  View v{};
+  gpu::stream_t stream{};
+  uint64_t n_cap = 0;        // capacity of nodes[]
+  uint64_t leaves_cap = 0;   // capacity of leafcnt/wres
+  Control *d_ctl = nullptr, *h_ctl = nullptr;
+  Plan *d_plans = nullptr;
+  StatShard *d_stats = nullptr, *h_stats = nullptr;
+  ExclOut *d_xout = nullptr, *h_xout = nullptr;
+  Op *d_ops = nullptr;
+  uint64_t ops_cap = 0;
+  Op *h_op1 = nullptr;  // pinned staging for single ops
+  // scan scratch
+  uint32_t *d_rank = nullptr, *d_tiles = nullptr;
+  uint64_t rank_cap = 0, tiles_cap = 0;
+  unsigned long long *d_total = nullptr, *h_total = nullptr;
+  ChainTable *d_table = nullptr;
+  int *d_nbr = nullptr;
+  uint64_t nbr_cap = 0;
+  uint32_t round = 0;
+  uint32_t max_horizon = 4096, min_horizon = 64, rounds_per_sync = 16, init_horizon = 256;
+  gpu::Timer timer;
+  EngineStats st{};
+  bool partial = false;  // init failed half-way: destructor frees only what exists
+};
+
+Engine::Engine() : p_(new Impl()) {}
+
+int Engine::fail(int code, const std::string &msg) {
+  err_ = msg;
+  return code;
+}
+
+uint64_t Engine::N() const { return p_->v.g.N; }
+uint32_t Engine::n() const { return p_->v.g.n; }
+int Engine::logN() const { return p_->v.g.logN; }
+int Engine::H() const { return p_->v.g.H; }
+
+static inline uint32_t grid_for(uint64_t work_items, uint32_t per_block, uint32_t cap = 2048 * 4) {
+  uint64_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (uint32_t)b;
+}
+
+int Engine::create(uint32_t init_n, uint32_t src_n, int lock_search, int device, Engine **out, std::string *errmsg) {
+  Engine *e = new Engine();
+  int rc = e->init(init_n, src_n, lock_search, device);
+  if (rc != PPCSR_OK) {
+    if (errmsg) *errmsg = e->err_;
+    e->p_->partial = true;
+    delete e;
+    *out = nullptr;
+    return rc;
+  }
+  *out = e;
+  return PPCSR_OK;
+}
+
+int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
+  Impl &p = *p_;
+  device_ = device;
+  int ndev = 0;
+  GCHK(gpu::device_count(&ndev));
+  if (ndev <= 0) return fail(PPCSR_EHIP, "no HIP device visible: the MI355X engine has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(PPCSR_EINVAL, "bad device ordinal");
+  GCHK(gpu::set_device(device));
+  GCHK(gpu::stream_create(&p.stream));
+  GCHK(p.timer.init());
+  const uint64_t N = initial_N(init_n, src_n);
+  Geometry g;
+  compute_geometry(N, src_n, lock_search, &g);
+  p.v.g = g;
+  p.n_cap = std::max<uint64_t>(src_n, 16);
+  p.leaves_cap = N >> g.sh;
+  GCHK(gpu::dmalloc((void **)&p.v.items, N * sizeof(Edge)));
+  GCHK(gpu::dmalloc((void **)&p.v.nodes, p.n_cap * sizeof(Node)));
+  GCHK(gpu::dmalloc((void **)&p.v.leafcnt, p.leaves_cap * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&p.v.wres, p.leaves_cap * sizeof(unsigned long long)));
+  p.v.rres = nullptr;
+  GCHK(gpu::dset(p.v.wres, 0xFF, p.leaves_cap * sizeof(unsigned long long), p.stream));
+  GCHK(gpu::dmalloc((void **)&p.d_ctl, sizeof(Control)));
+  GCHK(gpu::hmalloc((void **)&p.h_ctl, sizeof(Control)));
+  GCHK(gpu::dmalloc((void **)&p.d_stats, kStatShards * sizeof(StatShard)));
+  GCHK(gpu::hmalloc((void **)&p.h_stats, kStatShards * sizeof(StatShard)));
+  GCHK(gpu::dset(p.d_stats, 0, kStatShards * sizeof(StatShard), p.stream));
+  GCHK(gpu::dmalloc((void **)&p.d_xout, sizeof(ExclOut)));
+  GCHK(gpu::hmalloc((void **)&p.h_xout, sizeof(ExclOut)));
+  GCHK(gpu::hmalloc((void **)&p.h_op1, sizeof(Op)));
+  GCHK(gpu::dmalloc((void **)&p.d_total, sizeof(unsigned long long)));
+  GCHK(gpu::hmalloc((void **)&p.h_total, sizeof(unsigned long long)));
+  GCHK(gpu::dmalloc((void **)&p.d_table, sizeof(ChainTable)));
+  GCHK(gpu::dmalloc((void **)&p.d_plans, (uint64_t)p.max_horizon * sizeof(Plan)));
+  memset(p.h_ctl, 0, sizeof(Control));
+
+  // constructor layout (PCSR.cpp:796-837): sentinel positions come from an fp64 accumulator, O(n) on the host
+  std::vector<Node> nodes(src_n);
+  {
+    double index_d = 0.0;
+    const double step = ((double)N) / src_n;
+    for (uint32_t i = 0; i < src_n; i++) {
+      nodes[i].beginning = (i == 0) ? 0u : nodes[i - 1].end;
+      index_d += step;
+      nodes[i].end = (uint32_t)(int)index_d;
+      nodes[i].num_neighbors = 0;
+    }
+    if (src_n != 0) nodes[src_n - 1].end = (uint32_t)(N - 1);
+  }
+  if (src_n) {
+    GCHK(gpu::h2d(p.v.nodes, nodes.data(), (uint64_t)src_n * sizeof(Node), p.stream));
+    GCHK(gpu::sync(p.stream));
+  }
+  GPU_LAUNCH(p.stream, k_fill_null, grid_for(N * 3, 256 * 8), 256, p.v.items, (uint64_t)0, N);
+  if (src_n) GPU_LAUNCH(p.stream, k_place_sentinels, grid_for(src_n, 256), 256, p.v);
+  GPU_LAUNCH(p.stream, k_recount, grid_for((N + 63) / 64, 4), 256, p.v, (uint64_t)0, N);
+  GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
+  return PPCSR_OK;
+}
+
+Engine::~Engine() {
+  Impl &p = *p_;
+  gpu::set_device(device_);
+  gpu::sync(p.stream);
+  gpu::dfree(p.v.items);
+  gpu::dfree(p.v.nodes);
+  gpu::dfree(p.v.leafcnt);
+  gpu::dfree(p.v.wres);
+  gpu::dfree(p.d_ctl);
+  gpu::hfree(p.h_ctl);
+  gpu::dfree(p.d_stats);
+  gpu::hfree(p.h_stats);
+  gpu::dfree(p.d_xout);
+  gpu::hfree(p.h_xout);
+  gpu::hfree(p.h_op1);
+  gpu::dfree(p.d_total);
+  gpu::hfree(p.h_total);
+  gpu::dfree(p.d_table);
+  gpu::dfree(p.d_plans);
+  if (p.d_ops) gpu::dfree(p.d_ops);
+  if (p.d_rank) gpu::dfree(p.d_rank);
+  if (p.d_tiles) gpu::dfree(p.d_tiles);
+  if (p.d_nbr) gpu::dfree(p.d_nbr);
+  p.timer.destroy();
+  gpu::stream_destroy(p.stream);
+  delete p_;
+}
+
+int Engine::set_option(const char *key, int64_t value) {
+  Impl &p = *p_;
+  std::string k(key ? key : "");
+  if (k == "max_horizon") {
+    if (value < 1 || value > (1 << 20)) return fail(PPCSR_EINVAL, "max_horizon out of range");
+    gpu::set_device(device_);
+    gpu::sync(p.stream);
+    Plan *np = nullptr;
+    GCHK(gpu::dmalloc((void **)&np, (uint64_t)value * sizeof(Plan)));
+    gpu::dfree(p.d_plans);
+    p.d_plans = np;
+    p.max_horizon = (uint32_t)value;
+    if (p.min_horizon > p.max_horizon) p.min_horizon = p.max_horizon;
+    if (p.init_horizon > p.max_horizon) p.init_horizon = p.max_horizon;
+    return PPCSR_OK;
+  }
+  if (k == "min_horizon") {
+    if (value < 1) return fail(PPCSR_EINVAL, "min_horizon out of range");
+    p.min_horizon = (uint32_t)std::min<int64_t>(value, p.max_horizon);
+    return PPCSR_OK;
+  }
+  if (k == "init_horizon") {
+    if (value < 1) return fail(PPCSR_EINVAL, "init_horizon out of range");
+    p.init_horizon = (uint32_t)std::min<int64_t>(value, p.max_horizon);
+    return PPCSR_OK;
+  }
+  if (k == "rounds_per_sync") {
+    if (value < 1 || value > 4096) return fail(PPCSR_EINVAL, "rounds_per_sync out of range");
+    p.rounds_per_sync = (uint32_t)value;
+    return PPCSR_OK;
+  }
+  return fail(PPCSR_EINVAL, "unknown option " + k);
+}
+
+// ---- batch application ---------------------------------------------------------------------------------------
+int Engine::apply_batch_host(const Op *ops, uint64_t n) {
+  Impl &p = *p_;
+  if (n == 0) return PPCSR_OK;
+  if (!ops) return fail(PPCSR_EINVAL, "null ops");
+  GCHK(gpu::set_device(device_));
+  if (n > p.ops_cap) {
+    if (p.d_ops) gpu::dfree(p.d_ops);
+    p.d_ops = nullptr;
+    p.ops_cap = 0;
+    GCHK(gpu::dmalloc((void **)&p.d_ops, n * sizeof(Op)));
+    p.ops_cap = n;
+  }
+  auto t0 = std::chrono::steady_clock::now();
+  GCHK(gpu::h2d(p.d_ops, ops, n * sizeof(Op), p.stream));
+  GCHK(gpu::sync(p.stream));
+  p.st.last_batch_h2d_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return apply_batch_device(p.d_ops, n);
+}
+
+int Engine::apply_batch_device(const Op *d_ops, uint64_t n) {
+  Impl &p = *p_;
+  if (n == 0) return PPCSR_OK;
+  GCHK(gpu::set_device(device_));
+  p.timer.start(p.stream);
+  const uint64_t kChunk = 1ull << 30;
+  for (uint64_t off = 0; off < n; off += kChunk) {
+    int rc = run_rounds(d_ops + off, std::min(kChunk, n - off));
+    if (rc != PPCSR_OK) return rc;
+  }
+  p.timer.stop(p.stream);
+  p.st.last_batch_ms = p.timer.ms();
+  p.st.ops_applied += n;
+  return PPCSR_OK;
+}
+
+int Engine::run_rounds(const Op *d_ops, uint64_t n) {
+  Impl &p = *p_;
+  if (p.round > 0xFFFF0000u) {  // reservation tags would wrap: start a fresh epoch
+    GCHK(gpu::dset(p.v.wres, 0xFF, p.leaves_cap * sizeof(unsigned long long), p.stream));
+    p.round = 0;
+  }
+  uint64_t cur = 0;
+  uint32_t hor = (uint32_t)std::min<uint64_t>(p.init_horizon, n);
+  while (cur < n) {
+    // (re)arm the control block for the next round's parity
+    const uint32_t par = (p.round + 1) & 1u;
+    Control &c = *p.h_ctl;
+    c.base[par] = (uint32_t)cur;
+    c.base[par ^ 1u] = (uint32_t)cur;
+    c.horizon[par] = (uint32_t)std::min<uint64_t>(hor, n - cur);
+    c.horizon[par ^ 1u] = 0;
+    c.failmin[0] = c.failmin[1] = kMax;
+    c.n_ops = (uint32_t)n;
+    c.excl = 0;
+    c.error = 0;
+    c.max_horizon = p.max_horizon;
+    c.rounds = c.committed = c.planned = 0;
+    GCHK(gpu::h2d(p.d_ctl, p.h_ctl, sizeof(Control), p.stream));
+    bool need_excl = false;
+    while (cur < n && !need_excl) {
+      RoundArgs a;
+      a.v = p.v;
+      a.ops = d_ops;
+      a.plans = p.d_plans;
+      a.ctl = p.d_ctl;
+      a.stats = p.d_stats;
+      a.min_horizon = p.min_horizon;
+      const uint32_t blocks = (p.max_horizon + 3) / 4;
+      for (uint32_t r = 0; r < p.rounds_per_sync; r++) {
+        a.round = ++p.round;
+        GPU_LAUNCH(p.stream, k_plan, blocks, 256, a);
+        GPU_LAUNCH(p.stream, k_check, blocks, 256, a);
+        GPU_LAUNCH(p.stream, k_apply, blocks, 256, a);
+      }
+      GCHK(gpu::d2h(p.h_ctl, p.d_ctl, sizeof(Control), p.stream));
+      GCHK(gpu::sync(p.stream));
+      GCHK(gpu::last_error());
+      p.st.round_syncs++;
+      if (c.error) return fail(PPCSR_EINTERNAL, "device-side error " + std::to_string(c.error));
+      const uint32_t npar = (p.round + 1) & 1u;
+      cur = c.base[npar];
+      hor = std::max<uint32_t>(c.horizon[npar], p.min_horizon);
+      need_excl = c.excl != 0;
+      p.st.rounds += c.rounds;
+      p.st.committed += c.committed;
+      p.st.planned += c.planned;
+      c.rounds = c.committed = c.planned = 0;
+      if (!need_excl && cur < n) {
+        // counters were consumed on the host; clear them on the device without touching base/horizon
+        GCHK(gpu::dset(&p.d_ctl->rounds, 0, 3 * sizeof(unsigned long long), p.stream));
+      }
+    }
+    if (need_excl && cur < n) {
+      GCHK(gpu::d2h(p.h_op1, d_ops + cur, sizeof(Op), p.stream));
+      GCHK(gpu::sync(p.stream));
+      int rc = run_exclusive(*p.h_op1, 0);
+      if (rc != PPCSR_OK) return rc;
+      cur += 1;
+    }
+  }
+  return PPCSR_OK;
+}
+
+int Engine::run_exclusive(Op op, uint32_t flags) {
+  Impl &p = *p_;
+  p.st.exclusive_ops++;
+  for (int attempt = 0; attempt < 8; attempt++) {
+    GPU_LAUNCH(p.stream, k_exclusive, 1, 64, p.v, op, flags, p.d_xout, p.d_stats);
+    GCHK(gpu::d2h(p.h_xout, p.d_xout, sizeof(ExclOut), p.stream));
+    GCHK(gpu::sync(p.stream));
+    GCHK(gpu::last_error());
+    const ExclOut x = *p.h_xout;
+    switch (x.result) {
+      case X_DONE: return PPCSR_OK;
+      case X_NEED_DOUBLE: return resize(p.v.g.N * 2);
+      case X_NEED_HALF: return resize(p.v.g.N / 2);
+      case X_NEED_REDIST: return big_redistribute(x.wstart, x.wlen);
+      case X_DOUBLE_THEN_RETRY: {
+        int rc = resize(p.v.g.N * 2);
+        if (rc != PPCSR_OK) return rc;
+        flags |= XF_FORCE_NOINFO | XF_SKIP_COUNT;
+        if (flags & XF_ADD_NODE) flags |= XF_RESEARCH;
+        break;
+      }
+      case X_UNSUPPORTED: return fail(PPCSR_EUNSUPPORTED, error_string(PPCSR_EUNSUPPORTED));
+      default: return fail(PPCSR_EINTERNAL, "bad exclusive result");
+    }
+  }
+  return fail(PPCSR_EINTERNAL, "exclusive executor did not converge");
+}
+
+int Engine::ensure_scratch(uint64_t nleaves) {
+  Impl &p = *p_;
+  if (nleaves > p.rank_cap) {
+    if (p.d_rank) gpu::dfree(p.d_rank);
+    p.d_rank = nullptr;
+    p.rank_cap = 0;
+    GCHK(gpu::dmalloc((void **)&p.d_rank, nleaves * sizeof(uint32_t)));
+    p.rank_cap = nleaves;
+  }
+  const uint64_t ntiles = (nleaves + kScanTile - 1) / kScanTile;
+  if (ntiles > p.tiles_cap) {
+    if (p.d_tiles) gpu::dfree(p.d_tiles);
+    p.d_tiles = nullptr;
+    p.tiles_cap = 0;
+    GCHK(gpu::dmalloc((void **)&p.d_tiles, ntiles * sizeof(uint32_t)));
+    p.tiles_cap = ntiles;
+  }
+  return PPCSR_OK;
+}
+
+// exclusive prefix sum of d_cnt[0..nleaves) into d_rank_, grand total into d_total_
+int Engine::rank_scan(const uint32_t *d_cnt, uint64_t nleaves) {
+  Impl &p = *p_;
+  int rc = ensure_scratch(nleaves);
+  if (rc != PPCSR_OK) return rc;
+  const uint64_t ntiles = (nleaves + kScanTile - 1) / kScanTile;
+  GPU_LAUNCH(p.stream, k_scan_tiles, ntiles, 256, d_cnt, nleaves, p.d_tiles);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, 64, p.d_tiles, ntiles, p.d_total);
+  GPU_LAUNCH(p.stream, k_scan_apply, ntiles, 256, d_cnt, nleaves, (const uint32_t *)p.d_tiles, p.d_rank);
+  return PPCSR_OK;
+}
+
+// double_list / half_list (PCSR.cpp:251-320): out-of-place whole-array rebalance into a fresh buffer
+int Engine::resize(uint64_t newN) {
+  Impl &p = *p_;
+  if (newN < 2) return fail(PPCSR_EUNSUPPORTED, "array cannot shrink further");
+  if (newN > (1ull << 31)) return fail(PPCSR_EUNSUPPORTED, "edge array would exceed 2^31 slots (reference indexes with int)");
+  const View old = p.v;
+  const uint64_t oldN = old.g.N;
+  const uint64_t old_leaves = oldN >> old.g.sh;
+  Geometry g;
+  compute_geometry(newN, old.g.n, old.g.lock_search, &g);
+  View nv = old;
+  nv.g = g;
+  const uint64_t new_leaves = newN >> g.sh;
+  GCHK(gpu::dmalloc((void **)&nv.items, newN * sizeof(Edge)));
+  GCHK(gpu::dmalloc((void **)&nv.leafcnt, new_leaves * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&nv.wres, new_leaves * sizeof(unsigned long long)));
+  GCHK(gpu::dset(nv.wres, 0xFF, new_leaves * sizeof(unsigned long long), p.stream));
+  int rc = rank_scan(old.leafcnt, old_leaves);
+  if (rc != PPCSR_OK) return rc;
+  GPU_LAUNCH(p.stream, k_chain_table, 1, 64, (uint64_t)0, newN, (const unsigned long long *)p.d_total, p.d_table);
+  GPU_LAUNCH(p.stream, k_fill_null, grid_for(newN * 3, 256 * 8), 256, nv.items, (uint64_t)0, newN);
+  GPU_LAUNCH(p.stream, k_scatter, grid_for((oldN + 63) / 64, 4), 256, nv, (const Edge *)old.items, (uint64_t)0, oldN, old.g.sh,
+             (const uint32_t *)p.d_rank, (const ChainTable *)p.d_table, nv.items, (uint64_t)0);
+  GPU_LAUNCH(p.stream, k_recount, grid_for((newN + 63) / 64, 4), 256, nv, (uint64_t)0, newN);
+  GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
+  gpu::dfree(old.items);
+  gpu::dfree(old.leafcnt);
+  gpu::dfree(old.wres);
+  p.v = nv;
+  p.leaves_cap = new_leaves;
+  p.round = 0;  // fresh reservation array
+  if (newN > oldN) p.st.double_calls++; else p.st.half_calls++;
+  p.st.redistribute_calls++;
+  p.st.redistribute_slots += newN;
+  return PPCSR_OK;
+}
+
+// window rebalance too large for one wave: scan ranks, scatter into a scratch window, copy back
+int Engine::big_redistribute(uint64_t wstart, uint64_t wlen) {
+  Impl &p = *p_;
+  const View v = p.v;
+  const uint64_t leaf_lo = wstart >> v.g.sh, nleaves = wlen >> v.g.sh;
+  int rc = rank_scan(v.leafcnt + leaf_lo, nleaves);
+  if (rc != PPCSR_OK) return rc;
+  Edge *tmp = nullptr;
+  GCHK(gpu::dmalloc((void **)&tmp, wlen * sizeof(Edge)));
+  GPU_LAUNCH(p.stream, k_chain_table, 1, 64, wstart, wlen, (const unsigned long long *)p.d_total, p.d_table);
+  GPU_LAUNCH(p.stream, k_fill_null, grid_for(wlen * 3, 256 * 8), 256, tmp, (uint64_t)0, wlen);
+  GPU_LAUNCH(p.stream, k_scatter, grid_for((wlen + 63) / 64, 4), 256, v, (const Edge *)v.items, wstart, wlen, v.g.sh,
+             (const uint32_t *)p.d_rank, (const ChainTable *)p.d_table, tmp, wstart);
+  GPU_LAUNCH(p.stream, k_copy_slots, grid_for(wlen * 3, 256 * 8), 256, (const Edge *)tmp, v.items + wstart, wlen);
+  GPU_LAUNCH(p.stream, k_recount, grid_for((wlen + 63) / 64, 4), 256, v, wstart, wlen);
+  GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
+  gpu::dfree(tmp);
+  p.st.big_redistributes++;
+  return PPCSR_OK;
+}
+
+// ---- single operations (reference API surface, PCSR.h:73-124) ------------------------------------------------
+int Engine::add_edge(uint32_t s, uint32_t d, uint32_t value) {
+  if (value == 0) return PPCSR_OK;  // reference: silently ignored (PCSR.cpp:1375)
+  Op op{s, d, value};
+  return apply_batch_host(&op, 1);
+}
+int Engine::remove_edge(uint32_t s, uint32_t d) {
+  if (s >= n()) return fail(PPCSR_EINVAL, "remove_edge: src out of range (undefined behaviour in the reference)");
+  Op op{s, d, 0};
+  return apply_batch_host(&op, 1);
+}
+
+int Engine::add_node() {  // PCSR.cpp:681-703
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  const uint32_t len = p.v.g.n;
+  if ((uint64_t)len + 1 > p.n_cap) {
+    const uint64_t ncap = p.n_cap * 2;
+    Node *nn = nullptr;
+    GCHK(gpu::dmalloc((void **)&nn, ncap * sizeof(Node)));
+    GCHK(gpu::d2d(nn, p.v.nodes, (uint64_t)len * sizeof(Node), p.stream));
+    GCHK(gpu::sync(p.stream));
+    gpu::dfree(p.v.nodes);
+    p.v.nodes = nn;
+    p.n_cap = ncap;
+  }
+  Node nd;
+  uint32_t sval = len;
+  if (len > 0) {
+    Node last;
+    GCHK(gpu::d2h(&last, p.v.nodes + (len - 1), sizeof(Node), p.stream));
+    GCHK(gpu::sync(p.stream));
+    nd.beginning = last.end;
+    nd.end = nd.beginning + 1;
+  } else {
+    nd.beginning = 0;
+    nd.end = 1;
+    sval = kMax;
+  }
+  nd.num_neighbors = 0;
+  GCHK(gpu::h2d(p.v.nodes + len, &nd, sizeof(Node), p.stream));
+  GCHK(gpu::sync(p.stream));
+  p.v.g.n = len + 1;
+  Op op{len, nd.beginning, sval};
+  return run_exclusive(op, XF_ADD_NODE | XF_FORCE_NOINFO);
+}
+
+int Engine::edge_exists(uint32_t s, uint32_t d, int *out) {
+  Impl &p = *p_;
+  if (s >= n()) return fail(PPCSR_EINVAL, "edge_exists: src out of range");
+  GCHK(gpu::set_device(device_));
+  GPU_LAUNCH(p.stream, k_edge_exists, 1, 64, p.v, s, d, p.d_xout);
+  GCHK(gpu::d2h(p.h_xout, p.d_xout, sizeof(ExclOut), p.stream));
+  GCHK(gpu::sync(p.stream));
+  *out = (int)p.h_xout->found;
+  return PPCSR_OK;
+}
+
+int Engine::get_node(uint32_t vtx, Node *out) {
+  Impl &p = *p_;
+  if (vtx >= n()) return fail(PPCSR_EINVAL, "get_node: vertex out of range");
+  GCHK(gpu::set_device(device_));
+  GCHK(gpu::d2h(out, p.v.nodes + vtx, sizeof(Node), p.stream));
+  GCHK(gpu::sync(p.stream));
+  return PPCSR_OK;
+}
+
+int Engine::get_neighbourhood(int src, int *out, uint64_t cap, uint64_t *count) {
+  Impl &p = *p_;
+  *count = 0;
+  if (src < 0 || (uint64_t)src >= n()) return PPCSR_OK;  // reference returns an empty vector (PCSR.cpp:903)
+  GCHK(gpu::set_device(device_));
+  if (cap > p.nbr_cap) {
+    if (p.d_nbr) gpu::dfree(p.d_nbr);
+    p.d_nbr = nullptr;
+    p.nbr_cap = 0;
+    GCHK(gpu::dmalloc((void **)&p.d_nbr, cap * sizeof(int)));
+    p.nbr_cap = cap;
+  }
+  GPU_LAUNCH(p.stream, k_neighbourhood, 1, 64, p.v, (uint32_t)src, (out && cap) ? p.d_nbr : (int *)nullptr, cap, p.d_total);
+  GCHK(gpu::d2h(p.h_total, p.d_total, sizeof(unsigned long long), p.stream));
+  GCHK(gpu::sync(p.stream));
+  *count = *p.h_total;
+  const uint64_t m = std::min<uint64_t>(*count, cap);
+  if (out && m) {
+    GCHK(gpu::d2h(out, p.d_nbr, m * sizeof(int), p.stream));
+    GCHK(gpu::sync(p.stream));
+  }
+  return PPCSR_OK;
+}
+
+int Engine::read_neighbourhood(int src) {
+  uint64_t c = 0;
+  return get_neighbourhood(src, nullptr, 0, &c);
+}
+
+int Engine::scan_all_device(double *ms, uint64_t *total) {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  const uint64_t N = p.v.g.N, nchunks = (N + 63) / 64;
+  uint32_t *d_cc = nullptr;
+  unsigned long long *d_rows = nullptr;
+  int *d_dst = nullptr;
+  GCHK(gpu::dmalloc((void **)&d_cc, nchunks * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&d_rows, ((uint64_t)n() + 1) * sizeof(unsigned long long)));
+  GCHK(gpu::dmalloc((void **)&d_dst, N * sizeof(int)));
+  int rc = ensure_scratch(nchunks);
+  if (rc != PPCSR_OK) return rc;
+  p.timer.start(p.stream);
+  GPU_LAUNCH(p.stream, k_scan_count, grid_for(nchunks, 4), 256, p.v, d_cc);
+  rc = rank_scan(d_cc, nchunks);
+  if (rc != PPCSR_OK) return rc;
+  GPU_LAUNCH(p.stream, k_scan_write, grid_for(nchunks, 4), 256, p.v, (const uint32_t *)p.d_rank, d_rows, d_dst, N);
+  p.timer.stop(p.stream);
+  GCHK(gpu::d2h(p.h_total, p.d_total, sizeof(unsigned long long), p.stream));
+  GCHK(gpu::sync(p.stream));
+  if (ms) *ms = p.timer.ms();
+  if (total) *total = *p.h_total;
+  gpu::dfree(d_cc);
+  gpu::dfree(d_rows);
+  gpu::dfree(d_dst);
+  return PPCSR_OK;
+}
+
+int Engine::scan_all(uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *total) {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  const uint64_t N = p.v.g.N, nchunks = (N + 63) / 64;
+  const uint32_t nn = n();
+  uint32_t *d_cc = nullptr;
+  unsigned long long *d_rows = nullptr;
+  int *d_dst = nullptr;
+  GCHK(gpu::dmalloc((void **)&d_cc, nchunks * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&d_rows, ((uint64_t)nn + 1) * sizeof(unsigned long long)));
+  GCHK(gpu::dmalloc((void **)&d_dst, std::max<uint64_t>(cap, 1) * sizeof(int)));
+  GPU_LAUNCH(p.stream, k_scan_count, grid_for(nchunks, 4), 256, p.v, d_cc);
+  int rc = rank_scan(d_cc, nchunks);
+  if (rc != PPCSR_OK) return rc;
+  GPU_LAUNCH(p.stream, k_scan_write, grid_for(nchunks, 4), 256, p.v, (const uint32_t *)p.d_rank, d_rows, d_dst, cap);
+  GCHK(gpu::d2h(p.h_total, p.d_total, sizeof(unsigned long long), p.stream));
+  GCHK(gpu::sync(p.stream));
+  const uint64_t tot = *p.h_total;
+  if (total) *total = tot;
+  if (row_offsets && nn) {
+    GCHK(gpu::d2h(row_offsets, d_rows, (uint64_t)nn * sizeof(unsigned long long), p.stream));
+    GCHK(gpu::sync(p.stream));
+  }
+  if (row_offsets) row_offsets[nn] = tot;
+  if (dests && cap) {
+    GCHK(gpu::d2h(dests, d_dst, std::min(cap, tot) * sizeof(int), p.stream));
+    GCHK(gpu::sync(p.stream));
+  }
+  gpu::dfree(d_cc);
+  gpu::dfree(d_rows);
+  gpu::dfree(d_dst);
+  return (tot > cap && dests) ? PPCSR_ERANGE : PPCSR_OK;
+}
+
+int Engine::export_state(Edge *items, Node *nodes) {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  if (items) GCHK(gpu::d2h(items, p.v.items, p.v.g.N * sizeof(Edge), p.stream));
+  if (nodes && p.v.g.n) GCHK(gpu::d2h(nodes, p.v.nodes, (uint64_t)p.v.g.n * sizeof(Node), p.stream));
+  GCHK(gpu::sync(p.stream));
+  return PPCSR_OK;
+}
+
+int Engine::check_invariants(uint64_t *bad) {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  const uint64_t N = p.v.g.N, leaves = N >> p.v.g.sh;
+  std::vector<uint32_t> cnt(leaves), cnt2(leaves);
+  GCHK(gpu::d2h(cnt.data(), p.v.leafcnt, leaves * sizeof(uint32_t), p.stream));
+  GCHK(gpu::sync(p.stream));
+  View tmp = p.v;
+  GCHK(gpu::dmalloc((void **)&tmp.leafcnt, leaves * sizeof(uint32_t)));
+  GPU_LAUNCH(p.stream, k_recount, grid_for((N + 63) / 64, 4), 256, tmp, (uint64_t)0, N);
+  GCHK(gpu::d2h(cnt2.data(), tmp.leafcnt, leaves * sizeof(uint32_t), p.stream));
+  GCHK(gpu::sync(p.stream));
+  gpu::dfree(tmp.leafcnt);
+  uint64_t b = 0;
+  for (uint64_t i = 0; i < leaves; i++) b += cnt[i] != cnt2[i];
+  *bad = b;
+  return PPCSR_OK;
+}
+
+int Engine::pull_stats() {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  GCHK(gpu::d2h(p.h_stats, p.d_stats, kStatShards * sizeof(StatShard), p.stream));
+  GCHK(gpu::sync(p.stream));
+  return PPCSR_OK;
+}
+
+int Engine::stats(EngineStats *out) {
+  Impl &p = *p_;
+  int rc = pull_stats();
+  if (rc != PPCSR_OK) return rc;
+  EngineStats s = p.st;
+  s.N = p.v.g.N;
+  s.n = p.v.g.n;
+  s.logN = p.v.g.logN;
+  s.H = p.v.g.H;
+  for (int i = 0; i < kStatShards; i++) {
+    const StatShard &h = p.h_stats[i];
+    s.redistribute_calls += h.redistribute_calls;
+    s.redistribute_slots += h.redistribute_slots;
+    s.not_found += h.not_found;
+    s.duplicates += h.duplicates;
+    s.noops += h.noops;
+    s.slide_slots += h.slide_slots;
+  }
+  *out = s;
+  return PPCSR_OK;
+}
+
+// Times the whole-window rebalance pipeline (rank scan + chain table + null fill + scatter + copy-back +
+// recount) on the leftmost `wlen` slots without changing the final state (a rebalance is idempotent).
+int Engine::rebalance_bench(uint64_t wlen, int iters, double *ms_per_call) {
+  Impl &p = *p_;
+  if (wlen == 0 || wlen > p.v.g.N || (wlen & (wlen - 1)) || wlen < (uint64_t)p.v.g.logN) return fail(PPCSR_EINVAL, "bad window");
+  GCHK(gpu::set_device(device_));
+  int rc = big_redistribute(0, wlen);  // warm-up (and makes the window balanced)
+  if (rc != PPCSR_OK) return rc;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; i++) {
+    rc = big_redistribute(0, wlen);
+    if (rc != PPCSR_OK) return rc;
+  }
+  *ms_per_call = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
+  return PPCSR_OK;
+}
+
+}  // namespace ppcsr
+
+int gpu_device_count_for_capi(int *n) { return gpu::device_count(n); }

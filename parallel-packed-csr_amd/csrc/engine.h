@@ -1,0 +1,79 @@
+// Host side of the MI355X PMA engine: owns the HBM-resident state, drives the round scheduler and the
+// exclusive executor, and implements the whole-array phases (double_list / half_list / big windows).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "pma_types.h"
+
+namespace ppcsr {
+
+struct View;  // pma_device.h
+
+struct EngineStats {
+  uint64_t N, n;
+  int logN, H;
+  uint64_t rounds, committed, planned, exclusive_ops, round_syncs;
+  uint64_t redistribute_calls, redistribute_slots;  // algorithmic (what the reference performs)
+  uint64_t double_calls, half_calls, big_redistributes;
+  uint64_t not_found, duplicates, noops, slide_slots;
+  uint64_t ops_applied;
+  double last_batch_ms;      // device-only time of the last apply_batch (ops resident in HBM)
+  double last_batch_h2d_ms;  // time of the H2D copy of the op array (host-buffer entry point)
+};
+
+class Engine {
+ public:
+  static int create(uint32_t init_n, uint32_t src_n, int lock_search, int device, Engine **out, std::string *errmsg = nullptr);
+  ~Engine();
+
+  int apply_batch_host(const Op *ops, uint64_t n);
+  int apply_batch_device(const Op *d_ops, uint64_t n);
+  int add_edge(uint32_t s, uint32_t d, uint32_t value);
+  int remove_edge(uint32_t s, uint32_t d);
+  int add_node();
+  int edge_exists(uint32_t s, uint32_t d, int *out);
+  int get_node(uint32_t v, Node *out);
+  int get_neighbourhood(int src, int *out, uint64_t cap, uint64_t *count);
+  int read_neighbourhood(int src);
+  int scan_all(uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *total);
+  int scan_all_device(double *ms, uint64_t *total);  // device-only timing of the bulk scan (bench)
+  int export_state(Edge *items, Node *nodes);
+  int check_invariants(uint64_t *bad);  // leafcnt == recount(items)
+  int stats(EngineStats *out);
+  int set_option(const char *key, int64_t value);
+  int rebalance_bench(uint64_t wlen, int iters, double *ms_per_call);  // whole-window rebalance kernel timing
+
+  uint64_t N() const;
+  uint32_t n() const;
+  int logN() const;
+  int H() const;
+  int device() const { return device_; }
+  const std::string &last_error() const { return err_; }
+
+ private:
+  Engine();
+  int init(uint32_t init_n, uint32_t src_n, int lock_search, int device);
+  int run_rounds(const Op *d_ops, uint64_t n);
+  int run_exclusive(Op op, uint32_t flags);
+  int resize(uint64_t newN);
+  int big_redistribute(uint64_t wstart, uint64_t wlen);
+  int rank_scan(const uint32_t *d_cnt, uint64_t nleaves);  // -> d_rank_, d_total_
+  int ensure_scratch(uint64_t nleaves);
+  int fail(int code, const std::string &msg);
+  int pull_stats();
+
+  struct Impl;
+  Impl *p_;
+  int device_ = 0;
+  std::string err_;
+};
+
+const char *error_string(int code);
+}  // namespace ppcsr
+int gpu_device_count_for_capi(int *n);
+namespace ppcsr {
+
+}  // namespace ppcsr

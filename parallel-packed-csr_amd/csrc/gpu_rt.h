@@ -1,0 +1,84 @@
+// Minimal device-runtime layer used by engine.cc.  Product build: HIP on gfx950.  The PPCSR_SIM
+// branch exists only for tests/hostsim (CPU debugging of the kernel source) and is never compiled
+// into libppcsr_hip.so.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(PPCSR_SIM)
+#include <chrono>
+#include <cstdlib>
+
+#include "sim_runtime.h"
+namespace gpu {
+typedef int stream_t;
+inline const char *err_str(int) { return "sim error"; }
+inline int set_device(int) { return 0; }
+inline int device_count(int *n) { *n = 1; return 0; }
+inline int stream_create(stream_t *s) { *s = 0; return 0; }
+inline int stream_destroy(stream_t) { return 0; }
+inline int dmalloc(void **p, size_t b) { *p = ::malloc(b ? b : 1); return *p ? 0 : 2; }
+inline int dfree(void *p) { ::free(p); return 0; }
+inline int hmalloc(void **p, size_t b) { *p = ::malloc(b ? b : 1); return *p ? 0 : 2; }
+inline int hfree(void *p) { ::free(p); return 0; }
+inline int h2d(void *d, const void *s, size_t b, stream_t) { memcpy(d, s, b); return 0; }
+inline int d2h(void *d, const void *s, size_t b, stream_t) { memcpy(d, s, b); return 0; }
+inline int d2d(void *d, const void *s, size_t b, stream_t) { memmove(d, s, b); return 0; }
+inline int dset(void *d, int v, size_t b, stream_t) { memset(d, v, b); return 0; }
+inline int sync(stream_t) { return 0; }
+inline int last_error() { return 0; }
+struct Timer {
+  std::chrono::steady_clock::time_point a, b;
+  int init() { return 0; }
+  void destroy() {}
+  void start(stream_t) { a = std::chrono::steady_clock::now(); }
+  void stop(stream_t) { b = std::chrono::steady_clock::now(); }
+  double ms() { return std::chrono::duration<double, std::milli>(b - a).count(); }
+};
+}  // namespace gpu
+#define GPU_LAUNCH(stream, kernel, grid, block, ...) \
+  sim::launch((uint32_t)(grid), (uint32_t)(block), [=]() { kernel(__VA_ARGS__); })
+#else
+#include <hip/hip_runtime.h>
+namespace gpu {
+typedef hipStream_t stream_t;
+inline const char *err_str(int e) { return hipGetErrorString((hipError_t)e); }
+inline int set_device(int d) { return (int)hipSetDevice(d); }
+inline int device_count(int *n) { return (int)hipGetDeviceCount(n); }
+inline int stream_create(stream_t *s) { return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+inline int stream_destroy(stream_t s) { return (int)hipStreamDestroy(s); }
+inline int dmalloc(void **p, size_t b) { return (int)hipMalloc(p, b ? b : 1); }
+inline int dfree(void *p) { return (int)hipFree(p); }
+inline int hmalloc(void **p, size_t b) { return (int)hipHostMalloc(p, b ? b : 1, hipHostMallocDefault); }
+inline int hfree(void *p) { return (int)hipHostFree(p); }
+inline int h2d(void *d, const void *s, size_t b, stream_t st) { return (int)hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, st); }
+inline int d2h(void *d, const void *s, size_t b, stream_t st) { return (int)hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, st); }
+inline int d2d(void *d, const void *s, size_t b, stream_t st) { return (int)hipMemcpyAsync(d, s, b, hipMemcpyDeviceToDevice, st); }
+inline int dset(void *d, int v, size_t b, stream_t st) { return (int)hipMemsetAsync(d, v, b, st); }
+inline int sync(stream_t st) { return (int)hipStreamSynchronize(st); }
+inline int last_error() { return (int)hipGetLastError(); }
+struct Timer {
+  hipEvent_t a = nullptr, b = nullptr;
+  int init() {
+    int e = (int)hipEventCreate(&a);
+    if (e) return e;
+    return (int)hipEventCreate(&b);
+  }
+  void destroy() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+  void start(stream_t s) { (void)hipEventRecord(a, s); }
+  void stop(stream_t s) { (void)hipEventRecord(b, s); }
+  double ms() {
+    float f = 0;
+    (void)hipEventSynchronize(b);
+    (void)hipEventElapsedTime(&f, a, b);
+    return (double)f;
+  }
+};
+}  // namespace gpu
+#define GPU_LAUNCH(stream, kernel, grid, block, ...) \
+  hipLaunchKernelGGL(kernel, dim3((uint32_t)(grid)), dim3((uint32_t)(block)), 0, stream, __VA_ARGS__)
+#endif

@@ -1,0 +1,581 @@
+// Wave-level device routines of the PMA engine: one 64-lane wavefront executes one update.
+//
+// All control flow in these routines is wave-uniform (every decision is derived from ballots,
+// broadcasts or wave-uniform loads), lanes cooperate on the data: a wave-wide load covers 64
+// consecutive 12-byte slots (768 contiguous bytes), null/occupied masks come from __ballot and
+// ranks from popcounts of the ballot mask, and the rebalance scatter is staged through LDS.
+//
+// Reference semantics restated here (paths relative to /root/reference/src/pcsr/):
+//   pma_search        PCSR.cpp:427-502   gap-aware binary search, probe order mid, mid+1, mid-1, ...
+//   plan_insert       PCSR.cpp:949-1134  acquire_insert_locks: window from PRE-insert densities,
+//                                        min_node/tries bookkeeping decides normal vs global path
+//   plan_remove       PCSR.cpp:1147-1232 + 597-630
+//   apply_*           PCSR.cpp:519-595 (insert), 326-355 (slide_right), 597-630 (remove)
+//   redistribute_wave PCSR.cpp:222-249 + fix_sentinel 168-183
+#pragma once
+#include "pma_geometry.h"
+#include "pma_wave.h"
+
+namespace ppcsr {
+
+struct View {
+  Edge *items;
+  Node *nodes;
+  uint32_t *leafcnt;
+  unsigned long long *wres;  // per-leaf write reservation key of the current round
+  unsigned long long *rres;  // per-leaf read reservation key (optimistic mode)
+  Geometry g;
+};
+
+constexpr uint32_t kBigWindow = 4096;  // windows larger than this run through the exclusive executor
+constexpr uint32_t kMaxSlide = 4096;   // slides longer than this too
+constexpr int kStatShards = 256;
+
+struct StatShard {
+  unsigned long long redistribute_calls, redistribute_slots, not_found, duplicates, noops, slide_slots, committed, pad;
+};
+
+namespace dev {
+
+PMA_DEV uint32_t lanemask_lt_count(uint64_t m, int lane) { return (uint32_t)wv::popc64(m & ((1ull << lane) - 1ull)); }
+
+// sum of leafcnt[leaf_lo .. leaf_lo+nleaves)
+PMA_DEV uint32_t count_leaves(const View &v, uint32_t leaf_lo, uint32_t nleaves) {
+  if (nleaves == 1) return v.leafcnt[leaf_lo];
+  uint32_t s = 0;
+  for (uint32_t i = (uint32_t)wv::lane(); i < nleaves; i += 64) s += v.leafcnt[leaf_lo + i];
+  return wv::reduce_add(s);
+}
+PMA_DEV uint32_t count_window(const View &v, uint64_t start, uint64_t len) {
+  return count_leaves(v, (uint32_t)(start >> v.g.sh), (uint32_t)(len >> v.g.sh));
+}
+
+// fix the node index after sentinel `e` has been placed at slot `in` (fix_sentinel, PCSR.cpp:168-183)
+PMA_DEV void fix_sentinel(const View &v, const Edge &e, uint32_t in) {
+  if (!is_sentinel(e)) return;
+  uint32_t vid = e.value;
+  if (vid == kMax) {
+    vid = 0;
+  } else {
+    v.nodes[vid - 1].end = in;
+  }
+  v.nodes[vid].beginning = in;
+  if (vid == v.g.n - 1) v.nodes[vid].end = (uint32_t)(v.g.N - 1);
+}
+
+struct RangeRec {  // read-leaf ranges collected by lane 0 into the plan record
+  Plan *plan;
+  uint32_t nr;
+};
+PMA_DEV void rec_range(RangeRec &rr, const View &v, uint32_t slot_lo, uint32_t slot_hi) {
+  if (!rr.plan) return;
+  uint32_t lo = slot_lo >> v.g.sh, hi = slot_hi >> v.g.sh;
+  if (rr.nr < (uint32_t)kMaxR) {
+    if (wv::lane() == 0) {
+      rr.plan->rlo[rr.nr] = lo;
+      rr.plan->rhi[rr.nr] = hi;
+    }
+    rr.nr++;
+  } else if (wv::lane() == 0) {
+    // overflow: widen the last range (conservative)
+    uint32_t plo = rr.plan->rlo[kMaxR - 1], phi = rr.plan->rhi[kMaxR - 1];
+    rr.plan->rlo[kMaxR - 1] = lo < plo ? lo : plo;
+    rr.plan->rhi[kMaxR - 1] = hi > phi ? hi : phi;
+  }
+}
+
+// Gap-aware lower bound of `dest` in slots [start,end) (PCSR.cpp:427-502), one wave.
+// Lane p probes the p-th slot of the reference's probe sequence mid, mid+1, mid-1, mid+2, ... so the
+// first set bit of the ballot is exactly the slot the reference's scalar walk would stop at.
+PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32_t end, RangeRec &rr) {
+  const int lane = wv::lane();
+  const Edge *items = v.items;
+  while (start + 1 < end) {
+    const uint32_t mid = (start + end) / 2;
+    bool found = false;
+    uint32_t check = mid, idest = 0, dist = 0;
+    for (uint32_t pbase = 0;; pbase += 64) {
+      const uint32_t p = pbase + (uint32_t)lane;
+      const uint32_t d = (p + 1) >> 1;
+      bool valid;
+      uint32_t slot;
+      if (p & 1u) {
+        slot = mid + d;
+        valid = (d < end - mid);  // mid + d < end
+      } else {
+        slot = mid - d;
+        valid = (d <= mid - start);  // mid - d >= start
+      }
+      uint32_t val = 0, dst = 0;
+      if (valid) {
+        val = items[slot].value;
+        dst = items[slot].dest;
+      }
+      const uint64_t m = wv::ballot(valid && val != 0);
+      if (m) {
+        const int pl = wv::ctz64(m);
+        check = wv::shfl(slot, pl);
+        idest = wv::shfl(dst, pl);
+        dist = (pbase + (uint32_t)pl + 1) >> 1;
+        found = true;
+        break;
+      }
+      if (wv::ballot(valid) == 0) break;  // both sides exhausted: the whole range is null
+    }
+    if (found) {
+      uint32_t lo = (dist <= mid - start) ? mid - dist : start;
+      uint32_t hi = (dist < end - mid) ? mid + dist : end - 1;
+      rec_range(rr, v, lo, hi);
+    } else {
+      rec_range(rr, v, start, end - 1);
+    }
+    if (!found || check == start) {
+      if (found && dest <= idest) return check;
+      return mid;
+    }
+    if (dest == idest) return check;
+    if (dest < idest) end = check; else start = check;
+  }
+  if (end < start) start = end;
+  const Edge e = items[start];
+  rec_range(rr, v, start, start);
+  if (!is_null(e) && dest <= e.dest) return start;
+  return end;
+}
+
+// first null slot in [from, N); returns N if none.  Stops (returns kMax) after `limit` slots.
+PMA_DEV uint32_t find_gap_right(const View &v, uint32_t from, uint32_t limit) {
+  const int lane = wv::lane();
+  const uint64_t N = v.g.N;
+  for (uint64_t base = from; base < N; base += 64) {
+    if (base - from > limit) return kMax;
+    const uint64_t s = base + (uint64_t)lane;
+    bool nul = false;
+    if (s < N) nul = (v.items[s].value == 0);
+    const uint64_t m = wv::ballot(nul);
+    if (m) return (uint32_t)(base + (uint64_t)wv::ctz64(m));
+  }
+  return (uint32_t)N;
+}
+
+enum PlanStatus : int { PS_OK = 0, PS_GLOBAL_NOINFO = 1, PS_GLOBAL_DOUBLE = 2, PS_SLIDE_OFF_END = 3, PS_SLIDE_LONG = 4 };
+struct InsertPlan {
+  int status;
+  uint64_t node_index_final;
+  uint64_t max_len;
+  uint32_t gap;  // valid when occupied
+};
+
+// Emulation of acquire_insert_locks (PCSR.cpp:949-1134) for a single sequential caller.  The lock
+// range [min_node,max_node] is tracked only as far as it steers `tries`.
+PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied) {
+  const Geometry &g = v.g;
+  const int sh = g.sh;
+  const uint64_t logN = (uint64_t)g.logN;
+  InsertPlan out;
+  out.status = PS_OK;
+  out.node_index_final = 0;
+  out.max_len = logN;
+  out.gap = index;
+  int64_t left_bound = -1;
+  int tries = 0;
+  for (;;) {
+    if (tries > 3) {  // PCSR.cpp:952-955
+      out.status = PS_GLOBAL_NOINFO;
+      return out;
+    }
+    uint64_t node_index = ((uint64_t)index >> sh) << sh;
+    int level = g.H;
+    uint64_t len = logN;
+    const int64_t node_id = (int64_t)(node_index >> sh);
+    int64_t min_node = node_id;
+    if (left_bound != -1) {
+      if (left_bound < min_node) min_node = left_bound;
+    } else if (node_id > 0 && !g.lock_search) {
+      min_node = node_id - 1;
+    }
+    if ((uint64_t)index == g.N - 1 && occupied) {  // PCSR.cpp:992-997
+      out.status = PS_GLOBAL_NOINFO;
+      return out;
+    }
+    bool restart = false;
+    uint32_t c = v.leafcnt[node_index >> sh];
+    if ((uint64_t)c + 1 == len) {  // leaf would become full (PCSR.cpp:1012-1023)
+      const uint64_t new_idx = node_index & ~(2 * len - 1);
+      const int64_t new_id = (int64_t)(new_idx >> sh);
+      if (new_idx != node_index && new_id < min_node) {
+        left_bound = new_id;
+        tries++;
+        continue;
+      }
+      node_index = new_idx;
+      c = v.leafcnt[node_index >> sh];
+    }
+    while ((uint64_t)c + 1 >= (uint64_t)g.t_up[level]) {  // PCSR.cpp:1028-1061
+      len *= 2;
+      if (len <= g.N) {
+        level--;
+        const uint64_t new_idx = node_index & ~(len - 1);
+        if (new_idx < node_index) {
+          const int64_t new_id = (int64_t)(new_idx >> sh);
+          if (new_id < min_node) {
+            left_bound = new_id;
+            tries++;
+            restart = true;
+            break;
+          }
+          // window grew to the left: new count = old window + left half
+          c += count_window(v, new_idx, len / 2);
+          node_index = new_idx;
+        } else {
+          c += count_window(v, new_idx + len / 2, len / 2);
+        }
+      } else {
+        out.status = PS_GLOBAL_DOUBLE;
+        return out;
+      }
+    }
+    if (restart) continue;
+    out.max_len = len;
+    out.node_index_final = node_index;
+    // leaves the slide will cross (PCSR.cpp:1085-1132)
+    if (occupied) {
+      const uint32_t gap = find_gap_right(v, index + 1, kMaxSlide);
+      if (gap == kMax) {
+        out.status = PS_SLIDE_LONG;
+        return out;
+      }
+      if ((uint64_t)gap == g.N) {
+        out.status = PS_SLIDE_OFF_END;
+        return out;
+      }
+      out.gap = gap;
+    }
+    return out;
+  }
+}
+
+// NOTE on the count update inside the climb above: the reference recomputes get_density over the whole
+// new window at every level; the window at level L-1 is the union of the level-L window and its sibling,
+// so adding the sibling's count gives the identical integer.  In the "would become full" quirk case the
+// level-H window is the LEFT sibling leaf (len stays logN); the union argument still holds from there.
+
+struct RemovePlan {
+  int half;  // climb reached the root: half_list()
+  uint64_t wstart, wlen;
+};
+PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index) {
+  const Geometry &g = v.g;
+  const int sh = g.sh;
+  RemovePlan out;
+  out.half = 0;
+  uint64_t node_index = ((uint64_t)index >> sh) << sh;
+  int level = g.H;
+  uint64_t len = (uint64_t)g.logN;
+  uint32_t c = v.leafcnt[node_index >> sh];  // pre-removal count; compare c-1
+  while ((uint64_t)c < (uint64_t)g.t_lo[level] + 1) {  // (c - 1) < t_lo
+    len *= 2;
+    if (len <= g.N) {
+      level--;
+      const uint64_t new_idx = node_index & ~(len - 1);
+      if (new_idx < node_index) {
+        c += count_window(v, new_idx, len / 2);
+        node_index = new_idx;
+      } else {
+        c += count_window(v, new_idx + len / 2, len / 2);
+      }
+    } else {
+      out.half = 1;
+      break;
+    }
+  }
+  out.wstart = node_index;
+  out.wlen = len;
+  return out;
+}
+
+// ---- in-wave window rebalance (redistribute, PCSR.cpp:222-249) -----------------------------------------
+// Window of <= 64 slots: one coalesced load, ballot + popcount ranks, exact fp64 position chain,
+// scatter staged through this wave's LDS tile, one coalesced store.  Larger windows (rare) are
+// streamed through the same wave in 64-slot chunks: stable in-place compaction to the left, null fill,
+// then spread right-to-left — the reference's own three phases, 64 slots at a time.
+PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, uint32_t *lds /* >= 3*64 u32 per wave */) {
+  const int lane = wv::lane();
+  Edge *items = v.items;
+  const int sh = v.g.sh;
+  const uint32_t logN = (uint32_t)v.g.logN;
+  if (wlen <= 64) {
+    const bool valid = (uint64_t)lane < wlen;
+    Edge e = null_edge();
+    if (valid) e = items[wstart + lane];
+    const bool nn = valid && e.value != 0;
+    const uint64_t m = wv::ballot(nn);
+    const uint32_t j = (uint32_t)wv::popc64(m);
+    const uint32_t k = lanemask_lt_count(m, lane);
+    uint64_t mypos = wstart;
+    if (j >= 2) {
+      const double step = chain_step(wlen, j);
+      double x = chain_top(wstart, j, step);
+      for (uint32_t t = 0; t + 1 < j; t++) {
+        if (nn && k == j - 1 - t) mypos = (uint64_t)x;
+        x = chain_sub(x, step);
+      }
+    }
+    // LDS tile (SoA, stride-1): clear, scatter, gather
+    lds[lane] = kMax;
+    lds[64 + lane] = 0;
+    lds[128 + lane] = 0;
+    wv::fence();
+    if (nn) {
+      const uint32_t o = (uint32_t)(mypos - wstart);
+      lds[o] = e.src;
+      lds[64 + o] = e.dest;
+      lds[128 + o] = e.value;
+      fix_sentinel(v, e, (uint32_t)mypos);
+    }
+    wv::fence();
+    Edge out;
+    out.src = lds[lane];
+    out.dest = lds[64 + lane];
+    out.value = lds[128 + lane];
+    if (valid) items[wstart + lane] = out;
+    const uint64_t occ = wv::ballot(valid && out.value != 0);
+    const uint32_t nleaf = (uint32_t)(wlen >> sh);
+    if ((uint32_t)lane < nleaf) {
+      const uint64_t sub = (logN >= 64) ? occ : ((occ >> ((uint32_t)lane * logN)) & ((1ull << logN) - 1ull));
+      v.leafcnt[(wstart >> sh) + lane] = (uint32_t)wv::popc64(sub);
+    }
+    wv::fence();
+    return;
+  }
+  // ---- chunked path -----------------------------------------------------------------------------
+  const uint64_t wend = wstart + wlen;
+  uint64_t wr = wstart;
+  for (uint64_t base = wstart; base < wend; base += 64) {  // phase 1: stable compaction to the left
+    const Edge e = items[base + lane];
+    const bool nn = e.value != 0;
+    const uint64_t m = wv::ballot(nn);
+    const uint32_t k = lanemask_lt_count(m, lane);
+    wv::fence();
+    if (nn) items[wr + k] = e;
+    wr += (uint64_t)wv::popc64(m);
+    wv::fence();
+  }
+  const uint64_t j = wr - wstart;
+  for (uint64_t s = wstart + j + (uint64_t)lane; s < wend; s += 64) items[s] = null_edge();  // phase 1.5
+  wv::fence();
+  if (j >= 2) {  // phase 2: spread right-to-left, 64 elements per step
+    const double step = chain_step(wlen, j);
+    double x = chain_top(wstart, j, step);
+    uint64_t khi = j - 1;
+    while (khi >= 1) {
+      const uint64_t klo = (khi >= 64) ? khi - 63 : 1;
+      const uint32_t cntc = (uint32_t)(khi - klo + 1);
+      uint64_t mypos = 0;
+      for (uint32_t i = 0; i < cntc; i++) {
+        if ((uint32_t)lane == i) mypos = (uint64_t)x;
+        x = chain_sub(x, step);
+      }
+      const bool act = (uint32_t)lane < cntc;
+      const uint64_t srcslot = wstart + (khi - (uint64_t)lane);
+      Edge e = null_edge();
+      if (act) e = items[srcslot];
+      wv::fence();
+      if (act && mypos != srcslot) items[srcslot] = null_edge();
+      wv::fence();
+      if (act && mypos != srcslot) items[mypos] = e;
+      if (act) fix_sentinel(v, e, (uint32_t)mypos);
+      wv::fence();
+      khi = klo - 1;
+    }
+  }
+  if (j >= 1 && lane == 0) {
+    const Edge e0 = items[wstart];
+    fix_sentinel(v, e0, (uint32_t)wstart);
+  }
+  wv::fence();
+  // phase 3: recount the window's leaves
+  for (uint64_t base = wstart; base < wend; base += 64) {
+    const Edge e = items[base + lane];
+    const uint64_t occ = wv::ballot(e.value != 0);
+    const uint32_t nleaf = (logN >= 64) ? 1u : (64u >> sh);
+    if ((uint32_t)lane < nleaf) {
+      const uint64_t sub = (logN >= 64) ? occ : ((occ >> ((uint32_t)lane * logN)) & ((1ull << logN) - 1ull));
+      v.leafcnt[(base >> sh) + lane] = (uint32_t)wv::popc64(sub);
+    }
+  }
+  wv::fence();
+}
+
+// shift items[index .. gap-1] one slot to the right (slide_right, PCSR.cpp:326-355); gap is null.
+PMA_DEV void slide_right_wave(const View &v, uint32_t index, uint32_t gap) {
+  const int lane = wv::lane();
+  Edge *items = v.items;
+  uint64_t hi = gap;  // exclusive end of the run still to move
+  while (hi > index) {
+    const uint64_t lo = (hi - index > 64) ? hi - 64 : index;
+    const uint64_t s = lo + (uint64_t)lane;
+    const bool act = s < hi;
+    Edge e = null_edge();
+    if (act) e = items[s];
+    wv::fence();
+    if (act) {
+      items[s + 1] = e;
+      fix_sentinel(v, e, (uint32_t)(s + 1));
+    }
+    wv::fence();
+    hi = lo;
+  }
+}
+
+// ---- full per-op planning (search + window plan) -------------------------------------------------------
+PMA_DEV void plan_op(const View &v, const Op op, Plan *plan) {
+  const int lane = wv::lane();
+  const Geometry &g = v.g;
+  RangeRec rr;
+  rr.plan = plan;
+  rr.nr = 0;
+  uint32_t kind = K_NOOP, index = 0, gap = 0, wstart = 0, wlen = 0, wl = 1, wh = 0, acalls = 0, aslots = 0;
+  if (op.src < g.n) {
+    const Node nd = v.nodes[op.src];
+    // nodes[src].{beginning,end} move only when the sentinels of src / src+1 move: read dependency on their leaves
+    rec_range(rr, v, nd.beginning, nd.beginning);
+    rec_range(rr, v, nd.end, nd.end);
+    index = pma_search(v, op.dst, nd.beginning + 1, nd.end, rr);
+    const Edge at = v.items[index];
+    const bool occupied = !is_null(at);
+    const uint32_t leaf = index >> g.sh;
+    if (op.op != 0) {
+      const Edge elem{op.src, op.dst, op.op};
+      if (occupied && !is_sentinel(elem) && at.dest == op.dst) {
+        kind = K_DUP;
+        wl = wh = leaf;
+      } else {
+        const InsertPlan ip = plan_insert(v, index, occupied);
+        if (ip.status != PS_OK) {
+          kind = K_EXCL;
+        } else {
+          gap = ip.gap;
+          const uint32_t gleaf = gap >> g.sh;
+          const uint32_t cpost = v.leafcnt[leaf] + ((gleaf == leaf) ? 1u : 0u);
+          uint64_t ws, wn;
+          if (cpost == (uint32_t)g.logN) {  // PCSR.cpp:555-557
+            wn = 2ull * (uint64_t)g.logN;
+            ws = ((uint64_t)index) & ~(wn - 1);
+          } else {
+            wn = (uint64_t)g.logN;
+            ws = (uint64_t)leaf << g.sh;
+          }
+          acalls = 1;
+          aslots = (uint32_t)wn;
+          if (ip.max_len > (uint64_t)g.logN) {  // PCSR.cpp:592-594
+            ws = ip.node_index_final;
+            wn = ip.max_len;
+            acalls = 2;
+            aslots += (uint32_t)wn;
+          }
+          if (wn > kBigWindow || ws + wn > g.N) {
+            kind = K_EXCL;
+          } else {
+            kind = K_INSERT;
+            wstart = (uint32_t)ws;
+            wlen = (uint32_t)wn;
+            const uint32_t a = (uint32_t)(ws >> g.sh), b = (uint32_t)((ws + wn - 1) >> g.sh);
+            wl = a < leaf ? a : leaf;
+            wh = b > gleaf ? b : gleaf;
+          }
+        }
+      }
+    } else {
+      const Edge elem{op.src, op.dst, 1u};
+      if (!occupied || is_sentinel(elem) || at.dest != op.dst) {
+        kind = K_NOTFOUND;
+      } else {
+        const RemovePlan rp = plan_remove(v, index);
+        if (rp.half || rp.wlen > kBigWindow) {
+          kind = K_EXCL;
+        } else {
+          kind = K_REMOVE;
+          acalls = 2;  // leaf pass + window pass, always both (PCSR.cpp:609, 629)
+          aslots = (uint32_t)g.logN + (uint32_t)rp.wlen;
+          wstart = (uint32_t)rp.wstart;
+          wlen = (uint32_t)rp.wlen;
+          wl = (uint32_t)(rp.wstart >> g.sh);
+          wh = (uint32_t)((rp.wstart + rp.wlen - 1) >> g.sh);
+        }
+      }
+    }
+  } else if (op.op == 0) {
+    kind = K_NOOP;  // reference: unchecked out-of-range delete is UB; we ignore it
+  }
+  if (lane == 0) {
+    plan->kind = kind;
+    plan->index = index;
+    plan->gap = gap;
+    plan->wstart = wstart;
+    plan->wlen = wlen;
+    plan->wleaf_lo = wl;
+    plan->wleaf_hi = wh;
+    plan->alg_calls = acalls;
+    plan->alg_slots = aslots;
+    plan->nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
+  }
+}
+
+// apply a planned op whose reservations were validated
+PMA_DEV void apply_op(const View &v, const Op op, const Plan *plan, uint32_t *lds, StatShard *st) {
+  const int lane = wv::lane();
+  const Geometry &g = v.g;
+  const uint32_t kind = plan->kind;
+  const uint32_t index = plan->index;
+  if (kind == K_NOOP) {
+    if (lane == 0) wv::atomic_add_u64(&st->noops, 1ull);
+    return;
+  }
+  if (kind == K_DUP) {
+    if (lane == 0) {
+      v.items[index].value = op.op;
+      wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 1u);
+      wv::atomic_add_u64(&st->duplicates, 1ull);
+    }
+    return;
+  }
+  if (kind == K_NOTFOUND) {
+    if (lane == 0) {
+      wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
+      wv::atomic_add_u64(&st->not_found, 1ull);
+    }
+    return;
+  }
+  if (kind == K_INSERT) {
+    const uint32_t gap = plan->gap;
+    if (gap != index) slide_right_wave(v, index, gap);
+    if (lane == 0) {
+      v.items[index] = Edge{op.src, op.dst, op.op};
+      v.leafcnt[gap >> g.sh] += 1u;
+      wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 1u);
+      wv::atomic_add_u64(&st->redistribute_calls, (unsigned long long)plan->alg_calls);
+      wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)plan->alg_slots);
+      wv::atomic_add_u64(&st->slide_slots, (unsigned long long)(gap - index));
+    }
+    wv::fence();
+    redistribute_wave(v, plan->wstart, plan->wlen, lds);
+    return;
+  }
+  if (kind == K_REMOVE) {
+    if (lane == 0) {
+      v.items[index].value = 0;
+      v.items[index].dest = 0;
+      v.leafcnt[index >> g.sh] -= 1u;
+      wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
+      wv::atomic_add_u64(&st->redistribute_calls, (unsigned long long)plan->alg_calls);
+      wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)plan->alg_slots);
+    }
+    wv::fence();
+    redistribute_wave(v, plan->wstart, plan->wlen, lds);
+    return;
+  }
+}
+
+}  // namespace dev
+}  // namespace ppcsr

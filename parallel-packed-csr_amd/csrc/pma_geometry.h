@@ -1,0 +1,213 @@
+// Geometry, integer density thresholds and the exact rebalance-position chain.
+//
+// Everything here is scalar host+device code with no memory access pattern of its own; it is the
+// arithmetic contract with the reference:
+//   * resizeEdgeArray            /root/reference/src/pcsr/PCSR.cpp:68-73
+//   * density_bound              PCSR.cpp:156-165
+//   * redistribute position loop PCSR.cpp:237-247  (serial fp64 chain index_d -= step)
+#pragma once
+#include <math.h>
+#include <string.h>
+
+#include "pma_types.h"
+
+namespace ppcsr {
+
+PMA_HD inline int bsr64(uint64_t w) {  // index of highest set bit (reference bsr_word, PCSR.cpp:28-33)
+#if defined(__HIP_DEVICE_COMPILE__)
+  return 63 - __clzll((long long)w);
+#else
+  return 63 - __builtin_clzll(w);
+#endif
+}
+
+// ---- host only: geometry + thresholds ----------------------------------------------------------------
+inline void compute_geometry(uint64_t N, uint32_t n, int lock_search, Geometry *g) {
+  memset(g, 0, sizeof(*g));
+  g->N = N;
+  g->n = n;
+  g->lock_search = lock_search;
+  g->logN = 1 << bsr64((uint64_t)(bsr64(N) * 2 + 1));
+  g->sh = bsr64((uint64_t)g->logN);
+  g->H = bsr64(N / (uint64_t)g->logN);
+  for (int L = 0; L <= g->H && L < kMaxLevels; L++) {
+    const double len = (double)((uint64_t)g->logN << (g->H - L));
+    // same expressions, same evaluation order as density_bound(): x = lower, y = upper
+    volatile double lower = 1.0 / 4.0 - ((0.125 * L) / g->H);
+    volatile double upper = 3.0 / 4.0 + ((.25 * L) / g->H);
+    // t_up = min c with (double)c/len >= upper ; never if upper is NaN (H == 0)
+    uint32_t tu = kNever;
+    if (upper == upper) {
+      double c = ceil(upper * len);
+      if (c < 0) c = 0;
+      while (c > 0 && ((c - 1) / len >= upper)) c -= 1;
+      while (!(c / len >= upper)) c += 1;
+      tu = (c > 4294967294.0) ? kNever : (uint32_t)c;
+    }
+    // t_lo = min c with !((double)c/len < lower) ; 0 if lower is NaN or <= 0
+    uint32_t tl = 0;
+    if (lower == lower && lower > 0) {
+      double c = ceil(lower * len);
+      while (c > 0 && !((c - 1) / len < lower)) c -= 1;
+      while ((c / len < lower)) c += 1;
+      tl = (uint32_t)c;
+    }
+    g->t_up[L] = tu;
+    g->t_lo[L] = tl;
+  }
+}
+inline uint64_t initial_N(uint32_t init_n, uint32_t src_n) {  // PCSR.cpp:777
+  uint32_t m = init_n + src_n;
+  if (m < 1024u) m = 1024u;
+  return (uint64_t)2 << bsr64(m);
+}
+
+// ---- exact position chain as a piecewise-linear integer table ------------------------------------------
+// The reference computes, for a window (index,len) holding j live elements,
+//     step = (double)len / j;  x = index + (double)(j-1)*step;
+//     for k = j-1 .. 1:  pos_k = (size_t)x;  x -= step;          pos_0 = index
+// The subtraction chain accumulates fp64 rounding, so floor(index + k*step) is NOT equal to pos_k
+// in general.  While x stays inside one binade [2^e,2^(e+1)) its value is an integer multiple M of
+// u = 2^(e-52) and RN(x - step) is an integer decrement of M (constant after the first step), so the
+// whole chain is a short list of arithmetic progressions; one true fp64 subtraction is executed at each
+// binade crossing.  Random access to pos_k makes the rebalance embarrassingly parallel.
+constexpr int kMaxSeg = 128;
+struct ChainSeg {
+  uint64_t t0;      // first chain step (t = j-1-k) covered
+  uint64_t count;   // covers t0 .. t0+count
+  uint64_t M0;      // integer mantissa at t0
+  uint64_t Dfirst;  // decrement of the first step inside the segment
+  uint64_t Drest;   // decrement of every later step
+  int shift;        // pos = M >> shift   (shift = 52 - e >= 0)
+  int pad;
+};
+struct ChainTable {
+  uint64_t index, len, j;
+  int nseg;
+  int overflow;
+  ChainSeg seg[kMaxSeg];
+};
+
+PMA_HD inline uint64_t dbl_bits(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint64_t)__double_as_longlong(x);
+#else
+  uint64_t b;
+  memcpy(&b, &x, 8);
+  return b;
+#endif
+}
+PMA_HD inline double bits_dbl(uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __longlong_as_double((long long)b);
+#else
+  double x;
+  memcpy(&x, &b, 8);
+  return x;
+#endif
+}
+
+// These three must round exactly once each (no FMA contraction): the translation unit is compiled
+// with -ffp-contract=off and the pragma below guards against a caller's flags.
+PMA_HD inline double chain_step(uint64_t len, uint64_t j) {
+#pragma clang fp contract(off)
+  return (double)len / (double)j;
+}
+PMA_HD inline double chain_top(uint64_t index, uint64_t j, double step) {
+#pragma clang fp contract(off)
+  double prod = (double)(j - 1) * step;
+  return (double)index + prod;
+}
+PMA_HD inline double chain_sub(double x, double step) {
+#pragma clang fp contract(off)
+  return x - step;
+}
+
+PMA_HD inline void build_chain_table(uint64_t index, uint64_t len, uint64_t j, ChainTable *tb) {
+  tb->index = index;
+  tb->len = len;
+  tb->j = j;
+  tb->nseg = 0;
+  tb->overflow = 0;
+  if (j < 2) return;
+  const double step = chain_step(len, j);
+  double x = chain_top(index, j, step);
+  const uint64_t sb = dbl_bits(step);
+  const int es = (int)((sb >> 52) & 0x7FF) - 1023;
+  const uint64_t S = (sb & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+  const uint64_t T = j - 2;  // last chain step needed (k = 1)
+  uint64_t t = 0;
+  for (;;) {
+    if (tb->nseg >= kMaxSeg) {
+      tb->overflow = 1;
+      return;
+    }
+    const uint64_t xb = dbl_bits(x);
+    const int e = (int)((xb >> 52) & 0x7FF) - 1023;
+    const uint64_t M0 = (xb & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+    ChainSeg sg;
+    sg.t0 = t;
+    sg.M0 = M0;
+    sg.shift = 52 - e;
+    sg.pad = 0;
+    sg.Dfirst = sg.Drest = 0;
+    uint64_t c = 0;
+    const int r = e - es;
+    if (sg.shift >= 0 && r >= 0 && r <= 52) {
+      uint64_t q, rem, half;
+      if (r == 0) {
+        q = S;
+        rem = 0;
+        half = 1;
+      } else {
+        q = S >> r;
+        rem = S & ((1ull << r) - 1);
+        half = 1ull << (r - 1);
+      }
+      uint64_t Df, Dr;
+      if (rem < half) {
+        Df = Dr = q;
+      } else if (rem > half) {
+        Df = Dr = q + 1;
+      } else {  // exact tie: round to even mantissa
+        Df = (((M0 - q) & 1ull) == 0) ? q : q + 1;
+        Dr = ((q & 1ull) == 0) ? q : q + 1;
+      }
+      const uint64_t Th = (1ull << 52) + q + (rem ? 1 : 0);
+      if (M0 >= Th && Dr > 0) {
+        const uint64_t M1 = M0 - Df;
+        c = 1;
+        if (M1 >= Th) c += (M1 - Th) / Dr + 1;
+      }
+      sg.Dfirst = Df;
+      sg.Drest = Dr;
+    }
+    if (c > T - t) c = T - t;
+    sg.count = c;
+    tb->seg[tb->nseg++] = sg;
+    t += c;
+    if (t >= T) return;
+    // one true fp64 subtraction across the binade boundary
+    uint64_t Mc = (c == 0) ? M0 : (M0 - sg.Dfirst - (c - 1) * sg.Drest);
+    double xc = bits_dbl(((uint64_t)(e + 1023) << 52) | (Mc & 0xFFFFFFFFFFFFFull));
+    x = chain_sub(xc, step);
+    t += 1;
+  }
+}
+
+// position of element k (0 <= k < j) from the table; *hint is a segment cursor (monotone callers)
+PMA_HD inline uint64_t chain_pos(const ChainTable *tb, uint64_t k, int *hint) {
+  if (k == 0) return tb->index;
+  const uint64_t t = tb->j - 1 - k;
+  int s = *hint;
+  if (s < 0 || s >= tb->nseg) s = 0;
+  while (s > 0 && tb->seg[s].t0 > t) s--;
+  while (s + 1 < tb->nseg && tb->seg[s + 1].t0 <= t) s++;
+  *hint = s;
+  const ChainSeg &sg = tb->seg[s];
+  const uint64_t d = t - sg.t0;
+  const uint64_t M = (d == 0) ? sg.M0 : (sg.M0 - sg.Dfirst - (d - 1) * sg.Drest);
+  return M >> sg.shift;
+}
+
+}  // namespace ppcsr

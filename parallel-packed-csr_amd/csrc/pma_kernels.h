@@ -1,0 +1,549 @@
+// Kernels of the PMA engine.  Launch geometry: 256-thread workgroups = 4 wavefronts; the update
+// kernels give one wavefront to one update ("wave per op"), the whole-array kernels give one
+// wavefront to 64 consecutive slots (768 contiguous bytes per wave-wide access).
+//
+// Scheduling model (replaces the reference's per-leaf locks, PCSR.cpp:949-1232, and its thread pools):
+// a batch is applied in ROUNDS.  Each round plans the next `horizon` pending updates of the stream
+// against the current state (k_plan), every plan reserves the PMA leaves it would write with an
+// atomicMin of its stream index, k_check finds the first update whose read or write leaves were
+// reserved by an EARLIER update, and k_apply executes the conflict-free PREFIX before that update.
+// Inside such a prefix no update reads or writes anything an earlier one writes, so executing them
+// concurrently is identical to the reference's sequential stream order.
+#pragma once
+#include "pma_device.h"
+
+namespace ppcsr {
+
+struct RoundArgs {
+  View v;
+  const Op *ops;
+  Plan *plans;
+  Control *ctl;
+  StatShard *stats;
+  uint32_t round;
+  uint32_t min_horizon;
+};
+
+PMA_DEV unsigned long long make_key(uint32_t round, uint32_t idx) {
+  return ((unsigned long long)(0xFFFFFFFFu - round) << 32) | (unsigned long long)idx;
+}
+PMA_DEV bool kind_writes(uint32_t k) { return k == K_INSERT || k == K_DUP || k == K_REMOVE; }
+
+PMA_KERNEL void k_plan(RoundArgs a) {
+  Control *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  if (c->excl || c->error) return;
+  if (wv::block_idx() == 0 && wv::thread_idx() == 0) c->failmin[par ^ 1u] = kMax;
+  const uint32_t base = c->base[par], hor = c->horizon[par];
+  const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
+  if (wid >= hor) return;
+  const uint32_t idx = base + wid;
+  const Op op = a.ops[idx];
+  Plan *pl = &a.plans[wid];
+  dev::plan_op(a.v, op, pl);
+  wv::fence();
+  const uint32_t kind = pl->kind;
+  if (kind_writes(kind)) {
+    const unsigned long long key = make_key(a.round, idx);
+    const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
+    for (uint32_t leaf = wl + (uint32_t)wv::lane(); leaf <= wh; leaf += 64) wv::atomic_min_u64(&a.v.wres[leaf], key);
+  }
+}
+
+PMA_KERNEL void k_check(RoundArgs a) {
+  Control *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  if (c->excl || c->error) return;
+  const uint32_t base = c->base[par], hor = c->horizon[par];
+  const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
+  if (wid >= hor) return;
+  const uint32_t idx = base + wid;
+  const Plan *pl = &a.plans[wid];
+  const uint32_t kind = pl->kind;
+  const unsigned long long key = make_key(a.round, idx);
+  const uint32_t tag = (uint32_t)(key >> 32);
+  bool fail = (kind == K_EXCL);
+  if (kind_writes(kind)) {
+    const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
+    for (uint32_t leaf = wl + (uint32_t)wv::lane(); leaf <= wh; leaf += 64)
+      if (a.v.wres[leaf] != key) fail = true;  // an earlier update writes this leaf
+  }
+  const uint32_t nr = pl->nr;
+  for (uint32_t r = 0; r < nr; r++) {
+    const uint32_t lo = pl->rlo[r], hi = pl->rhi[r];
+    for (uint32_t leaf = lo + (uint32_t)wv::lane(); leaf <= hi; leaf += 64) {
+      const unsigned long long k = a.v.wres[leaf];
+      if ((uint32_t)(k >> 32) == tag && (uint32_t)k < idx) fail = true;  // an earlier update writes what we read
+    }
+  }
+  if (wv::ballot(fail) != 0 && wv::lane() == 0) wv::atomic_min_u32(&c->failmin[par], idx);
+}
+
+PMA_KERNEL void k_apply(RoundArgs a) {
+  PMA_SHARED uint32_t lds[4][192];
+  Control *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  if (c->error) return;
+  const uint32_t base = c->base[par], hor = c->horizon[par];
+  if (hor == 0) {
+    if (wv::block_idx() == 0 && wv::thread_idx() == 0) {
+      c->base[par ^ 1u] = base;
+      c->horizon[par ^ 1u] = 0;
+    }
+    return;
+  }
+  const uint32_t fm = c->failmin[par];
+  const uint32_t limit = (fm < base + hor) ? fm : base + hor;
+  if (wv::block_idx() == 0 && wv::thread_idx() == 0) {
+    const uint32_t committed = limit - base;
+    uint32_t nh = committed * 2u;
+    if (nh < a.min_horizon) nh = a.min_horizon;
+    if (nh > c->max_horizon) nh = c->max_horizon;
+    const uint32_t left = c->n_ops - limit;
+    if (nh > left) nh = left;
+    if (committed == 0) {  // the op at base needs the exclusive executor
+      c->excl = 1;
+      nh = 0;
+    }
+    c->base[par ^ 1u] = limit;
+    c->horizon[par ^ 1u] = nh;
+    c->rounds += 1ull;
+    c->committed += (unsigned long long)committed;
+    c->planned += (unsigned long long)hor;
+  }
+  const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
+  if (wid >= hor) return;
+  const uint32_t idx = base + wid;
+  if (idx >= limit) return;
+  const Op op = a.ops[idx];
+  dev::apply_op(a.v, op, &a.plans[wid], lds[wv::wave_in_block()], &a.stats[wv::block_idx() & (kStatShards - 1)]);
+}
+
+// ---- exclusive executor: one wave runs one update alone ---------------------------------------------------
+// Handles what the prefix rounds refuse (K_EXCL): the reference's global-write path
+// (PCSR.cpp:1433-1437 -> insert(..., nullptr) climbing on POST-insert densities, :578-590), root
+// overflow/underflow (double_list / half_list), windows > kBigWindow and long slides.  Whole-array work
+// is handed back to the host as an ExclOut request.
+constexpr uint32_t XF_FORCE_NOINFO = 1u;  // insert(..., nullptr): climb on post-insert densities
+constexpr uint32_t XF_SKIP_COUNT = 2u;    // num_neighbors already adjusted by a previous attempt
+constexpr uint32_t XF_ADD_NODE = 4u;      // op.src = new vertex id, op.dst = slot to insert the sentinel at, op.op = sentinel value
+constexpr uint32_t XF_RESEARCH = 8u;      // add_node retry after double_list: search again (PCSR.cpp:539)
+constexpr uint32_t kExclInWave = 1u << 16;
+
+PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatShard *st) {
+  PMA_SHARED uint32_t lds[192];
+  const int lane = wv::lane();
+  const Geometry &g = v.g;
+  const int sh = g.sh;
+  const uint32_t logN = (uint32_t)g.logN;
+  uint32_t result = X_DONE, rws = 0, rwl = 0, found = 0;
+  dev::RangeRec rr;
+  rr.plan = nullptr;
+  rr.nr = 0;
+  const bool add_node = (flags & XF_ADD_NODE) != 0;
+  if (op.op != 0 || add_node) {
+    Edge elem{op.src, op.dst, op.op};
+    uint32_t index;
+    if (add_node) {
+      elem.dest = kMax;
+      if (flags & XF_RESEARCH) {
+        const Node nd = v.nodes[op.src];
+        index = dev::pma_search(v, kMax, nd.beginning + 1, nd.end, rr);
+      } else {
+        index = op.dst;
+      }
+    } else {
+      const Node nd = v.nodes[op.src];
+      index = dev::pma_search(v, op.dst, nd.beginning + 1, nd.end, rr);
+      if (!(flags & XF_SKIP_COUNT) && lane == 0) wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 1u);
+    }
+    const Edge at = v.items[index];
+    wv::fence();  // every lane has read the slot before lane 0 may overwrite it
+    const bool occupied = !is_null(at);
+    if (occupied && !is_sentinel(elem) && at.dest == elem.dest) {  // PCSR.cpp:529-532
+      if (lane == 0) {
+        v.items[index].value = elem.value;
+        wv::atomic_add_u64(&st->duplicates, 1ull);
+      }
+    } else if (occupied && (uint64_t)index == g.N - 1) {  // PCSR.cpp:533-540
+      result = X_DOUBLE_THEN_RETRY;
+    } else {
+      int status = dev::PS_GLOBAL_NOINFO;
+      dev::InsertPlan ip;
+      ip.gap = index;
+      ip.max_len = logN;
+      ip.node_index_final = 0;
+      if (!(flags & XF_FORCE_NOINFO) && !add_node) {
+        ip = dev::plan_insert(v, index, occupied);
+        status = ip.status;
+      }
+      uint32_t gap = index;
+      if (occupied) {
+        gap = dev::find_gap_right(v, index + 1, kMax - 1u);
+        if ((uint64_t)gap == g.N) status = dev::PS_SLIDE_OFF_END;
+      }
+      if (status == dev::PS_SLIDE_OFF_END) {
+        result = X_UNSUPPORTED;
+      } else {
+        if (status == dev::PS_SLIDE_LONG) status = dev::PS_OK;  // the wave slides any length here
+        wv::fence();  // planning reads are complete in every lane before the state is modified
+        if (gap != index) dev::slide_right_wave(v, index, gap);
+        if (lane == 0) {
+          v.items[index] = elem;
+          v.leafcnt[gap >> sh] += 1u;
+          wv::atomic_add_u64(&st->slide_slots, (unsigned long long)(gap - index));
+        }
+        wv::fence();
+        const uint32_t leaf = index >> sh;
+        const uint32_t cpost = v.leafcnt[leaf];
+        uint64_t ws, wn;
+        if (cpost == logN) {
+          wn = 2ull * logN;
+          ws = ((uint64_t)index) & ~(wn - 1);
+        } else {
+          wn = logN;
+          ws = (uint64_t)leaf << sh;
+        }
+        unsigned long long acalls = 1, aslots = wn;
+        if (status == dev::PS_GLOBAL_DOUBLE) {
+          result = X_NEED_DOUBLE;
+        } else if (status == dev::PS_OK) {
+          if (ip.max_len > logN) {
+            ws = ip.node_index_final;
+            wn = ip.max_len;
+            acalls = 2;
+            aslots += wn;
+          }
+        } else {  // PS_GLOBAL_NOINFO: climb on post-insert densities (PCSR.cpp:578-590)
+          // The first density the reference looks at is that of (node_index, logN) AFTER the leaf / 2-leaf
+          // pass (PCSR.cpp:555-564): with a 2-leaf pass that is the evened-out left leaf, so the inner pass
+          // must really be executed before climbing (it cannot be folded into the outer pass here).
+          dev::redistribute_wave(v, ws, wn, lds);
+          uint64_t node_index = ws, len = logN;
+          int level = g.H;
+          uint32_t c = v.leafcnt[node_index >> sh];
+          while ((uint64_t)c >= (uint64_t)g.t_up[level]) {
+            len *= 2;
+            if (len <= g.N) {
+              level--;
+              const uint64_t new_idx = node_index & ~(len - 1);
+              if (new_idx < node_index) {
+                c += dev::count_window(v, new_idx, len / 2);
+                node_index = new_idx;
+              } else {
+                c += dev::count_window(v, new_idx + len / 2, len / 2);
+              }
+            } else {
+              result = X_NEED_DOUBLE;
+              break;
+            }
+          }
+          if (result == X_DONE && len > logN) {
+            ws = node_index;
+            wn = len;
+            acalls = 2;
+            aslots += wn;
+          }
+        }
+        if (lane == 0) {
+          wv::atomic_add_u64(&st->redistribute_calls, acalls);
+          wv::atomic_add_u64(&st->redistribute_slots, aslots);
+        }
+        if (result == X_DONE) {
+          if (ws + wn > g.N) {
+            result = X_UNSUPPORTED;
+          } else if (wn <= kExclInWave) {
+            dev::redistribute_wave(v, ws, wn, lds);
+          } else {
+            result = X_NEED_REDIST;
+            rws = (uint32_t)ws;
+            rwl = (uint32_t)wn;
+          }
+        }
+      }
+    }
+  } else {  // delete
+    if (op.src < g.n) {
+      const Node nd = v.nodes[op.src];
+      const uint32_t index = dev::pma_search(v, op.dst, nd.beginning + 1, nd.end, rr);
+      if (!(flags & XF_SKIP_COUNT) && lane == 0) wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
+      const Edge at = v.items[index];
+      wv::fence();
+      const Edge elem{op.src, op.dst, 1u};
+      if (is_null(at) || is_sentinel(elem) || at.dest != op.dst) {
+        if (lane == 0) wv::atomic_add_u64(&st->not_found, 1ull);
+      } else {
+        found = 1;
+        const dev::RemovePlan rp = dev::plan_remove(v, index);
+        wv::fence();  // planning reads are complete in every lane before the state is modified
+        if (lane == 0) {
+          v.items[index].value = 0;
+          v.items[index].dest = 0;
+          v.leafcnt[index >> sh] -= 1u;
+        }
+        wv::fence();
+        if (rp.half) {
+          result = X_NEED_HALF;
+          if (lane == 0) {
+            wv::atomic_add_u64(&st->redistribute_calls, 1ull);
+            wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)logN);
+          }
+        } else {
+          if (lane == 0) {
+            wv::atomic_add_u64(&st->redistribute_calls, 2ull);
+            wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)logN + rp.wlen);
+          }
+          if (rp.wlen <= kExclInWave) {
+            dev::redistribute_wave(v, rp.wstart, rp.wlen, lds);
+          } else {
+            result = X_NEED_REDIST;
+            rws = (uint32_t)rp.wstart;
+            rwl = (uint32_t)rp.wlen;
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    out->result = result;
+    out->wstart = rws;
+    out->wlen = rwl;
+    out->found = found;
+  }
+}
+
+// ---- whole-array kernels ---------------------------------------------------------------------------------
+// 12-byte null pattern {0xFFFFFFFF,0,0} written as a dword stream (coalesced)
+PMA_KERNEL void k_fill_null(Edge *items, uint64_t start, uint64_t len) {
+  uint32_t *w = reinterpret_cast<uint32_t *>(items + start);
+  const uint64_t total = len * 3ull;
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t i = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); i < total; i += stride)
+    w[i] = (i % 3ull == 0) ? kMax : 0u;
+}
+
+// leafcnt[leaf] for leaves [leaf_lo, leaf_lo+nleaves): one wave per 64 slots
+PMA_KERNEL void k_recount(View v, uint64_t slot_lo, uint64_t nslots) {
+  const int lane = wv::lane();
+  const uint32_t logN = (uint32_t)v.g.logN;
+  const int sh = v.g.sh;
+  const uint64_t nchunks = (nslots + 63) / 64;
+  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
+  for (uint64_t ch = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); ch < nchunks; ch += wstride) {
+    const uint64_t s = slot_lo + ch * 64 + (uint64_t)lane;
+    bool nn = false;
+    if (s < slot_lo + nslots) nn = v.items[s].value != 0;
+    const uint64_t occ = wv::ballot(nn);
+    const uint32_t nleaf = (logN >= 64) ? 1u : (64u >> sh);
+    if ((uint32_t)lane < nleaf) {
+      const uint64_t ls = slot_lo + ch * 64 + (uint64_t)lane * logN;
+      if (ls < slot_lo + nslots) {
+        const uint64_t sub = (logN >= 64) ? occ : ((occ >> ((uint32_t)lane * logN)) & ((1ull << logN) - 1ull));
+        v.leafcnt[ls >> sh] = (uint32_t)wv::popc64(sub);
+      }
+    }
+  }
+}
+
+// place the initial sentinels (constructor, PCSR.cpp:815-837): sentinel k sits at nodes[k].beginning
+PMA_KERNEL void k_place_sentinels(View v) {
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t k = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); k < v.g.n; k += stride) {
+    Edge e;
+    e.src = (uint32_t)k;
+    e.dest = kMax;
+    e.value = (k == 0) ? kMax : (uint32_t)k;
+    v.items[v.nodes[k].beginning] = e;
+  }
+}
+
+// exclusive prefix sum of leafcnt over [leaf_lo, leaf_lo + nleaves) -> rank[i]; three small kernels
+constexpr uint32_t kScanTile = 1024;  // leaves per workgroup
+PMA_KERNEL void k_scan_tiles(const uint32_t *cnt, uint64_t nleaves, uint32_t *tilesum) {
+  PMA_SHARED uint32_t red[4];
+  const uint64_t b = wv::block_idx();
+  uint32_t s = 0;
+  for (uint32_t i = wv::thread_idx(); i < kScanTile; i += wv::block_dim()) {
+    const uint64_t l = b * kScanTile + i;
+    if (l < nleaves) s += cnt[l];
+  }
+  s = wv::reduce_add(s);
+  if (wv::lane() == 0) red[wv::wave_in_block()] = s;
+  wv::block_sync();
+  if (wv::thread_idx() == 0) tilesum[b] = red[0] + red[1] + red[2] + red[3];
+}
+PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned long long *total) {
+  // single wave, serial over chunks of 64 (ntiles <= 2^31/ (8*1024) — tiny)
+  const int lane = wv::lane();
+  unsigned long long run = 0;
+  for (uint64_t base = 0; base < ntiles; base += 64) {
+    const uint64_t i = base + (uint64_t)lane;
+    uint32_t x = (i < ntiles) ? tilesum[i] : 0u;
+    // inclusive scan across lanes via shuffles
+    uint32_t incl = x;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
+      if (lane >= o) incl += y;
+    }
+    if (i < ntiles) tilesum[i] = (uint32_t)(run + incl - x);
+    run += wv::shfl(incl, 63);
+  }
+  if (lane == 0) *total = run;
+}
+PMA_KERNEL void k_scan_apply(const uint32_t *cnt, uint64_t nleaves, const uint32_t *tilesum, uint32_t *rank) {
+  PMA_SHARED uint32_t wsum[4];
+  const uint64_t b = wv::block_idx();
+  const int lane = wv::lane(), w = wv::wave_in_block();
+  uint32_t run = tilesum[b];
+  for (uint32_t it = 0; it < kScanTile / 256; it++) {
+    const uint64_t l = b * kScanTile + it * 256 + wv::thread_idx();
+    const uint32_t x = (l < nleaves) ? cnt[l] : 0u;
+    uint32_t incl = x;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[w] = incl;
+    wv::block_sync();
+    uint32_t woff = 0;
+    for (int q = 0; q < w; q++) woff += wsum[q];
+    if (l < nleaves) rank[l] = run + woff + incl - x;
+    run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    wv::block_sync();
+  }
+}
+
+PMA_KERNEL void k_chain_table(uint64_t index, uint64_t len, const unsigned long long *j, ChainTable *tb) {
+  if (wv::block_idx() == 0 && wv::thread_idx() == 0) build_chain_table(index, len, (uint64_t)*j, tb);
+}
+
+// Rebalance scatter: every live element of src window [src_lo, src_lo+src_len) goes to
+// dst[pos_k - dst_bias] where k = its rank among the live elements (rank[] = exclusive leaf prefix).
+// `v` carries the NEW geometry (n, N) for the sentinel back-pointers.
+PMA_KERNEL void k_scatter(View v, const Edge *src, uint64_t src_lo, uint64_t src_len, int src_sh, const uint32_t *rank,
+                          const ChainTable *tb, Edge *dst, uint64_t dst_bias) {
+  PMA_SHARED ChainTable stb;
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
+    uint32_t *s = reinterpret_cast<uint32_t *>(&stb);
+    for (uint32_t i = wv::thread_idx(); i < sizeof(ChainTable) / 4; i += wv::block_dim()) s[i] = g[i];
+  }
+  wv::block_sync();
+  const int lane = wv::lane();
+  const uint32_t slogN = 1u << src_sh;
+  const uint64_t nchunks = (src_len + 63) / 64;
+  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
+  int hint = 0;
+  for (uint64_t ch = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); ch < nchunks; ch += wstride) {
+    const uint64_t off = ch * 64 + (uint64_t)lane;
+    Edge e = null_edge();
+    if (off < src_len) e = src[src_lo + off];
+    const bool nn = e.value != 0;
+    const uint64_t m = wv::ballot(nn);
+    if (nn) {
+      const uint64_t lleaf = off >> src_sh;  // leaf index inside the window
+      uint64_t lmask;
+      if (slogN >= 64) {
+        lmask = ~0ull;
+      } else {
+        const uint32_t first = (uint32_t)(lane & ~(int)(slogN - 1));
+        lmask = ((1ull << slogN) - 1ull) << first;
+      }
+      const uint64_t k = (uint64_t)rank[lleaf] + (uint64_t)wv::popc64(m & lmask & ((1ull << lane) - 1ull));
+      const uint64_t pos = chain_pos(&stb, k, &hint);
+      dst[pos - dst_bias] = e;
+      dev::fix_sentinel(v, e, (uint32_t)pos);
+    }
+  }
+}
+
+PMA_KERNEL void k_copy_slots(const Edge *src, Edge *dst, uint64_t len) {
+  const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
+  uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+  const uint64_t total = len * 3ull;
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t i = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); i < total; i += stride) d[i] = s[i];
+}
+
+// ---- read-side kernels (get_neighbourhood PCSR.cpp:901-912, edge_exists :860-869) --------------------------
+PMA_KERNEL void k_edge_exists(View v, uint32_t src, uint32_t dst, ExclOut *out) {
+  dev::RangeRec rr;
+  rr.plan = nullptr;
+  rr.nr = 0;
+  uint32_t found = 0;
+  if (src < v.g.n) {
+    const Node nd = v.nodes[src];
+    const uint32_t loc = dev::pma_search(v, dst, nd.beginning + 1, nd.end, rr);
+    const Edge e = v.items[loc];
+    found = (!is_null(e) && !is_sentinel(e) && e.dest == dst) ? 1u : 0u;
+  }
+  if (wv::lane() == 0) {
+    out->found = found;
+    out->result = X_DONE;
+  }
+}
+
+// neighbours of one vertex: live dests in slots (beginning, end), in slot order; single workgroup of one wave
+PMA_KERNEL void k_neighbourhood(View v, uint32_t src, int *outbuf, uint64_t cap, unsigned long long *count) {
+  const int lane = wv::lane();
+  unsigned long long run = 0;
+  if (src < v.g.n) {
+    const Node nd = v.nodes[src];
+    for (uint64_t base = (uint64_t)nd.beginning + 1; base < (uint64_t)nd.end; base += 64) {
+      const uint64_t s = base + (uint64_t)lane;
+      Edge e = null_edge();
+      if (s < (uint64_t)nd.end) e = v.items[s];
+      const bool nn = e.value != 0;
+      const uint64_t m = wv::ballot(nn);
+      if (nn) {
+        const unsigned long long o = run + dev::lanemask_lt_count(m, lane);
+        if (outbuf && o < cap) outbuf[o] = (int)e.dest;
+      }
+      run += (unsigned long long)wv::popc64(m);
+    }
+  }
+  if (lane == 0) *count = run;
+}
+
+// bulk neighbour scan (CSR export): pass 1 counts live edges per 64-slot chunk (slot N-1 is never part of a
+// neighbourhood: the last vertex's end is N-1 exclusive), pass 2 (after an exclusive scan of the chunk counts)
+// writes dests in array order == CSR order and row offsets at the sentinels.
+PMA_KERNEL void k_scan_count(View v, uint32_t *chunkcnt) {
+  const int lane = wv::lane();
+  const uint64_t N = v.g.N;
+  const uint64_t nchunks = (N + 63) / 64;
+  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
+  for (uint64_t ch = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); ch < nchunks; ch += wstride) {
+    const uint64_t s = ch * 64 + (uint64_t)lane;
+    bool live = false;
+    if (s + 1 < N) {
+      const Edge e = v.items[s];
+      live = e.value != 0 && !is_sentinel(e);
+    }
+    const uint64_t m = wv::ballot(live);
+    if (lane == 0) chunkcnt[ch] = (uint32_t)wv::popc64(m);
+  }
+}
+PMA_KERNEL void k_scan_write(View v, const uint32_t *chunkoff, unsigned long long *row_offsets, int *dests, uint64_t cap) {
+  const int lane = wv::lane();
+  const uint64_t N = v.g.N;
+  const uint64_t nchunks = (N + 63) / 64;
+  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
+  for (uint64_t ch = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); ch < nchunks; ch += wstride) {
+    const uint64_t s = ch * 64 + (uint64_t)lane;
+    Edge e = null_edge();
+    if (s < N) e = v.items[s];
+    const bool nn = e.value != 0;
+    const bool sent = nn && is_sentinel(e);
+    const bool live = nn && !sent && (s + 1 < N);
+    const uint64_t m = wv::ballot(live);
+    const unsigned long long o = (unsigned long long)chunkoff[ch] + dev::lanemask_lt_count(m, lane);
+    if (live && o < cap) dests[o] = (int)e.dest;
+    if (sent) {
+      const uint32_t vid = (e.value == kMax) ? 0u : e.value;
+      row_offsets[vid] = o;
+    }
+  }
+}
+
+}  // namespace ppcsr

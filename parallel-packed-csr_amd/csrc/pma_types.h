@@ -1,0 +1,119 @@
+// Core types of the MI355X packed-memory-array engine (shared by host and device code).
+//
+// HBM layout (bit-identical to the reference's in-memory layout so that state export is a
+// plain copy and parity is checked byte-for-byte):
+//   items[N]   : 12-byte AoS slots {src, dest, value}            (reference edge_t, PCSR.h:30-35)
+//   nodes[n]   : 12-byte {beginning, end, num_neighbors}          (reference node_t, PCSR.h:18-23)
+// Auxiliary device-only arrays (derived state, never exported):
+//   leafcnt[N/logN] : live slots per PMA leaf   (replaces the reference's get_density rescans,
+//                                                PCSR.cpp:126-133; same values, no re-reading)
+//   wres/rres[N/logN] : per-leaf write/read reservations of the current scheduling round
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PMA_HD __host__ __device__
+#else
+#define PMA_HD
+#endif
+
+namespace ppcsr {
+
+struct Edge {
+  uint32_t src, dest, value;
+};
+struct Node {
+  uint32_t beginning, end, num_neighbors;
+};
+struct Op {  // op == 0: delete (src,dst); op != 0: add (src,dst) with edge value `op`
+  uint32_t src, dst, op;
+};
+
+constexpr uint32_t kMax = 0xFFFFFFFFu;
+constexpr int kMaxLevels = 36;
+constexpr uint32_t kNever = 0xFFFFFFFFu;
+
+// Geometry of the implicit calibrator tree + integer density thresholds.
+// Level L in [0,H]: window length len(L) = logN << (H - L)  (level H = leaf, level 0 = root).
+//   insert climbs while  count + 1 >= t_up[L]   <=>  count/len + 1/len >= 3/4 + (.25*L)/H   (PCSR.cpp:1026-1028,163)
+//   remove climbs while  count - 1 <  t_lo[L]   <=>  count/len - 1/len <  1/4 - (.125*L)/H  (PCSR.cpp:1193-1197,162)
+// (densities are exact dyadic rationals, so the fp64 comparisons of the reference reduce to
+//  integer comparisons against thresholds computed once on the host with the same fp64 expressions)
+struct Geometry {
+  uint64_t N;
+  uint32_t n;
+  int logN, sh, H;
+  int lock_search;
+  uint32_t t_up[kMaxLevels];
+  uint32_t t_lo[kMaxLevels];
+};
+
+PMA_HD inline bool is_null(const Edge &e) { return e.value == 0; }
+PMA_HD inline bool is_sentinel(const Edge &e) { return e.dest == kMax || e.value == kMax; }  // PCSR.cpp:64
+PMA_HD inline Edge null_edge() { return Edge{kMax, 0u, 0u}; }
+
+// ---- per-op plan produced by the plan phase and consumed by check/apply ---------------------------
+enum Kind : uint32_t {
+  K_NOOP = 0,      // add with src >= n (silently ignored, PCSR.cpp:1375)
+  K_INSERT = 1,    // new edge: optional slide, write, one window rebalance
+  K_DUP = 2,       // edge exists: overwrite value only (PCSR.cpp:529-532)
+  K_REMOVE = 3,    // edge found: null the slot, one window rebalance
+  K_NOTFOUND = 4,  // delete of a missing edge: only num_neighbors-- (PCSR.cpp:747-754)
+  K_EXCL = 5,      // must run alone through the exclusive executor (global path, resize, big window)
+};
+
+constexpr int kMaxR = 40;  // read-leaf ranges recorded per op (<= 32 search iterations + a few)
+
+struct Plan {
+  uint32_t kind;
+  uint32_t index;             // slot returned by the gap-aware search
+  uint32_t gap;               // first null slot at or right of index (== index if items[index] is null)
+  uint32_t wstart, wlen;      // the single window rebalance that the op performs
+  uint32_t wleaf_lo, wleaf_hi;  // inclusive leaf range written (slide + window)
+  uint32_t alg_calls, alg_slots;  // redistribute() calls / slots the reference performs for this op
+  uint32_t nr;
+  uint32_t rlo[kMaxR], rhi[kMaxR];  // inclusive leaf ranges read by the search / vertex range lookup
+};
+
+// scheduler control block (device memory, mirrored to pinned host memory between round chunks)
+struct Control {
+  uint32_t base[2];      // stream position of the first pending op, double-buffered by round parity
+  uint32_t horizon[2];   // ops planned this round
+  uint32_t failmin[2];   // smallest stream index that failed its reservation check
+  uint32_t n_ops;
+  uint32_t excl;         // 1: the op at base[] needs the exclusive executor
+  uint32_t error;        // sticky device-side error code
+  uint32_t max_horizon;
+  // statistics (monotone counters)
+  unsigned long long rounds, committed, planned;
+  unsigned long long redistribute_calls, redistribute_slots;  // algorithmic: what the reference would do
+  unsigned long long not_found, duplicates, noops;
+  unsigned long long slide_slots;
+};
+
+// result of the exclusive executor
+enum ExclResult : uint32_t {
+  X_DONE = 0,
+  X_NEED_DOUBLE = 1,        // double_list() completes the op (PCSR.cpp:570-572, 586-588)
+  X_NEED_HALF = 2,          // half_list() completes the op (PCSR.cpp:624-626)
+  X_NEED_REDIST = 3,        // host must run the multi-workgroup window rebalance on (wstart,wlen)
+  X_DOUBLE_THEN_RETRY = 4,  // slot N-1 occupied: double_list(), re-search, insert(..., nullptr) (PCSR.cpp:533-540)
+  X_UNSUPPORTED = 5,        // slide ran off both ends (reference: PCSR.cpp:347-351, 378-383) — never observed
+};
+struct ExclOut {
+  uint32_t result;
+  uint32_t wstart, wlen;
+  uint32_t found;  // edge_exists / misc
+};
+
+enum ErrorCode : int {
+  PPCSR_OK = 0,
+  PPCSR_EINVAL = 1,
+  PPCSR_ENOMEM = 2,
+  PPCSR_EHIP = 3,
+  PPCSR_EUNSUPPORTED = 4,
+  PPCSR_EINTERNAL = 5,
+  PPCSR_ERANGE = 6,
+};
+
+}  // namespace ppcsr

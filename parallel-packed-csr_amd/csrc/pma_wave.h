@@ -1,0 +1,44 @@
+// Wavefront primitives used by the PMA kernels.  Product build: gfx950 intrinsics (wave64).
+// When PPCSR_SIM is defined (tests/hostsim only — never in the shipped library) the same names are
+// provided by a single-threaded fiber SIMT emulator so the kernel source can be debugged on CPU.
+#pragma once
+#include "pma_types.h"
+
+#if defined(PPCSR_SIM)
+#include "sim_runtime.h"
+#else
+#include <hip/hip_runtime.h>
+#define PMA_DEV __device__ __forceinline__
+#define PMA_KERNEL __global__
+#define PMA_SHARED __shared__
+
+namespace ppcsr {
+namespace wv {
+PMA_DEV int lane() { return (int)(threadIdx.x & 63u); }
+PMA_DEV int wave_in_block() { return (int)(threadIdx.x >> 6); }
+PMA_DEV uint64_t ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
+PMA_DEV uint32_t shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+PMA_DEV uint32_t first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+PMA_DEV uint32_t reduce_add(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+  return v;
+}
+// orders this wave's LDS + global accesses among its own lanes (same CU: L1 is shared)
+PMA_DEV void fence() { __threadfence_block(); }
+PMA_DEV void block_sync() { __syncthreads(); }
+PMA_DEV uint32_t atomic_min_u32(uint32_t *p, uint32_t v) { return atomicMin(p, v); }
+PMA_DEV unsigned long long atomic_min_u64(unsigned long long *p, unsigned long long v) { return atomicMin(p, v); }
+PMA_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+PMA_DEV unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
+PMA_DEV uint32_t atomic_max_u32(uint32_t *p, uint32_t v) { return atomicMax(p, v); }
+PMA_DEV uint32_t atomic_exch_u32(uint32_t *p, uint32_t v) { return atomicExch(p, v); }
+PMA_DEV int popc64(uint64_t m) { return __popcll((unsigned long long)m); }
+PMA_DEV int ctz64(uint64_t m) { return __ffsll((long long)m) - 1; }
+PMA_DEV uint32_t block_idx() { return blockIdx.x; }
+PMA_DEV uint32_t thread_idx() { return threadIdx.x; }
+PMA_DEV uint32_t block_dim() { return blockDim.x; }
+PMA_DEV uint32_t grid_dim() { return gridDim.x; }
+}  // namespace wv
+}  // namespace ppcsr
+#endif

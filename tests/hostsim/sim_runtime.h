@@ -1,0 +1,54 @@
+// TEST INFRASTRUCTURE ONLY.  A single-threaded fiber SIMT emulator: every GPU thread is a fiber,
+// a workgroup's fibers are scheduled round-robin and rendezvous at wave collectives (ballot / shfl /
+// reduce) and at block barriers.  It exists so the *actual kernel source* of the engine can be debugged
+// on a machine without a GPU.  The shipped library (libppcsr_hip.so) never contains this code; the
+// sim build is a separate .so that only tests/ load explicitly.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <functional>
+
+#define PMA_DEV inline
+#define PMA_KERNEL
+#define PMA_SHARED static
+
+namespace sim {
+struct Fiber;
+extern Fiber *cur;
+int cur_tid();
+int cur_block();
+int cur_block_dim();
+int cur_grid_dim();
+uint64_t ballot(bool p);
+uint64_t shfl64(uint64_t v, int src);
+uint64_t reduce_add64(uint64_t v);
+void block_sync();
+void launch(uint32_t grid, uint32_t block, const std::function<void()> &body);
+}  // namespace sim
+
+namespace ppcsr {
+namespace wv {
+inline int lane() { return sim::cur_tid() & 63; }
+inline int wave_in_block() { return sim::cur_tid() >> 6; }
+inline uint64_t ballot(bool p) { return sim::ballot(p); }
+inline uint32_t shfl(uint32_t v, int src) { return (uint32_t)sim::shfl64(v, src); }
+inline uint32_t first(uint32_t v) { return v; }  // callers only pass wave-uniform values
+inline uint32_t reduce_add(uint32_t v) { return (uint32_t)sim::reduce_add64(v); }
+inline void fence() { (void)sim::shfl64(0, 0); }  // lanes run sequentially between collectives: a fence must be a rendezvous
+inline void block_sync() { sim::block_sync(); }
+inline uint32_t atomic_min_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
+inline unsigned long long atomic_min_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
+inline uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+inline unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+inline uint32_t atomic_max_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
+inline uint32_t atomic_exch_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
+inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
+inline int ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
+inline uint32_t block_idx() { return (uint32_t)sim::cur_block(); }
+inline uint32_t thread_idx() { return (uint32_t)sim::cur_tid(); }
+inline uint32_t block_dim() { return (uint32_t)sim::cur_block_dim(); }
+inline uint32_t grid_dim() { return (uint32_t)sim::cur_grid_dim(); }
+}  // namespace wv
+}  // namespace ppcsr

@@ -1,0 +1,179 @@
+"""GPU (MI355X): bit-exact parity of the HIP engine, driven through the C ABI, against
+(a) the golden fixtures generated from the real reference and (b) the oracle on seeded streams.
+Integer / index work: the bar is byte-for-byte equality of edges[] and nodes[]."""
+import numpy as np
+import pytest
+
+from helpers import GOLDEN_SINGLE, digest, golden, load_pkg, replay_golden
+from oracle_lib import Oracle, OraclePPPCSR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_pkg()
+    p.load_library()  # must be the in-tree HIP build; raises if missing
+    return p
+
+
+def _same(eng, o, label=""):
+    assert eng.geometry() == o.geometry(), f"{label}: geometry {eng.geometry()} vs {o.geometry()}"
+    ei, en = eng.state()
+    oi, on = o.state()
+    if not np.array_equal(en, on):
+        bad = np.nonzero((en != on).any(1))[0]
+        raise AssertionError(f"{label}: nodes[] differ at {bad[:8]}: {en[bad[:4]]} vs {on[bad[:4]]}")
+    if not np.array_equal(ei, oi):
+        bad = np.nonzero((ei != oi).any(1))[0]
+        raise AssertionError(f"{label}: edges[] differ at {len(bad)} slots, first {bad[:8]}")
+    assert eng.check_invariants() == 0, label
+
+
+def _stats_match(eng, o):
+    se, so = eng.stats(), o.stats()
+    for k in ("redistribute_calls", "redistribute_slots", "double_calls", "half_calls", "not_found", "duplicates"):
+        assert se[k] == so[k], (k, se[k], so[k])
+
+
+@pytest.mark.parametrize("name", GOLDEN_SINGLE)
+def test_golden(pkg, name):
+    eng = replay_golden(lambda n, lock: pkg.PCSR(n, lock_search=lock), name)
+    assert eng.check_invariants() == 0
+
+
+def test_golden_one_op_at_a_time(pkg):
+    """same fixture through the single-op entry points (add_edge / remove_edge)"""
+    g = golden("add_node_empty_then_edges")
+    eng = pkg.PCSR(0)
+    for _ in range(5):
+        eng.add_node()
+    for s, d, op in g["ops"]:
+        if op:
+            eng.add_edge(int(s), int(d), int(op))
+        else:
+            eng.remove_edge(int(s), int(d))
+    items, nodes = eng.state()
+    assert digest(items, nodes, eng.geometry()) == str(g["digests"][-1])
+
+
+def test_pppcsr_golden(pkg):
+    g = golden("pppcsr_p8_n1000")
+    pp = pkg.PPPCSR(1000, numDomain=1, partitionsPerDomain=8)
+    assert pp.num_partitions() == 8
+    np.testing.assert_array_equal([pp.get_partiton(v) for v in range(0, 1000, 7)], g["part_of_vertex"][::7])
+    pp.apply(g["ops"])
+    for k in range(8):
+        p = pp.partition(k)
+        assert p.get_n() == int(g["sizes"][k])
+        items, nodes = p.state()
+        assert digest(items, nodes, p.geometry()) == str(g["digests"][k]), f"partition {k}"
+    assert pp.get_n() == 1000
+
+
+@pytest.mark.parametrize("seed,n", [(0, 30), (1, 300), (2, 3000), (3, 20000), (4, 100000)])
+@pytest.mark.parametrize("lock", [True, False])
+def test_random_mixed_vs_oracle(pkg, streams, seed, n, lock):
+    core = streams.random_stream(n, 60000, seed=100 + seed)
+    fresh = streams.random_stream(n, 20000, seed=200 + seed)
+    ops = np.concatenate([core, streams.mixed_existing_stream(core, fresh, seed=300 + seed)])
+    eng, o = pkg.PCSR(n, lock_search=lock), Oracle(n, lock_search=lock)
+    for lo in range(0, len(ops), 25000):
+        eng.apply(ops[lo:lo + 25000])
+        o.apply(ops[lo:lo + 25000])
+        _same(eng, o, f"seed {seed} after {lo + 25000}")
+    _stats_match(eng, o)
+
+
+def test_hubs_and_last_vertex(pkg, streams):
+    m = 20000
+    for src_mode in ("last", "first", "tail"):
+        hub = np.stack([np.full(m, 9), streams.uniform_ints(3, m, 1 << 30), np.ones(m)], 1).astype(np.uint32)
+        if src_mode == "first":
+            hub[:, 0] = 0
+        elif src_mode == "tail":
+            hub[:, 0] = streams.uniform_ints(4, m, 3) + 7
+        dele = hub.copy()
+        dele[:, 2] = 0
+        ops = np.concatenate([hub, dele[::-1]])
+        eng, o = pkg.PCSR(10), Oracle(10)
+        eng.apply(ops)
+        o.apply(ops)
+        _same(eng, o, src_mode)
+        _stats_match(eng, o)
+
+
+def test_ascending_and_descending_runs(pkg):
+    """long slides (descending dests) and end-of-array inserts (ascending dests into the last vertex)"""
+    m = 12000
+    for order in ("asc", "desc"):
+        d = np.arange(m) + 5 if order == "asc" else np.arange(m, 0, -1) + 5
+        ops = np.stack([np.full(m, 9), d, np.ones(m)], 1).astype(np.uint32)
+        eng, o = pkg.PCSR(10), Oracle(10)
+        eng.apply(ops)
+        o.apply(ops)
+        _same(eng, o, order)
+
+
+def test_rmat_core_plus_updates(pkg, streams):
+    s, d = streams.rmat_edges(16, 600000, seed=1)
+    core = streams.adds(s, d)
+    s2, d2 = streams.rmat_edges(16, 100000, seed=2)
+    upd = streams.mixed_existing_stream(core, streams.adds(s2, d2), seed=3)
+    n = 1 << 16
+    eng, o = pkg.PCSR(n), Oracle(n)
+    eng.apply(core)
+    o.apply(core)
+    _same(eng, o, "core")
+    eng.apply(upd)
+    o.apply(upd)
+    _same(eng, o, "updates")
+    _stats_match(eng, o)
+    # neighbour lists and the bulk scan (get_neighbourhood for all vertices)
+    rows, dests = eng.scan_all()
+    for v in list(range(0, 64)) + list(range(64, n, 997)) + [n - 1]:
+        ref = o.get_neighbourhood(v)
+        np.testing.assert_array_equal(eng.get_neighbourhood(v), ref)
+        np.testing.assert_array_equal(dests[int(rows[v]):int(rows[v + 1])], ref)
+    items, _ = o.state()
+    live = (items[:, 2] != 0) & (items[:, 1] != 0xFFFFFFFF)
+    live[-1] = False
+    assert rows[-1] == live.sum()
+
+
+def test_api_semantics(pkg):
+    """DataStructureTest.cpp:12-49 restated against the HIP engine (through PPPCSR with one partition)"""
+    p = pkg.PPPCSR(10, numDomain=1, partitionsPerDomain=1)
+    assert p.get_n() == 10
+    p.add_edge(11, 1, 1)  # no such source: silently ignored
+    p.add_edge(0, 1, 1)
+    assert p.edge_exists(0, 1)
+    assert len(p.get_neighbourhood(0)) == 1 and len(p.get_neighbourhood(2)) == 0
+    p.add_node()
+    assert p.get_n() == 11
+    p.remove_edge(0, 1)
+    assert not p.edge_exists(0, 1)
+    p.remove_edge(0, 1)  # miss
+    assert p.getNode(0)[2] == 0xFFFFFFFF  # num_neighbors underflow quirk (PCSR.cpp:747)
+    e = pkg.PPPCSR(0, numDomain=1, partitionsPerDomain=1)
+    assert e.get_n() == 0
+    e.add_node()
+    assert e.get_n() == 1 and len(e.get_neighbourhood(0)) == 0
+    assert len(p.get_neighbourhood(500)) == 0  # out of range source -> empty (PCSR.cpp:903)
+
+
+def test_seq_stress_edge_exists(pkg):
+    """add_remove_edge_1E4_seq (DataStructureTest.cpp:51-79), with edge_exists sampled"""
+    eng = pkg.PCSR(10)
+    m = 10000
+    ins = np.stack([np.zeros(m), np.arange(1, m + 1), np.arange(1, m + 1)], 1).astype(np.uint32)
+    eng.apply(ins)
+    assert eng.getNode(0)[2] == m
+    for i in (1, 2, 777, 5000, m):
+        assert eng.edge_exists(0, i)
+    assert not eng.edge_exists(0, m + 1)
+    dele = ins.copy()
+    dele[:, 2] = 0
+    eng.apply(dele)
+    assert len(eng.get_neighbourhood(0)) == 0 and eng.get_n() == 10
+    assert not eng.edge_exists(0, 5)
