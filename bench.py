@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py — edge-updates/s of the MI355X PMA engine on BASELINE.json's workloads.
+
+One "step" = one pass of the hot path over one batch of synthetic updates already resident in HBM:
+  N = 1 : config #2 — RMAT scale-20 core graph (10 M edges, a/b/c = .57/.19/.19), single partition,
+          each step applies a fresh batch of 1 M RMAT inserts (or --mixed: config #3, 50/50 insert +
+          delete of existing core edges) in stream order.
+  N > 1 : configs #4/#5 shape, weak scaling — N * 2^20 vertices, N * 10 M core edges, N * 1 M updates per
+          step; every rank owns one vertex-range partition (PPPCSR.cpp:13-34 rule), holds a contiguous
+          block of the global stream, buckets it by owner (stable) and exchanges buckets with one RCCL
+          all-to-all; the receiver concatenates in source-rank order == global stream order.
+Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+Prints ONE JSON line on rank 0 (see DESIGN.md §6 for the field definitions).
+"""
+import argparse
+import ctypes
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _load(name, path, pkg=False):
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(
+        name, path, submodule_search_locations=[os.path.dirname(path)] if pkg else None)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def gen_block(streams, kind, scale, count, seed, offset, n_global, permute, core=None, mixed_seed=0):
+    """counter-based block [offset, offset+count) of the global stream `seed`"""
+    s, d = streams.rmat_edges(scale, count, seed=seed, offset=offset)
+    if permute:
+        s = streams.permute_labels(s, n_global)
+        d = streams.permute_labels(d, n_global)
+    ops = streams.adds(s, d)
+    if kind == "mixed":
+        half = count // 2
+        ops = streams.mixed_existing_stream(core, ops[:half], seed=mixed_seed)
+    return ops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scale", type=int, default=20, help="RMAT scale per GPU")
+    ap.add_argument("--core-edges", type=int, default=10_000_000, help="core edges per GPU")
+    ap.add_argument("--batch", type=int, default=1_000_000, help="updates per GPU per step")
+    ap.add_argument("--mixed", action="store_true", help="config #3: alternate insert / delete-existing")
+    ap.add_argument("--labels", choices=["permuted", "raw"], default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket round kernels with HIP events")
+    ap.add_argument("--max-horizon", type=int, default=0)
+    ap.add_argument("--rounds-per-sync", type=int, default=0)
+    ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (slow)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    P = args.gpus
+    if world != P:
+        raise SystemExit(f"--gpus {P} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {P}")
+    if not torch.cuda.is_available():
+        raise SystemExit("no GPU: the engine is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if P > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    pkg = _load("ppcsr_amd", os.path.join(ROOT, "parallel-packed-csr_amd", "__init__.py"), pkg=True)
+    streams = _load("ppcsr_streams", os.path.join(ROOT, "parallel-packed-csr_amd", "streams.py"))
+    exch = _load("ppcsr_exchange", os.path.join(ROOT, "parallel-packed-csr_amd", "exchange.py"))
+    pkg.load_library()  # in-tree HIP build; raises if missing
+
+    gscale = args.scale + int(np.log2(P))
+    assert (1 << (gscale - args.scale)) == P, "--gpus must be a power of two"
+    n_global = 1 << gscale
+    permute = (args.labels or ("permuted" if P > 1 else "raw")) == "permuted"
+    starts, sizes = exch.partition_layout(n_global, P)
+    my_n = int(sizes[rank])
+    kind = "mixed" if args.mixed else "insert"
+
+    t0 = time.time()
+    core_blk = gen_block(streams, "insert", gscale, args.core_edges, 1, rank * args.core_edges, n_global, permute)
+    nsteps = args.warmup + args.steps + (0 if args.no_profile else 0)
+    upd = []
+    for k in range(nsteps):
+        upd.append(gen_block(streams, kind, gscale, args.batch, 2 + 10 * k, rank * args.batch, n_global, permute,
+                             core=core_blk, mixed_seed=3 + 10 * k))
+    log(rank, f"generated core {len(core_blk)} + {nsteps} x {args.batch} updates per rank in {time.time() - t0:.1f}s "
+              f"(n_global={n_global}, labels={'permuted' if permute else 'raw'})")
+
+    eng = pkg.PCSR(my_n, device=local_rank)
+    if args.max_horizon:
+        eng.set_option("max_horizon", args.max_horizon)
+    if args.rounds_per_sync:
+        eng.set_option("rounds_per_sync", args.rounds_per_sync)
+
+    def to_dev(a):
+        return torch.from_numpy(a.view(np.int32)).to(dev)
+
+    def run_step(ops_dev):
+        """bucket by owner + all-to-all (N > 1), then apply in stream order on this rank's partition"""
+        if P > 1:
+            mine = exch.exchange_ops(ops_dev, n_global, P, dist.group.WORLD)
+        else:
+            mine = ops_dev
+        if mine.shape[0]:
+            eng.apply_device(mine.data_ptr(), mine.shape[0])
+        return mine.shape[0]
+
+    # ---- core load (untimed) ----
+    t0 = time.time()
+    core_dev = to_dev(core_blk)
+    run_step(core_dev)
+    torch.cuda.synchronize()
+    del core_dev
+    st = eng.stats()
+    log(rank, f"core loaded in {time.time() - t0:.1f}s: N={st['N']} logN={st['logN']} rounds={st['rounds']} "
+              f"exclusive={st['exclusive_ops']} doubles={st['double_calls']}")
+
+    upd_dev = [to_dev(u) for u in upd]
+    for k in range(args.warmup):
+        run_step(upd_dev[k])
+    torch.cuda.synchronize()
+
+    if not args.no_profile:
+        eng.set_option("profile", 1)
+    s0 = eng.stats()
+    if P > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    applied = 0
+    for k in range(args.warmup, args.warmup + args.steps):
+        applied += run_step(upd_dev[k])
+    torch.cuda.synchronize()
+    if P > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    s1 = eng.stats()
+    if P > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_updates = args.batch * P * args.steps
+    value = total_updates / elapsed
+
+    # ---- roofline of the dominant round kernel, from HIP events on the engine's stream over the timed region ----
+    roofline = None
+    kern = {}
+    if not args.no_profile:
+        launches = s1["prof_launches"]
+        kern = {"k_plan": s1["prof_plan_ms"], "k_check": s1["prof_check_ms"], "k_apply": s1["prof_apply_ms"]}
+        dom = max(kern, key=kern.get)
+        d = {k: s1[k] - s0[k] for k in ("redistribute_slots", "redistribute_calls", "committed", "rounds", "planned",
+                                         "exclusive_ops", "ops_applied")}
+        # algorithmic bytes: 12 B op record + 24 B per slot of every redistribute() the reference makes
+        alg_bytes = 12.0 * d["ops_applied"] + 24.0 * d["redistribute_slots"]
+        avg_ms = kern[dom] / max(launches, 1)
+        achieved = (alg_bytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "launches": int(launches), "avg_launch_us": avg_ms * 1e3,
+                    "alg_bytes_per_launch": alg_bytes / max(launches, 1),
+                    "alg_bytes_per_update": alg_bytes / max(d["ops_applied"], 1),
+                    "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
+                    "rounds": int(d["rounds"]), "updates_per_round": d["committed"] / max(d["rounds"], 1),
+                    "planned_per_committed": d["planned"] / max(d["committed"], 1),
+                    "exclusive_ops": int(d["exclusive_ops"])}
+        eng.set_option("profile", 0)
+
+    # ---- secondary kernels: bulk neighbour scan + whole-window rebalance (HBM-roofline kernels) ----
+    extra = {}
+    if rank == 0:
+        try:
+            ms, tot = eng.bench_scan_all()
+            ms, tot = eng.bench_scan_all()
+            stt = eng.stats()
+            scan_bytes = 12.0 * stt["N"] + 12.0 * stt["n"] + 4.0 * tot
+            extra["neighbour_scan"] = {"edges_per_s": tot / (ms * 1e-3), "ms": ms, "edges": int(tot),
+                                       "alg_GBps": scan_bytes / (ms * 1e-3) / 1e9,
+                                       "frac_of_peak": scan_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            w = int(stt["N"])
+            rms = eng.bench_rebalance(w, 3)
+            extra["window_rebalance"] = {"window_slots": w, "ms_per_call_host": rms,
+                                         "alg_GBps": 24.0 * w / (rms * 1e-3) / 1e9,
+                                         "frac_of_peak": 24.0 * w / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        except Exception as e:  # never let a secondary measurement kill the headline
+            extra["secondary_error"] = str(e)
+
+    # ---- CPU baseline beside it (rank 0, N == 1): the reference (oracle/_ref) or the oracle port, 1 thread ----
+    cpu = None
+    if rank == 0 and P == 1 and not args.no_cpu_baseline:
+        from oracle_lib import Oracle, RefPCSR, have_ref
+        kindc = "reference" if have_ref() else "port"
+        Cls = RefPCSR if have_ref() else Oracle
+        c = Cls(my_n)
+        tl = time.time()
+        c.apply(core_blk)
+        tl = time.time() - tl
+        for k in range(args.warmup):
+            c.apply(upd[k])
+        tc = time.time()
+        c.apply(upd[args.warmup])
+        tc = time.time() - tc
+        cpu = {"value": len(upd[args.warmup]) / tc, "unit": "edge-updates/s", "cores": 1, "kind": kindc,
+               "sample": f"same {args.core_edges}-edge core ({tl:.1f}s load, untimed) + the first timed batch of "
+                         f"{len(upd[args.warmup])} updates in stream order on one host thread ({tc:.2f}s)"}
+        if args.check:
+            c2 = Oracle(my_n)
+            c2.apply(core_blk)
+            for u in upd:
+                c2.apply(u)
+            ei, en = eng.state()
+            oi, on = c2.state()
+            assert eng.geometry() == c2.geometry() and np.array_equal(ei, oi) and np.array_equal(en, on), "PARITY FAILURE"
+            extra["parity_checked"] = True
+        c.close()
+
+    if rank == 0:
+        out = {
+            "metric": "edge-updates/sec", "value": value, "unit": "edge-updates/s", "n_gpus": P, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": ("config#3 mixed 50/50 insert+delete" if args.mixed else "config#2 1M random inserts")
+                       + f" on RMAT scale-{args.scale} / {args.core_edges}-edge core per GPU"
+                       + (f", {P} vertex-range partitions, labels {'permuted' if permute else 'raw'}, RCCL all-to-all" if P > 1 else ", 1 partition"),
+                       "vertices": n_global, "core_edges": args.core_edges * P, "updates_per_step": args.batch * P,
+                       "parallelism": f"partition-per-gpu x{P}", "N_slots": int(s1["N"]), "logN": int(s1["logN"]),
+                       "semantics": "sequential stream order (bit-exact vs reference -threads=1)"},
+            "roofline": roofline, "cpu_baseline": cpu, **extra,
+        }
+        print(json.dumps(out), flush=True)
+    if P > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,9 @@ typedef struct {
   uint64_t ops_applied;
   double last_batch_ms;     /* device-only time of the last batch (ops already in HBM)  */
   double last_batch_h2d_ms; /* H2D time of the op array when it came from a host buffer */
+  /* option "profile"=1: HIP-event time spent in each round kernel, measured on the engine's own stream */
+  double prof_plan_ms, prof_check_ms, prof_apply_ms;
+  uint64_t prof_launches; /* launches of each of the three round kernels */
 } ppcsr_stats_t;
 
 /* PCSR::PCSR(init_n, src_n, lock_search, domain)  — PCSR.cpp:775-838; `device` replaces the NUMA domain */
@@ -88,7 +91,7 @@ int ppcsr_scan_all(ppcsr_t h, uint64_t *row_offsets, int *dests, uint64_t cap, u
 /* raw state for parity checks: items[N], nodes[n] exactly as the reference holds them (PCSR.h:67,128) */
 int ppcsr_export_state(ppcsr_t h, ppcsr_edge *items, ppcsr_node *nodes);
 int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out);
-/* tuning knobs: "max_horizon", "min_horizon", "init_horizon", "rounds_per_sync" */
+/* tuning knobs: "max_horizon", "min_horizon", "init_horizon", "rounds_per_sync", "profile" */
 int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value);
 /* debugging / measurement helpers */
 int ppcsr_check_invariants(ppcsr_t h, uint64_t *bad_leaves);

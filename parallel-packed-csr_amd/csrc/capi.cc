@@ -120,6 +120,8 @@ int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out) {
   out->double_calls = s.double_calls; out->half_calls = s.half_calls; out->big_redistributes = s.big_redistributes;
   out->not_found = s.not_found; out->duplicates = s.duplicates; out->noops = s.noops; out->slide_slots = s.slide_slots;
   out->ops_applied = s.ops_applied; out->last_batch_ms = s.last_batch_ms; out->last_batch_h2d_ms = s.last_batch_h2d_ms;
+  out->prof_plan_ms = s.prof_plan_ms; out->prof_check_ms = s.prof_check_ms; out->prof_apply_ms = s.prof_apply_ms;
+  out->prof_launches = s.prof_launches;
   return 0;
 }
 int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value) { H_CHECK(); return ret(h->e, h->e->set_option(key, value)); }

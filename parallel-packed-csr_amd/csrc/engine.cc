@@ -53,7 +53,9 @@ struct Engine::Impl {
   uint32_t max_horizon = 4096, min_horizon = 64, rounds_per_sync = 16, init_horizon = 256;
   gpu::Timer timer;
   EngineStats st{};
-  bool partial = false;  // init failed half-way: destructor frees only what exists
+  bool partial = false;
+  bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
+  std::vector<gpu::Event> events;  // init failed half-way: destructor frees only what exists
 };
 
 Engine::Engine() : p_(new Impl()) {}
@@ -173,6 +175,7 @@ Engine::~Engine() {
   if (p.d_rank) gpu::dfree(p.d_rank);
   if (p.d_tiles) gpu::dfree(p.d_tiles);
   if (p.d_nbr) gpu::dfree(p.d_nbr);
+  for (auto &e : p.events) e.destroy();
   p.timer.destroy();
   gpu::stream_destroy(p.stream);
   delete p_;
@@ -202,6 +205,12 @@ int Engine::set_option(const char *key, int64_t value) {
   if (k == "init_horizon") {
     if (value < 1) return fail(PPCSR_EINVAL, "init_horizon out of range");
     p.init_horizon = (uint32_t)std::min<int64_t>(value, p.max_horizon);
+    return PPCSR_OK;
+  }
+  if (k == "profile") {
+    p.profile = value != 0;
+    p.st.prof_plan_ms = p.st.prof_check_ms = p.st.prof_apply_ms = 0;
+    p.st.prof_launches = 0;
     return PPCSR_OK;
   }
   if (k == "rounds_per_sync") {
@@ -281,15 +290,32 @@ int Engine::run_rounds(const Op *d_ops, uint64_t n) {
       a.stats = p.d_stats;
       a.min_horizon = p.min_horizon;
       const uint32_t blocks = (p.max_horizon + 3) / 4;
+      if (p.profile && p.events.size() < 4ull * p.rounds_per_sync) {
+        const size_t old = p.events.size();
+        p.events.resize(4ull * p.rounds_per_sync);
+        for (size_t i = old; i < p.events.size(); i++) GCHK(p.events[i].init());
+      }
       for (uint32_t r = 0; r < p.rounds_per_sync; r++) {
         a.round = ++p.round;
+        if (p.profile) p.events[4 * r + 0].record(p.stream);
         GPU_LAUNCH(p.stream, k_plan, blocks, 256, a);
+        if (p.profile) p.events[4 * r + 1].record(p.stream);
         GPU_LAUNCH(p.stream, k_check, blocks, 256, a);
+        if (p.profile) p.events[4 * r + 2].record(p.stream);
         GPU_LAUNCH(p.stream, k_apply, blocks, 256, a);
+        if (p.profile) p.events[4 * r + 3].record(p.stream);
       }
       GCHK(gpu::d2h(p.h_ctl, p.d_ctl, sizeof(Control), p.stream));
       GCHK(gpu::sync(p.stream));
       GCHK(gpu::last_error());
+      if (p.profile) {
+        for (uint32_t r = 0; r < p.rounds_per_sync; r++) {
+          p.st.prof_plan_ms += gpu::Event::elapsed_ms(p.events[4 * r + 0], p.events[4 * r + 1]);
+          p.st.prof_check_ms += gpu::Event::elapsed_ms(p.events[4 * r + 1], p.events[4 * r + 2]);
+          p.st.prof_apply_ms += gpu::Event::elapsed_ms(p.events[4 * r + 2], p.events[4 * r + 3]);
+          p.st.prof_launches += 1;
+        }
+      }
       p.st.round_syncs++;
       if (c.error) return fail(PPCSR_EINTERNAL, "device-side error " + std::to_string(c.error));
       const uint32_t npar = (p.round + 1) & 1u;

@@ -22,6 +22,9 @@ struct EngineStats {
   uint64_t ops_applied;
   double last_batch_ms;      // device-only time of the last apply_batch (ops resident in HBM)
   double last_batch_h2d_ms;  // time of the H2D copy of the op array (host-buffer entry point)
+  // profile mode (option "profile"=1): HIP-event time of each round kernel on the engine's stream
+  double prof_plan_ms, prof_check_ms, prof_apply_ms;
+  uint64_t prof_launches;  // launches of EACH of the three kernels
 };
 
 class Engine {

@@ -36,6 +36,13 @@ struct Timer {
   void stop(stream_t) { b = std::chrono::steady_clock::now(); }
   double ms() { return std::chrono::duration<double, std::milli>(b - a).count(); }
 };
+struct Event {
+  std::chrono::steady_clock::time_point t;
+  int init() { return 0; }
+  void destroy() {}
+  void record(stream_t) { t = std::chrono::steady_clock::now(); }
+  static double elapsed_ms(Event &a, Event &b) { return std::chrono::duration<double, std::milli>(b.t - a.t).count(); }
+};
 }  // namespace gpu
 #define GPU_LAUNCH(stream, kernel, grid, block, ...) \
   sim::launch((uint32_t)(grid), (uint32_t)(block), [=]() { kernel(__VA_ARGS__); })
@@ -75,6 +82,20 @@ struct Timer {
     float f = 0;
     (void)hipEventSynchronize(b);
     (void)hipEventElapsedTime(&f, a, b);
+    return (double)f;
+  }
+};
+struct Event {
+  hipEvent_t e = nullptr;
+  int init() { return (int)hipEventCreate(&e); }
+  void destroy() {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
+  void record(stream_t s) { (void)hipEventRecord(e, s); }
+  static double elapsed_ms(Event &a, Event &b) {
+    float f = 0;
+    (void)hipEventElapsedTime(&f, a.e, b.e);
     return (double)f;
   }
 };

@@ -1,0 +1,55 @@
+"""Multi-GPU routing of update batches: one vertex-range partition per GPU (PPPCSR.cpp:13-34, 58-66).
+
+Each rank holds a contiguous block of the global update stream.  `exchange_ops` buckets that block by
+owner (stable, so every bucket keeps stream order), makes `src` partition-local (PPPCSR.cpp:46-52 passes
+`src - distribution[p]` and the GLOBAL dest) and swaps buckets with ONE all-to-all (RCCL over xGMI when the
+process group is "nccl"; gloo in the CPU tests).  all_to_all_single concatenates what it receives in
+source-rank order; because rank r holds block r of the stream, that order IS global stream order, so each
+partition sees exactly the subsequence the reference's PPPCSR would feed it (bit-exact per partition).
+The volume is tiny (12 B per update), so the exchange is latency-bound: one collective per batch.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition_layout(init_n, n_parts):
+    """(starts, sizes) per PPPCSR.cpp:20-29: size = floor(n / P), the last partition takes the remainder"""
+    ps = init_n // n_parts
+    starts = np.arange(n_parts, dtype=np.int64) * ps
+    sizes = np.full(n_parts, ps, np.int64)
+    sizes[-1] = init_n - (n_parts - 1) * ps
+    return starts, sizes
+
+
+def owners_of(src_u32, init_n, n_parts):
+    """PPPCSR::get_partiton (PPPCSR.cpp:58-66) for a tensor of vertex ids (int64, values in [0, 2^32))"""
+    ps = init_n // n_parts
+    if ps == 0:
+        return torch.full_like(src_u32, n_parts - 1)
+    return torch.clamp(src_u32 // ps, max=n_parts - 1)
+
+
+def bucket_ops(ops, init_n, n_parts):
+    """ops: (m,3) int32 tensor (bit patterns of uint32 src,dst,op) -> (bucketed ops with local src, counts[P])"""
+    src = ops[:, 0].to(torch.int64) & 0xFFFFFFFF
+    own = owners_of(src, init_n, n_parts)
+    order = torch.sort(own, stable=True).indices
+    b = ops.index_select(0, order).clone()
+    ps = init_n // n_parts
+    local = src.index_select(0, order) - own.index_select(0, order) * ps
+    b[:, 0] = local.to(torch.int32)
+    counts = torch.bincount(own, minlength=n_parts)
+    return b.contiguous(), counts
+
+
+def exchange_ops(ops, init_n, n_parts, group=None):
+    """all-to-all of owner buckets; returns this rank's partition subsequence (stream order, local src)"""
+    b, counts = bucket_ops(ops, init_n, n_parts)
+    recv_counts = torch.empty_like(counts)
+    dist.all_to_all_single(recv_counts, counts, group=group)
+    in_split = [int(x) for x in counts.tolist()]
+    out_split = [int(x) for x in recv_counts.tolist()]
+    out = torch.empty((sum(out_split), 3), dtype=ops.dtype, device=ops.device)
+    dist.all_to_all_single(out, b, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    return out
