@@ -144,8 +144,12 @@ def main():
     log(rank, f"core loaded in {time.time() - t0:.1f}s: N={st['N']} logN={st['logN']} rounds={st['rounds']} "
               f"exclusive={st['exclusive_ops']} doubles={st['double_calls']}")
 
+    # every step starts from the SAME core graph (config #2/#3 exactly): the device-to-device restore of the
+    # core snapshot is part of the step and inside the timed region (2 x 12 B/slot of HBM traffic, ~0.1 ms)
+    eng.snapshot()
     upd_dev = [to_dev(u) for u in upd]
     for k in range(args.warmup):
+        eng.restore()
         run_step(upd_dev[k])
     torch.cuda.synchronize()
 
@@ -158,6 +162,7 @@ def main():
     t_start = time.perf_counter()
     applied = 0
     for k in range(args.warmup, args.warmup + args.steps):
+        eng.restore()
         applied += run_step(upd_dev[k])
     torch.cuda.synchronize()
     if P > 1:
@@ -195,8 +200,34 @@ def main():
                     "exclusive_ops": int(d["exclusive_ops"])}
         eng.set_option("profile", 0)
 
-    # ---- secondary kernels: bulk neighbour scan + whole-window rebalance (HBM-roofline kernels, SURVEY §8d) ----
+    # ---- CPU baseline beside it (rank 0, N == 1): the reference (oracle/_ref) or the oracle port, 1 thread ----
+    cpu = None
     extra = {}
+    if rank == 0 and P == 1 and not args.no_cpu_baseline:
+        from oracle_lib import Oracle, RefPCSR, have_ref
+        kindc = "reference" if have_ref() else "port"
+        Cls = RefPCSR if have_ref() else Oracle
+        c = Cls(my_n)
+        tl = time.time()
+        c.apply(core_blk)
+        tl = time.time() - tl
+        tc = time.time()
+        c.apply(upd[args.warmup])
+        tc = time.time() - tc
+        cpu = {"value": len(upd[args.warmup]) / tc, "unit": "edge-updates/s", "cores": 1, "kind": kindc,
+               "sample": f"same {args.core_edges}-edge core ({tl:.1f}s load, untimed) + the first timed batch of "
+                         f"{len(upd[args.warmup])} updates in stream order on one host thread ({tc:.2f}s)"}
+        if args.check:
+            c2 = Oracle(my_n)
+            c2.apply(core_blk)
+            c2.apply(upd[args.warmup + args.steps - 1])  # the engine holds core + the last timed batch
+            ei, en = eng.state()
+            oi, on = c2.state()
+            assert eng.geometry() == c2.geometry() and np.array_equal(ei, oi) and np.array_equal(en, on), "PARITY FAILURE"
+            extra["parity_checked"] = True
+        c.close()
+
+    # ---- secondary kernels: bulk neighbour scan + whole-window rebalance (HBM-roofline kernels, SURVEY §8d) ----
     if rank == 0:
         try:
             ms, tot = eng.bench_scan_all()
@@ -213,35 +244,6 @@ def main():
                                          "frac_of_peak": 24.0 * w / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         except Exception as e:  # never let a secondary measurement kill the headline
             extra["secondary_error"] = str(e)
-
-    # ---- CPU baseline beside it (rank 0, N == 1): the reference (oracle/_ref) or the oracle port, 1 thread ----
-    cpu = None
-    if rank == 0 and P == 1 and not args.no_cpu_baseline:
-        from oracle_lib import Oracle, RefPCSR, have_ref
-        kindc = "reference" if have_ref() else "port"
-        Cls = RefPCSR if have_ref() else Oracle
-        c = Cls(my_n)
-        tl = time.time()
-        c.apply(core_blk)
-        tl = time.time() - tl
-        for k in range(args.warmup):
-            c.apply(upd[k])
-        tc = time.time()
-        c.apply(upd[args.warmup])
-        tc = time.time() - tc
-        cpu = {"value": len(upd[args.warmup]) / tc, "unit": "edge-updates/s", "cores": 1, "kind": kindc,
-               "sample": f"same {args.core_edges}-edge core ({tl:.1f}s load, untimed) + the first timed batch of "
-                         f"{len(upd[args.warmup])} updates in stream order on one host thread ({tc:.2f}s)"}
-        if args.check:
-            c2 = Oracle(my_n)
-            c2.apply(core_blk)
-            for u in upd:
-                c2.apply(u)
-            ei, en = eng.state()
-            oi, on = c2.state()
-            assert eng.geometry() == c2.geometry() and np.array_equal(ei, oi) and np.array_equal(en, on), "PARITY FAILURE"
-            extra["parity_checked"] = True
-        c.close()
 
     if rank == 0:
         out = {

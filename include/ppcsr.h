@@ -93,6 +93,10 @@ int ppcsr_export_state(ppcsr_t h, ppcsr_edge *items, ppcsr_node *nodes);
 int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out);
 /* tuning knobs: "max_horizon", "min_horizon", "init_horizon", "rounds_per_sync", "profile" */
 int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value);
+/* device-side copy of the whole state and return to it (used by the benchmark to replay a batch on the same
+ * core graph, and by the engine itself as the rollback point of speculative rounds); no reference equivalent */
+int ppcsr_snapshot(ppcsr_t h);
+int ppcsr_restore(ppcsr_t h);
 /* debugging / measurement helpers */
 int ppcsr_check_invariants(ppcsr_t h, uint64_t *bad_leaves);
 int ppcsr_bench_scan_all(ppcsr_t h, double *ms, uint64_t *total);

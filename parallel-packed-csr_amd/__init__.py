@@ -39,7 +39,7 @@ EXPORTED = [
     "ppcsr_create", "ppcsr_destroy", "ppcsr_add_edge", "ppcsr_remove_edge", "ppcsr_add_node", "ppcsr_apply_batch",
     "ppcsr_apply_batch_device", "ppcsr_edge_exists", "ppcsr_get_n", "ppcsr_get_node", "ppcsr_geometry",
     "ppcsr_get_neighbourhood", "ppcsr_read_neighbourhood", "ppcsr_scan_all", "ppcsr_export_state", "ppcsr_stats",
-    "ppcsr_set_option", "ppcsr_check_invariants", "ppcsr_bench_scan_all", "ppcsr_bench_rebalance", "ppcsr_strerror",
+    "ppcsr_set_option", "ppcsr_snapshot", "ppcsr_restore", "ppcsr_check_invariants", "ppcsr_bench_scan_all", "ppcsr_bench_rebalance", "ppcsr_strerror",
     "ppcsr_last_error", "ppcsr_device_count", "pppcsr_create", "pppcsr_destroy", "pppcsr_num_partitions",
     "pppcsr_get_partition", "pppcsr_partition_start", "pppcsr_partition", "pppcsr_add_edge", "pppcsr_remove_edge",
     "pppcsr_edge_exists", "pppcsr_get_neighbourhood", "pppcsr_get_node", "pppcsr_get_n", "pppcsr_add_node",
@@ -75,6 +75,8 @@ def load_library(path=None):
     L.ppcsr_export_state.argtypes = [c_vp, c_vp, c_vp]
     L.ppcsr_stats.argtypes = [c_vp, ctypes.POINTER(Stats)]
     L.ppcsr_set_option.argtypes = [c_vp, ctypes.c_char_p, c_i64]
+    L.ppcsr_snapshot.argtypes = [c_vp]
+    L.ppcsr_restore.argtypes = [c_vp]
     L.ppcsr_check_invariants.argtypes = [c_vp, ctypes.POINTER(c_u64)]
     L.ppcsr_bench_scan_all.argtypes = [c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_u64)]
     L.ppcsr_bench_rebalance.argtypes = [c_vp, c_u64, c_int, ctypes.POINTER(c_dbl)]
@@ -204,6 +206,9 @@ class PCSR:
         return s.as_dict()
 
     def set_option(self, key, value): self._chk(self.L.ppcsr_set_option(self.h, key.encode(), int(value)))
+
+    def snapshot(self): self._chk(self.L.ppcsr_snapshot(self.h))
+    def restore(self): self._chk(self.L.ppcsr_restore(self.h))
 
     def check_invariants(self):
         bad = c_u64()

@@ -53,6 +53,10 @@ struct Engine::Impl {
   uint32_t max_horizon = 4096, min_horizon = 64, rounds_per_sync = 16, init_horizon = 256;
   gpu::Timer timer;
   EngineStats st{};
+  // snapshot (snapshot()/restore()): a second copy of the state in HBM
+  View snap{};
+  uint64_t snap_n_cap = 0;
+  bool has_snap = false;
   bool partial = false;
   bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
   std::vector<gpu::Event> events;  // init failed half-way: destructor frees only what exists
@@ -175,6 +179,11 @@ Engine::~Engine() {
   if (p.d_rank) gpu::dfree(p.d_rank);
   if (p.d_tiles) gpu::dfree(p.d_tiles);
   if (p.d_nbr) gpu::dfree(p.d_nbr);
+  if (p.has_snap) {
+    gpu::dfree(p.snap.items);
+    gpu::dfree(p.snap.nodes);
+    gpu::dfree(p.snap.leafcnt);
+  }
   for (auto &e : p.events) e.destroy();
   p.timer.destroy();
   gpu::stream_destroy(p.stream);
@@ -536,6 +545,11 @@ int Engine::get_neighbourhood(int src, int *out, uint64_t cap, uint64_t *count) 
   GCHK(gpu::set_device(device_));
   if (cap > p.nbr_cap) {
     if (p.d_nbr) gpu::dfree(p.d_nbr);
+  if (p.has_snap) {
+    gpu::dfree(p.snap.items);
+    gpu::dfree(p.snap.nodes);
+    gpu::dfree(p.snap.leafcnt);
+  }
     p.d_nbr = nullptr;
     p.nbr_cap = 0;
     GCHK(gpu::dmalloc((void **)&p.d_nbr, cap * sizeof(int)));
@@ -675,6 +689,54 @@ int Engine::stats(EngineStats *out) {
     s.slide_slots += h.slide_slots;
   }
   *out = s;
+  return PPCSR_OK;
+}
+
+int Engine::snapshot() {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  if (p.has_snap) {
+    gpu::dfree(p.snap.items);
+    gpu::dfree(p.snap.nodes);
+    gpu::dfree(p.snap.leafcnt);
+    p.has_snap = false;
+  }
+  const uint64_t N = p.v.g.N, leaves = N >> p.v.g.sh;
+  p.snap = p.v;
+  p.snap.wres = nullptr;
+  GCHK(gpu::dmalloc((void **)&p.snap.items, N * sizeof(Edge)));
+  GCHK(gpu::dmalloc((void **)&p.snap.nodes, p.n_cap * sizeof(Node)));
+  GCHK(gpu::dmalloc((void **)&p.snap.leafcnt, leaves * sizeof(uint32_t)));
+  p.snap_n_cap = p.n_cap;
+  GCHK(gpu::d2d(p.snap.items, p.v.items, N * sizeof(Edge), p.stream));
+  GCHK(gpu::d2d(p.snap.nodes, p.v.nodes, (uint64_t)p.v.g.n * sizeof(Node), p.stream));
+  GCHK(gpu::d2d(p.snap.leafcnt, p.v.leafcnt, leaves * sizeof(uint32_t), p.stream));
+  GCHK(gpu::sync(p.stream));
+  p.has_snap = true;
+  return PPCSR_OK;
+}
+
+int Engine::restore() {
+  Impl &p = *p_;
+  if (!p.has_snap) return fail(PPCSR_EINVAL, "restore without snapshot");
+  GCHK(gpu::set_device(device_));
+  const uint64_t N = p.snap.g.N, leaves = N >> p.snap.g.sh;
+  if (p.v.g.N != N) {  // the array was resized since the snapshot: go back to buffers of the old size
+    gpu::dfree(p.v.items);
+    gpu::dfree(p.v.leafcnt);
+    gpu::dfree(p.v.wres);
+    GCHK(gpu::dmalloc((void **)&p.v.items, N * sizeof(Edge)));
+    GCHK(gpu::dmalloc((void **)&p.v.leafcnt, leaves * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.v.wres, leaves * sizeof(unsigned long long)));
+    GCHK(gpu::dset(p.v.wres, 0xFF, leaves * sizeof(unsigned long long), p.stream));
+    p.leaves_cap = leaves;
+    p.round = 0;
+  }
+  if (p.n_cap < p.snap_n_cap) return fail(PPCSR_EINTERNAL, "node capacity shrank");
+  p.v.g = p.snap.g;
+  GCHK(gpu::d2d(p.v.items, p.snap.items, N * sizeof(Edge), p.stream));
+  GCHK(gpu::d2d(p.v.nodes, p.snap.nodes, (uint64_t)p.snap.g.n * sizeof(Node), p.stream));
+  GCHK(gpu::d2d(p.v.leafcnt, p.snap.leafcnt, leaves * sizeof(uint32_t), p.stream));
   return PPCSR_OK;
 }
 

@@ -47,7 +47,9 @@ class Engine {
   int check_invariants(uint64_t *bad);  // leafcnt == recount(items)
   int stats(EngineStats *out);
   int set_option(const char *key, int64_t value);
-  int rebalance_bench(uint64_t wlen, int iters, double *ms_per_call);  // whole-window rebalance kernel timing
+  int rebalance_bench(uint64_t wlen, int iters, double *ms_per_call);
+  int snapshot();  // device-side copy of the whole state (items, nodes, leaf counts, geometry)
+  int restore();   // back to the last snapshot (device-to-device)  // whole-window rebalance kernel timing
 
   uint64_t N() const;
   uint32_t n() const;

@@ -168,7 +168,7 @@ struct InsertPlan {
 
 // Emulation of acquire_insert_locks (PCSR.cpp:949-1134) for a single sequential caller.  The lock
 // range [min_node,max_node] is tracked only as far as it steers `tries`.
-PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied) {
+PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, RangeRec &rr) {
   const Geometry &g = v.g;
   const int sh = g.sh;
   const uint64_t logN = (uint64_t)g.logN;
@@ -199,7 +199,10 @@ PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied) {
       return out;
     }
     bool restart = false;
+    // every leaf count consulted below is a READ of that leaf: record it, so that an earlier update of the same
+    // round writing there is seen as a conflict even when the leaf ends up outside this update's own window
     uint32_t c = v.leafcnt[node_index >> sh];
+    rec_range(rr, v, (uint32_t)node_index, (uint32_t)node_index);
     if ((uint64_t)c + 1 == len) {  // leaf would become full (PCSR.cpp:1012-1023)
       const uint64_t new_idx = node_index & ~(2 * len - 1);
       const int64_t new_id = (int64_t)(new_idx >> sh);
@@ -210,6 +213,7 @@ PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied) {
       }
       node_index = new_idx;
       c = v.leafcnt[node_index >> sh];
+      rec_range(rr, v, (uint32_t)node_index, (uint32_t)node_index);
     }
     while ((uint64_t)c + 1 >= (uint64_t)g.t_up[level]) {  // PCSR.cpp:1028-1061
       len *= 2;
@@ -226,9 +230,11 @@ PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied) {
           }
           // window grew to the left: new count = old window + left half
           c += count_window(v, new_idx, len / 2);
+          rec_range(rr, v, (uint32_t)new_idx, (uint32_t)(new_idx + len / 2 - 1));
           node_index = new_idx;
         } else {
           c += count_window(v, new_idx + len / 2, len / 2);
+          rec_range(rr, v, (uint32_t)(new_idx + len / 2), (uint32_t)(new_idx + len - 1));
         }
       } else {
         out.status = PS_GLOBAL_DOUBLE;
@@ -264,7 +270,7 @@ struct RemovePlan {
   int half;  // climb reached the root: half_list()
   uint64_t wstart, wlen;
 };
-PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index) {
+PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index, RangeRec &rr) {
   const Geometry &g = v.g;
   const int sh = g.sh;
   RemovePlan out;
@@ -273,6 +279,7 @@ PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index) {
   int level = g.H;
   uint64_t len = (uint64_t)g.logN;
   uint32_t c = v.leafcnt[node_index >> sh];  // pre-removal count; compare c-1
+  rec_range(rr, v, (uint32_t)node_index, (uint32_t)node_index);
   while ((uint64_t)c < (uint64_t)g.t_lo[level] + 1) {  // (c - 1) < t_lo
     len *= 2;
     if (len <= g.N) {
@@ -280,9 +287,11 @@ PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index) {
       const uint64_t new_idx = node_index & ~(len - 1);
       if (new_idx < node_index) {
         c += count_window(v, new_idx, len / 2);
+        rec_range(rr, v, (uint32_t)new_idx, (uint32_t)(new_idx + len / 2 - 1));
         node_index = new_idx;
       } else {
         c += count_window(v, new_idx + len / 2, len / 2);
+        rec_range(rr, v, (uint32_t)(new_idx + len / 2), (uint32_t)(new_idx + len - 1));
       }
     } else {
       out.half = 1;
@@ -451,7 +460,7 @@ PMA_DEV void plan_op(const View &v, const Op op, Plan *plan) {
         kind = K_DUP;
         wl = wh = leaf;
       } else {
-        const InsertPlan ip = plan_insert(v, index, occupied);
+        const InsertPlan ip = plan_insert(v, index, occupied, rr);
         if (ip.status != PS_OK) {
           kind = K_EXCL;
         } else {
@@ -491,7 +500,7 @@ PMA_DEV void plan_op(const View &v, const Op op, Plan *plan) {
       if (!occupied || is_sentinel(elem) || at.dest != op.dst) {
         kind = K_NOTFOUND;
       } else {
-        const RemovePlan rp = plan_remove(v, index);
+        const RemovePlan rp = plan_remove(v, index, rr);
         if (rp.half || rp.wlen > kBigWindow) {
           kind = K_EXCL;
         } else {

@@ -174,7 +174,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
       ip.max_len = logN;
       ip.node_index_final = 0;
       if (!(flags & XF_FORCE_NOINFO) && !add_node) {
-        ip = dev::plan_insert(v, index, occupied);
+        ip = dev::plan_insert(v, index, occupied, rr);
         status = ip.status;
       }
       uint32_t gap = index;
@@ -274,7 +274,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
         if (lane == 0) wv::atomic_add_u64(&st->not_found, 1ull);
       } else {
         found = 1;
-        const dev::RemovePlan rp = dev::plan_remove(v, index);
+        const dev::RemovePlan rp = dev::plan_remove(v, index, rr);
         wv::fence();  // planning reads are complete in every lane before the state is modified
         if (lane == 0) {
           v.items[index].value = 0;

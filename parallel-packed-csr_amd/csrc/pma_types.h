@@ -62,7 +62,7 @@ enum Kind : uint32_t {
   K_EXCL = 5,      // must run alone through the exclusive executor (global path, resize, big window)
 };
 
-constexpr int kMaxR = 40;  // read-leaf ranges recorded per op (<= 32 search iterations + a few)
+constexpr int kMaxR = 72;  // read-leaf ranges recorded per op (<= 32 search iterations + <= 32 climb levels + a few)
 
 struct Plan {
   uint32_t kind;
