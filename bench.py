@@ -70,6 +70,10 @@ def main():
     ap.add_argument("--labels", choices=["permuted", "raw"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket round kernels with HIP events")
+    ap.add_argument("--mode", type=int, default=-1, help="0 strict prefix rounds, 1 speculative rounds (engine default)")
+    ap.add_argument("--opt-horizon", type=int, default=0)
+    ap.add_argument("--epoch-ops", type=int, default=0)
+    ap.add_argument("--region-slots", type=int, default=0)
     ap.add_argument("--max-horizon", type=int, default=0)
     ap.add_argument("--rounds-per-sync", type=int, default=0)
     ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (slow)")
@@ -116,6 +120,14 @@ def main():
               f"(n_global={n_global}, labels={'permuted' if permute else 'raw'})")
 
     eng = pkg.PCSR(my_n, device=local_rank)
+    if args.mode >= 0:
+        eng.set_option("mode", args.mode)
+    if args.opt_horizon:
+        eng.set_option("opt_horizon", args.opt_horizon)
+    if args.epoch_ops:
+        eng.set_option("epoch_ops", args.epoch_ops)
+    if args.region_slots:
+        eng.set_option("region_slots", args.region_slots)
     if args.max_horizon:
         eng.set_option("max_horizon", args.max_horizon)
     if args.rounds_per_sync:
@@ -142,7 +154,7 @@ def main():
     del core_dev
     st = eng.stats()
     log(rank, f"core loaded in {time.time() - t0:.1f}s: N={st['N']} logN={st['logN']} rounds={st['rounds']} "
-              f"exclusive={st['exclusive_ops']} doubles={st['double_calls']}")
+              f"exclusive={st['exclusive_ops']} doubles={st['double_calls']} rollbacks={st['rollbacks']}")
 
     # every step starts from the SAME core graph (config #2/#3 exactly): the device-to-device restore of the
     # core snapshot is part of the step and inside the timed region (2 x 12 B/slot of HBM traffic, ~0.1 ms)
@@ -176,6 +188,9 @@ def main():
     total_updates = args.batch * P * args.steps
     value = total_updates / elapsed
 
+    dstat = {k: s1[k] - s0[k] for k in ("rounds", "committed", "planned", "exclusive_ops", "rollbacks", "round_syncs",
+                                         "redistribute_slots", "redistribute_calls", "ops_applied", "double_calls")}
+    dstat["updates_per_round"] = dstat["committed"] / max(dstat["rounds"], 1)
     # ---- roofline of the dominant round kernel, from HIP events on the engine's stream over the timed region ----
     roofline = None
     kern = {}
@@ -256,7 +271,7 @@ def main():
                        "vertices": n_global, "core_edges": args.core_edges * P, "updates_per_step": args.batch * P,
                        "parallelism": f"partition-per-gpu x{P}", "N_slots": int(s1["N"]), "logN": int(s1["logN"]),
                        "semantics": "sequential stream order (bit-exact vs reference -threads=1)"},
-            "roofline": roofline, "cpu_baseline": cpu, **extra,
+            "roofline": roofline, "cpu_baseline": cpu, "engine": dstat, **extra,
         }
         print(json.dumps(out), flush=True)
     if P > 1:

@@ -49,7 +49,7 @@ typedef struct {
   int32_t logN, H;
   uint64_t rounds, committed, planned, exclusive_ops, round_syncs;
   uint64_t redistribute_calls, redistribute_slots; /* what the reference's redistribute() would move */
-  uint64_t double_calls, half_calls, big_redistributes;
+  uint64_t double_calls, half_calls, big_redistributes, rollbacks;
   uint64_t not_found, duplicates, noops, slide_slots;
   uint64_t ops_applied;
   double last_batch_ms;     /* device-only time of the last batch (ops already in HBM)  */
@@ -91,7 +91,8 @@ int ppcsr_scan_all(ppcsr_t h, uint64_t *row_offsets, int *dests, uint64_t cap, u
 /* raw state for parity checks: items[N], nodes[n] exactly as the reference holds them (PCSR.h:67,128) */
 int ppcsr_export_state(ppcsr_t h, ppcsr_edge *items, ppcsr_node *nodes);
 int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out);
-/* tuning knobs: "max_horizon", "min_horizon", "init_horizon", "rounds_per_sync", "profile" */
+/* knobs: "mode" (0 strict prefix rounds, 1 speculative rounds + validated rollback), "opt_horizon", "epoch_ops",
+ * "region_slots", "max_horizon", "min_horizon", "init_horizon", "rounds_per_sync", "profile" */
 int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value);
 /* device-side copy of the whole state and return to it (used by the benchmark to replay a batch on the same
  * core graph, and by the engine itself as the rollback point of speculative rounds); no reference equivalent */

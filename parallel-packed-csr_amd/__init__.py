@@ -26,7 +26,7 @@ class Stats(ctypes.Structure):
     _fields_ = [("N", c_u64), ("n", c_u64), ("logN", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("rounds", c_u64), ("committed", c_u64), ("planned", c_u64), ("exclusive_ops", c_u64),
                 ("round_syncs", c_u64), ("redistribute_calls", c_u64), ("redistribute_slots", c_u64),
-                ("double_calls", c_u64), ("half_calls", c_u64), ("big_redistributes", c_u64),
+                ("double_calls", c_u64), ("half_calls", c_u64), ("big_redistributes", c_u64), ("rollbacks", c_u64),
                 ("not_found", c_u64), ("duplicates", c_u64), ("noops", c_u64), ("slide_slots", c_u64),
                 ("ops_applied", c_u64), ("last_batch_ms", c_dbl), ("last_batch_h2d_ms", c_dbl),
                 ("prof_plan_ms", c_dbl), ("prof_check_ms", c_dbl), ("prof_apply_ms", c_dbl), ("prof_launches", c_u64)]

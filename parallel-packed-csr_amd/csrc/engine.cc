@@ -37,7 +37,7 @@ struct Engine::Impl {
   uint64_t leaves_cap = 0;   // capacity of leafcnt/wres
   Control *d_ctl = nullptr, *h_ctl = nullptr;
   Plan *d_plans = nullptr;
-  StatShard *d_stats = nullptr, *h_stats = nullptr;
+  StatShard *d_stats = nullptr, *h_stats = nullptr, *d_stats_snap = nullptr;
   ExclOut *d_xout = nullptr, *h_xout = nullptr;
   Op *d_ops = nullptr;
   uint64_t ops_cap = 0;
@@ -53,16 +53,59 @@ struct Engine::Impl {
   uint32_t max_horizon = 4096, min_horizon = 64, rounds_per_sync = 16, init_horizon = 256;
   gpu::Timer timer;
   EngineStats st{};
-  // snapshot (snapshot()/restore()): a second copy of the state in HBM
-  View snap{};
-  uint64_t snap_n_cap = 0;
-  bool has_snap = false;
+  // snapshots: second copies of the state in HBM.  `snap` = user snapshot()/restore(); `esnap` = rollback
+  // point of the current speculative epoch
+  struct Snap {
+    View v{};
+    uint64_t cap_slots = 0, cap_nodes = 0;
+    bool valid = false;
+  };
+  Snap snap, esnap;
+  // speculative scheduler state
+  OptCtl *d_octl = nullptr, *h_octl = nullptr;
+  uint32_t *d_opidx = nullptr, *d_status = nullptr, *d_carry0 = nullptr, *d_carry1 = nullptr;
+  uint64_t carry_cap = 0, hslot_cap = 0;
+  unsigned long long *d_regfail = nullptr;
+  uint32_t *d_wstamp = nullptr, *d_rstamp = nullptr;
+  uint32_t mode = 1;             // 0 = strict prefix rounds, 1 = speculative rounds with validated rollback
+  uint32_t epoch_ops = 1u << 18;  // rollback granularity
+  uint32_t region_slots = 4096;  // per-region prefix rule (>= kBigWindow so a window never leaves its region)
+  uint32_t opt_horizon = 32768;
   bool partial = false;
   bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
   std::vector<gpu::Event> events;  // init failed half-way: destructor frees only what exists
 };
 
 Engine::Engine() : p_(new Impl()) {}
+
+// per-leaf auxiliary arrays that follow the geometry of `v` (reservations, stamps, region fail-mins)
+static int alloc_aux(Engine::Impl &p, View &v) {
+  const uint64_t leaves = v.g.N >> v.g.sh;
+  int e;
+  if ((e = gpu::dmalloc((void **)&v.wres, leaves * sizeof(unsigned long long)))) return e;
+  if ((e = gpu::dmalloc((void **)&v.rres, leaves * sizeof(unsigned long long)))) return e;
+  if ((e = gpu::dmalloc((void **)&p.d_wstamp, leaves * sizeof(uint32_t)))) return e;
+  if ((e = gpu::dmalloc((void **)&p.d_rstamp, leaves * sizeof(uint32_t)))) return e;
+  if ((e = gpu::dmalloc((void **)&p.d_regfail, (leaves + 1) * sizeof(unsigned long long)))) return e;
+  if ((e = gpu::dset(v.wres, 0xFF, leaves * sizeof(unsigned long long), p.stream))) return e;
+  if ((e = gpu::dset(v.rres, 0xFF, leaves * sizeof(unsigned long long), p.stream))) return e;
+  if ((e = gpu::dset(p.d_regfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream))) return e;
+  if ((e = gpu::dset(p.d_wstamp, 0, leaves * sizeof(uint32_t), p.stream))) return e;
+  if ((e = gpu::dset(p.d_rstamp, 0, leaves * sizeof(uint32_t), p.stream))) return e;
+  p.leaves_cap = leaves;
+  p.round = 0;
+  return 0;
+}
+static void free_aux(Engine::Impl &p, View &v) {
+  gpu::dfree(v.wres);
+  gpu::dfree(v.rres);
+  gpu::dfree(p.d_wstamp);
+  gpu::dfree(p.d_rstamp);
+  gpu::dfree(p.d_regfail);
+  v.wres = v.rres = nullptr;
+  p.d_wstamp = p.d_rstamp = nullptr;
+  p.d_regfail = nullptr;
+}
 
 int Engine::fail(int code, const std::string &msg) {
   err_ = msg;
@@ -114,14 +157,15 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   GCHK(gpu::dmalloc((void **)&p.v.items, N * sizeof(Edge)));
   GCHK(gpu::dmalloc((void **)&p.v.nodes, p.n_cap * sizeof(Node)));
   GCHK(gpu::dmalloc((void **)&p.v.leafcnt, p.leaves_cap * sizeof(uint32_t)));
-  GCHK(gpu::dmalloc((void **)&p.v.wres, p.leaves_cap * sizeof(unsigned long long)));
-  p.v.rres = nullptr;
-  GCHK(gpu::dset(p.v.wres, 0xFF, p.leaves_cap * sizeof(unsigned long long), p.stream));
+  GCHK(alloc_aux(p, p.v));
+  GCHK(gpu::dmalloc((void **)&p.d_octl, sizeof(OptCtl)));
+  GCHK(gpu::hmalloc((void **)&p.h_octl, sizeof(OptCtl)));
   GCHK(gpu::dmalloc((void **)&p.d_ctl, sizeof(Control)));
   GCHK(gpu::hmalloc((void **)&p.h_ctl, sizeof(Control)));
   GCHK(gpu::dmalloc((void **)&p.d_stats, kStatShards * sizeof(StatShard)));
   GCHK(gpu::hmalloc((void **)&p.h_stats, kStatShards * sizeof(StatShard)));
   GCHK(gpu::dset(p.d_stats, 0, kStatShards * sizeof(StatShard), p.stream));
+  GCHK(gpu::dmalloc((void **)&p.d_stats_snap, kStatShards * sizeof(StatShard)));
   GCHK(gpu::dmalloc((void **)&p.d_xout, sizeof(ExclOut)));
   GCHK(gpu::hmalloc((void **)&p.h_xout, sizeof(ExclOut)));
   GCHK(gpu::hmalloc((void **)&p.h_op1, sizeof(Op)));
@@ -163,11 +207,18 @@ Engine::~Engine() {
   gpu::dfree(p.v.items);
   gpu::dfree(p.v.nodes);
   gpu::dfree(p.v.leafcnt);
-  gpu::dfree(p.v.wres);
+  free_aux(p, p.v);
+  gpu::dfree(p.d_octl);
+  gpu::hfree(p.h_octl);
+  if (p.d_opidx) gpu::dfree(p.d_opidx);
+  if (p.d_status) gpu::dfree(p.d_status);
+  if (p.d_carry0) gpu::dfree(p.d_carry0);
+  if (p.d_carry1) gpu::dfree(p.d_carry1);
   gpu::dfree(p.d_ctl);
   gpu::hfree(p.h_ctl);
   gpu::dfree(p.d_stats);
   gpu::hfree(p.h_stats);
+  gpu::dfree(p.d_stats_snap);
   gpu::dfree(p.d_xout);
   gpu::hfree(p.h_xout);
   gpu::hfree(p.h_op1);
@@ -179,10 +230,10 @@ Engine::~Engine() {
   if (p.d_rank) gpu::dfree(p.d_rank);
   if (p.d_tiles) gpu::dfree(p.d_tiles);
   if (p.d_nbr) gpu::dfree(p.d_nbr);
-  if (p.has_snap) {
-    gpu::dfree(p.snap.items);
-    gpu::dfree(p.snap.nodes);
-    gpu::dfree(p.snap.leafcnt);
+  for (Impl::Snap *sp : {&p.snap, &p.esnap}) {
+    if (sp->v.items) gpu::dfree(sp->v.items);
+    if (sp->v.nodes) gpu::dfree(sp->v.nodes);
+    if (sp->v.leafcnt) gpu::dfree(sp->v.leafcnt);
   }
   for (auto &e : p.events) e.destroy();
   p.timer.destroy();
@@ -214,6 +265,26 @@ int Engine::set_option(const char *key, int64_t value) {
   if (k == "init_horizon") {
     if (value < 1) return fail(PPCSR_EINVAL, "init_horizon out of range");
     p.init_horizon = (uint32_t)std::min<int64_t>(value, p.max_horizon);
+    return PPCSR_OK;
+  }
+  if (k == "mode") {
+    if (value != 0 && value != 1) return fail(PPCSR_EINVAL, "mode must be 0 (strict) or 1 (speculative)");
+    p.mode = (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "epoch_ops") {
+    if (value < 1 || value > (1 << 24)) return fail(PPCSR_EINVAL, "epoch_ops out of range");
+    p.epoch_ops = (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "region_slots") {
+    if (value < 1 || (value & (value - 1))) return fail(PPCSR_EINVAL, "region_slots must be a power of two");
+    p.region_slots = (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "opt_horizon") {
+    if (value < 1 || value > (1 << 20)) return fail(PPCSR_EINVAL, "opt_horizon out of range");
+    p.opt_horizon = (uint32_t)value;
     return PPCSR_OK;
   }
   if (k == "profile") {
@@ -257,7 +328,8 @@ int Engine::apply_batch_device(const Op *d_ops, uint64_t n) {
   p.timer.start(p.stream);
   const uint64_t kChunk = 1ull << 30;
   for (uint64_t off = 0; off < n; off += kChunk) {
-    int rc = run_rounds(d_ops + off, std::min(kChunk, n - off));
+    const uint64_t m = std::min(kChunk, n - off);
+    int rc = (p.mode == 1) ? run_speculative(d_ops + off, m) : run_rounds(d_ops + off, m);
     if (rc != PPCSR_OK) return rc;
   }
   p.timer.stop(p.stream);
@@ -351,6 +423,164 @@ int Engine::run_rounds(const Op *d_ops, uint64_t n) {
   return PPCSR_OK;
 }
 
+static int snap_save(Engine::Impl &p, Engine::Impl::Snap &sn);
+static int snap_load(Engine::Impl &p, Engine::Impl::Snap &sn);
+
+// Speculative rounds (pma_kernels.h, second half): epochs of at most `epoch_ops` updates, each with a rollback
+// snapshot; a validation failure replays the epoch with the strict prefix rounds, an exclusive update ends the epoch.
+int Engine::run_speculative(const Op *d_ops, uint64_t n) {
+  Impl &p = *p_;
+  // per-slot and carry arrays
+  if (p.hslot_cap < p.opt_horizon) {
+    if (p.d_opidx) gpu::dfree(p.d_opidx);
+    if (p.d_status) gpu::dfree(p.d_status);
+    p.d_opidx = p.d_status = nullptr;
+    p.hslot_cap = 0;
+    GCHK(gpu::dmalloc((void **)&p.d_opidx, (uint64_t)p.opt_horizon * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_status, (uint64_t)p.opt_horizon * sizeof(uint32_t)));
+    gpu::dfree(p.d_plans);
+    p.d_plans = nullptr;
+    GCHK(gpu::dmalloc((void **)&p.d_plans, (uint64_t)std::max(p.opt_horizon, p.max_horizon) * sizeof(Plan)));
+    p.hslot_cap = p.opt_horizon;
+  }
+  if (p.carry_cap < p.epoch_ops) {
+    if (p.d_carry0) gpu::dfree(p.d_carry0);
+    if (p.d_carry1) gpu::dfree(p.d_carry1);
+    p.d_carry0 = p.d_carry1 = nullptr;
+    p.carry_cap = 0;
+    GCHK(gpu::dmalloc((void **)&p.d_carry0, (uint64_t)p.epoch_ops * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_carry1, (uint64_t)p.epoch_ops * sizeof(uint32_t)));
+    p.carry_cap = p.epoch_ops;
+  }
+  uint64_t e0 = 0;
+  uint64_t forced_e1 = 0;  // after a rollback: end the retried epoch right after the update that failed validation
+  int retries = 0;
+  while (e0 < n) {
+    uint64_t e1 = std::min<uint64_t>(e0 + p.epoch_ops, n);
+    if (forced_e1 > e0 && forced_e1 < e1) e1 = forced_e1;
+    if (p.round > 0xFFFF0000u) {
+      const uint64_t leaves = p.v.g.N >> p.v.g.sh;
+      GCHK(gpu::dset(p.v.wres, 0xFF, leaves * sizeof(unsigned long long), p.stream));
+      GCHK(gpu::dset(p.v.rres, 0xFF, leaves * sizeof(unsigned long long), p.stream));
+      GCHK(gpu::dset(p.d_regfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream));
+      p.round = 0;
+    }
+    GCHK(snap_save(p, p.esnap));
+    GCHK(gpu::d2d(p.d_stats_snap, p.d_stats, kStatShards * sizeof(StatShard), p.stream));
+    {
+      const uint64_t leaves = p.v.g.N >> p.v.g.sh;
+      GCHK(gpu::dset(p.d_wstamp, 0, leaves * sizeof(uint32_t), p.stream));
+      GCHK(gpu::dset(p.d_rstamp, 0, leaves * sizeof(uint32_t), p.stream));
+    }
+    OptCtl &c = *p.h_octl;
+    memset(&c, 0, sizeof(c));
+    const uint32_t par = (p.round + 1) & 1u;
+    c.carry_n[0] = c.carry_n[1] = 0;
+    c.next_fresh[0] = c.next_fresh[1] = (uint32_t)e0;
+    c.hor[par] = (uint32_t)std::min<uint64_t>(p.opt_horizon, e1 - e0);
+    c.e1 = (uint32_t)e1;
+    c.max_horizon = p.opt_horizon;
+    c.gbar[0] = c.gbar[1] = ~0ull;
+    c.viol_idx = kMax;
+    GCHK(gpu::h2d(p.d_octl, p.h_octl, sizeof(OptCtl), p.stream));
+    int rs = 0;
+    while ((p.region_slots >> rs) > (uint32_t)p.v.g.logN) rs++;
+    bool epoch_open = true;
+    uint32_t hint_hor = c.hor[par];
+    while (epoch_open) {
+      OptArgs a;
+      a.v = p.v;
+      a.ops = d_ops;
+      a.plans = p.d_plans;
+      a.opidx = p.d_opidx;
+      a.status = p.d_status;
+      a.carry0 = p.d_carry0;
+      a.carry1 = p.d_carry1;
+      a.ctl = p.d_octl;
+      a.stats = p.d_stats;
+      a.regfail = p.d_regfail;
+      a.wstamp = p.d_wstamp;
+      a.rstamp = p.d_rstamp;
+      a.regshift = rs;
+      // grid sized for the horizon the device last reported (it can only shrink within a chunk when fresh
+      // updates run out; it never exceeds opt_horizon)
+      uint32_t gh = p.opt_horizon;
+      if (hint_hor * 2u < gh) gh = std::max<uint32_t>(hint_hor * 2u, 256u);
+      const uint32_t blocks = (gh + 3) / 4;
+      if (gh != c.max_horizon) {  // the device must never choose a horizon larger than the launched grid
+        GCHK(gpu::h2d(&p.d_octl->max_horizon, &gh, sizeof(uint32_t), p.stream));
+        c.max_horizon = gh;
+      }
+      const uint32_t rounds = (gh == p.opt_horizon) ? std::max<uint32_t>(1u, p.rounds_per_sync / 4) : p.rounds_per_sync;
+      for (uint32_t r = 0; r < rounds; r++) {
+        a.round = ++p.round;
+        GPU_LAUNCH(p.stream, o_plan, blocks, 256, a);
+        GPU_LAUNCH(p.stream, o_check, blocks, 256, a);
+        GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
+        GPU_LAUNCH(p.stream, o_compact, 1, 1024, a);
+      }
+      GCHK(gpu::d2h(p.h_octl, p.d_octl, sizeof(OptCtl), p.stream));
+      GCHK(gpu::sync(p.stream));
+      GCHK(gpu::last_error());
+      p.st.round_syncs++;
+      if (c.error) return fail(PPCSR_EINTERNAL, "device-side error " + std::to_string(c.error));
+      const uint32_t npar = (p.round + 1) & 1u;
+      // an exclusive update rewrites an unbounded part of the array; if anything LATER has already been
+      // committed (it turned exclusive only after being deferred) the epoch is not serialisable: roll back
+      if (c.excl && !c.violation && c.maxc > c.excl_idx + 1u) {
+        c.violation = 1;
+        c.viol_idx = c.excl_idx;
+      }
+      if (c.violation) {
+        // a later update was committed before an earlier one whose footprint then reached it: roll the epoch back
+        // and retry it cut right after that update (nothing can overtake the last update of an epoch); after
+        // repeated failures replay the epoch with the strict prefix rounds
+        p.st.rollbacks++;
+        GCHK(snap_load(p, p.esnap));
+        GCHK(gpu::d2d(p.d_stats, p.d_stats_snap, kStatShards * sizeof(StatShard), p.stream));
+        p.st.rounds += c.rounds;
+        const uint64_t cut = (uint64_t)c.viol_idx + 1;
+        if (retries < 3 && c.viol_idx != kMax && cut > e0 && cut < e1) {
+          retries++;
+          forced_e1 = cut;
+        } else {
+          int rc = run_rounds(d_ops + e0, e1 - e0);
+          if (rc != PPCSR_OK) return rc;
+          e0 = e1;
+          retries = 0;
+          forced_e1 = 0;
+        }
+        epoch_open = false;
+      } else if (c.excl) {
+        p.st.rounds += c.rounds;
+        p.st.committed += c.committed;
+        p.st.planned += c.planned;
+        const uint64_t g = c.excl_idx;
+        GCHK(gpu::d2h(p.h_op1, d_ops + g, sizeof(Op), p.stream));
+        GCHK(gpu::sync(p.stream));
+        int rc = run_exclusive(*p.h_op1, 0);
+        if (rc != PPCSR_OK) return rc;
+        e0 = g + 1;
+        retries = 0;
+        epoch_open = false;
+      } else if (c.done) {
+        p.st.rounds += c.rounds;
+        p.st.committed += c.committed;
+        p.st.planned += c.planned;
+        e0 = e1;
+        retries = 0;
+        epoch_open = false;
+      } else {
+        hint_hor = c.hor[npar];
+        if (hint_hor > gh) {
+          // the grid of the next chunk must cover the horizon the device chose
+        }
+      }
+    }
+  }
+  return PPCSR_OK;
+}
+
 int Engine::run_exclusive(Op op, uint32_t flags) {
   Impl &p = *p_;
   p.st.exclusive_ops++;
@@ -426,8 +656,6 @@ int Engine::resize(uint64_t newN) {
   const uint64_t new_leaves = newN >> g.sh;
   GCHK(gpu::dmalloc((void **)&nv.items, newN * sizeof(Edge)));
   GCHK(gpu::dmalloc((void **)&nv.leafcnt, new_leaves * sizeof(uint32_t)));
-  GCHK(gpu::dmalloc((void **)&nv.wres, new_leaves * sizeof(unsigned long long)));
-  GCHK(gpu::dset(nv.wres, 0xFF, new_leaves * sizeof(unsigned long long), p.stream));
   int rc = rank_scan(old.leafcnt, old_leaves);
   if (rc != PPCSR_OK) return rc;
   GPU_LAUNCH(p.stream, k_chain_table, 1, 64, (uint64_t)0, newN, (const unsigned long long *)p.d_total, p.d_table);
@@ -439,10 +667,12 @@ int Engine::resize(uint64_t newN) {
   GCHK(gpu::last_error());
   gpu::dfree(old.items);
   gpu::dfree(old.leafcnt);
-  gpu::dfree(old.wres);
+  {
+    View tmp = old;
+    free_aux(p, tmp);
+  }
   p.v = nv;
-  p.leaves_cap = new_leaves;
-  p.round = 0;  // fresh reservation array
+  GCHK(alloc_aux(p, p.v));  // fresh reservation / stamp arrays for the new leaf count
   if (newN > oldN) p.st.double_calls++; else p.st.half_calls++;
   p.st.redistribute_calls++;
   p.st.redistribute_slots += newN;
@@ -545,10 +775,10 @@ int Engine::get_neighbourhood(int src, int *out, uint64_t cap, uint64_t *count) 
   GCHK(gpu::set_device(device_));
   if (cap > p.nbr_cap) {
     if (p.d_nbr) gpu::dfree(p.d_nbr);
-  if (p.has_snap) {
-    gpu::dfree(p.snap.items);
-    gpu::dfree(p.snap.nodes);
-    gpu::dfree(p.snap.leafcnt);
+  for (Impl::Snap *sp : {&p.snap, &p.esnap}) {
+    if (sp->v.items) gpu::dfree(sp->v.items);
+    if (sp->v.nodes) gpu::dfree(sp->v.nodes);
+    if (sp->v.leafcnt) gpu::dfree(sp->v.leafcnt);
   }
     p.d_nbr = nullptr;
     p.nbr_cap = 0;
@@ -692,51 +922,65 @@ int Engine::stats(EngineStats *out) {
   return PPCSR_OK;
 }
 
+static int snap_save(Engine::Impl &p, Engine::Impl::Snap &sn) {
+  const uint64_t N = p.v.g.N, leaves = N >> p.v.g.sh;
+  int e;
+  if (sn.cap_slots < N) {
+    if (sn.v.items) gpu::dfree(sn.v.items);
+    if (sn.v.leafcnt) gpu::dfree(sn.v.leafcnt);
+    sn.v.items = nullptr;
+    sn.v.leafcnt = nullptr;
+    sn.cap_slots = 0;
+    if ((e = gpu::dmalloc((void **)&sn.v.items, N * sizeof(Edge)))) return e;
+    if ((e = gpu::dmalloc((void **)&sn.v.leafcnt, N * sizeof(uint32_t) / 2 + 64))) return e;  // leaves <= N/2
+    sn.cap_slots = N;
+  }
+  if (sn.cap_nodes < p.n_cap) {
+    if (sn.v.nodes) gpu::dfree(sn.v.nodes);
+    sn.v.nodes = nullptr;
+    sn.cap_nodes = 0;
+    if ((e = gpu::dmalloc((void **)&sn.v.nodes, p.n_cap * sizeof(Node)))) return e;
+    sn.cap_nodes = p.n_cap;
+  }
+  sn.v.g = p.v.g;
+  if ((e = gpu::d2d(sn.v.items, p.v.items, N * sizeof(Edge), p.stream))) return e;
+  if (p.v.g.n && (e = gpu::d2d(sn.v.nodes, p.v.nodes, (uint64_t)p.v.g.n * sizeof(Node), p.stream))) return e;
+  if ((e = gpu::d2d(sn.v.leafcnt, p.v.leafcnt, leaves * sizeof(uint32_t), p.stream))) return e;
+  sn.valid = true;
+  return 0;
+}
+static int snap_load(Engine::Impl &p, Engine::Impl::Snap &sn) {
+  const uint64_t N = sn.v.g.N, leaves = N >> sn.v.g.sh;
+  int e;
+  if (p.v.g.N != N) {  // the array was resized since the snapshot: go back to buffers of the old size
+    gpu::dfree(p.v.items);
+    gpu::dfree(p.v.leafcnt);
+    free_aux(p, p.v);
+    if ((e = gpu::dmalloc((void **)&p.v.items, N * sizeof(Edge)))) return e;
+    if ((e = gpu::dmalloc((void **)&p.v.leafcnt, leaves * sizeof(uint32_t)))) return e;
+    p.v.g = sn.v.g;
+    if ((e = alloc_aux(p, p.v))) return e;
+  }
+  p.v.g = sn.v.g;
+  if ((e = gpu::d2d(p.v.items, sn.v.items, N * sizeof(Edge), p.stream))) return e;
+  if (sn.v.g.n && (e = gpu::d2d(p.v.nodes, sn.v.nodes, (uint64_t)sn.v.g.n * sizeof(Node), p.stream))) return e;
+  if ((e = gpu::d2d(p.v.leafcnt, sn.v.leafcnt, leaves * sizeof(uint32_t), p.stream))) return e;
+  return 0;
+}
+
 int Engine::snapshot() {
   Impl &p = *p_;
   GCHK(gpu::set_device(device_));
-  if (p.has_snap) {
-    gpu::dfree(p.snap.items);
-    gpu::dfree(p.snap.nodes);
-    gpu::dfree(p.snap.leafcnt);
-    p.has_snap = false;
-  }
-  const uint64_t N = p.v.g.N, leaves = N >> p.v.g.sh;
-  p.snap = p.v;
-  p.snap.wres = nullptr;
-  GCHK(gpu::dmalloc((void **)&p.snap.items, N * sizeof(Edge)));
-  GCHK(gpu::dmalloc((void **)&p.snap.nodes, p.n_cap * sizeof(Node)));
-  GCHK(gpu::dmalloc((void **)&p.snap.leafcnt, leaves * sizeof(uint32_t)));
-  p.snap_n_cap = p.n_cap;
-  GCHK(gpu::d2d(p.snap.items, p.v.items, N * sizeof(Edge), p.stream));
-  GCHK(gpu::d2d(p.snap.nodes, p.v.nodes, (uint64_t)p.v.g.n * sizeof(Node), p.stream));
-  GCHK(gpu::d2d(p.snap.leafcnt, p.v.leafcnt, leaves * sizeof(uint32_t), p.stream));
+  GCHK(snap_save(p, p.snap));
   GCHK(gpu::sync(p.stream));
-  p.has_snap = true;
   return PPCSR_OK;
 }
 
 int Engine::restore() {
   Impl &p = *p_;
-  if (!p.has_snap) return fail(PPCSR_EINVAL, "restore without snapshot");
+  if (!p.snap.valid) return fail(PPCSR_EINVAL, "restore without snapshot");
   GCHK(gpu::set_device(device_));
-  const uint64_t N = p.snap.g.N, leaves = N >> p.snap.g.sh;
-  if (p.v.g.N != N) {  // the array was resized since the snapshot: go back to buffers of the old size
-    gpu::dfree(p.v.items);
-    gpu::dfree(p.v.leafcnt);
-    gpu::dfree(p.v.wres);
-    GCHK(gpu::dmalloc((void **)&p.v.items, N * sizeof(Edge)));
-    GCHK(gpu::dmalloc((void **)&p.v.leafcnt, leaves * sizeof(uint32_t)));
-    GCHK(gpu::dmalloc((void **)&p.v.wres, leaves * sizeof(unsigned long long)));
-    GCHK(gpu::dset(p.v.wres, 0xFF, leaves * sizeof(unsigned long long), p.stream));
-    p.leaves_cap = leaves;
-    p.round = 0;
-  }
-  if (p.n_cap < p.snap_n_cap) return fail(PPCSR_EINTERNAL, "node capacity shrank");
-  p.v.g = p.snap.g;
-  GCHK(gpu::d2d(p.v.items, p.snap.items, N * sizeof(Edge), p.stream));
-  GCHK(gpu::d2d(p.v.nodes, p.snap.nodes, (uint64_t)p.snap.g.n * sizeof(Node), p.stream));
-  GCHK(gpu::d2d(p.v.leafcnt, p.snap.leafcnt, leaves * sizeof(uint32_t), p.stream));
+  GCHK(snap_load(p, p.snap));
   return PPCSR_OK;
 }
 

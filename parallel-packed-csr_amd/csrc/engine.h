@@ -17,7 +17,7 @@ struct EngineStats {
   int logN, H;
   uint64_t rounds, committed, planned, exclusive_ops, round_syncs;
   uint64_t redistribute_calls, redistribute_slots;  // algorithmic (what the reference performs)
-  uint64_t double_calls, half_calls, big_redistributes;
+  uint64_t double_calls, half_calls, big_redistributes, rollbacks;
   uint64_t not_found, duplicates, noops, slide_slots;
   uint64_t ops_applied;
   double last_batch_ms;      // device-only time of the last apply_batch (ops resident in HBM)
@@ -70,7 +70,12 @@ class Engine {
   int fail(int code, const std::string &msg);
   int pull_stats();
 
+  int run_speculative(const Op *d_ops, uint64_t n);
+
+ public:
   struct Impl;
+
+ private:
   Impl *p_;
   int device_ = 0;
   std::string err_;

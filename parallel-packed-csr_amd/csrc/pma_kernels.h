@@ -546,4 +546,259 @@ PMA_KERNEL void k_scan_write(View v, const uint32_t *chunkoff, unsigned long lon
   }
 }
 
+// =====================================================================================================================
+// Speculative rounds ("optimistic mode"): commit more than a strict prefix per round, validated, with rollback.
+//
+// A round plans the M lowest pending updates (the carry list of deferred updates, then fresh ones from the stream).
+// Every plan reserves its write leaves (wres) and read leaves (rres) with atomicMin(stream index).  An update PASSES
+// when no earlier pending update writes anything it reads or writes and no earlier pending update reads anything it
+// writes.  Passing updates commit unless an earlier update of the same REGION (aligned block of 2^regshift leaves)
+// failed this round — a per-region strict prefix, which keeps later updates from overtaking a deferred update inside
+// the block where its footprint can still move (rebalance windows are aligned power-of-two blocks no larger than a
+// region, so a deferred update's window cannot leave its region).
+//
+// Soundness does not rest on that heuristic: every committed update stamps the leaves it read (rstamp) and wrote
+// (wstamp) with its stream index, and an update may only commit if no LATER update has already written a leaf it
+// reads or writes, nor read a leaf it writes.  With that check the executed schedule is conflict-serialisable in
+// stream order (every conflicting pair ran in index order), i.e. identical to the reference's sequential result.  A
+// failed check raises `violation`: the host restores the epoch snapshot and replays the epoch with the strict prefix
+// rounds above.  K_EXCL updates are barriers: nothing later commits until the exclusive executor has run them.
+// =====================================================================================================================
+struct OptCtl {
+  uint32_t carry_n[2], next_fresh[2], hor[2];
+  uint32_t e1;  // end of the epoch (exclusive stream index)
+  uint32_t violation, excl, done, error;
+  uint32_t max_horizon, excl_idx;
+  uint32_t maxc;  // 1 + largest stream index committed in this epoch
+  uint32_t viol_idx;  // smallest stream index whose commit-time validation failed
+  unsigned long long gbar[2];  // keyed min index of a K_EXCL update in the horizon
+  unsigned long long rounds, committed, planned, blocked, failed;
+};
+struct OptArgs {
+  View v;
+  const Op *ops;
+  Plan *plans;
+  uint32_t *opidx, *status;
+  uint32_t *carry0, *carry1;
+  OptCtl *ctl;
+  StatShard *stats;
+  unsigned long long *regfail;
+  uint32_t *wstamp, *rstamp;
+  uint32_t round;
+  int regshift;
+};
+constexpr uint32_t OS_PASS = 1u, OS_STAMP_BAD = 2u, OS_COMMITTED = 4u;
+
+PMA_DEV bool key_earlier(unsigned long long k, uint32_t tag, uint32_t idx) { return (uint32_t)(k >> 32) == tag && (uint32_t)k < idx; }
+
+PMA_KERNEL void o_plan(OptArgs a) {
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  if (c->done || c->violation || c->excl || c->error) return;
+  const uint32_t hor = c->hor[par], cn = c->carry_n[par], nf = c->next_fresh[par];
+  const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
+  if (wid >= hor) return;
+  const uint32_t used = cn < hor ? cn : hor;
+  const uint32_t *carry = par ? a.carry1 : a.carry0;
+  const uint32_t idx = (wid < used) ? carry[wid] : nf + (wid - used);
+  const Op op = a.ops[idx];
+  Plan *pl = &a.plans[wid];
+  dev::plan_op(a.v, op, pl);
+  wv::fence();
+  const int lane = wv::lane();
+  if (lane == 0) a.opidx[wid] = idx;
+  const unsigned long long key = make_key(a.round, idx);
+  const uint32_t kind = pl->kind;
+  if (kind == K_EXCL) {
+    if (lane == 0) wv::atomic_min_u64(&c->gbar[par], key);
+    return;
+  }
+  if (kind_writes(kind)) {
+    const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
+    for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_min_u64(&a.v.wres[leaf], key);
+  }
+  const uint32_t nr = pl->nr;
+  for (uint32_t r = 0; r < nr; r++) {
+    const uint32_t lo = pl->rlo[r], hi = pl->rhi[r];
+    for (uint32_t leaf = lo + (uint32_t)lane; leaf <= hi; leaf += 64) wv::atomic_min_u64(&a.v.rres[leaf], key);
+  }
+}
+
+PMA_KERNEL void o_check(OptArgs a) {
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  if (c->done || c->violation || c->excl || c->error) return;
+  const uint32_t hor = c->hor[par];
+  const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
+  if (wid >= hor) return;
+  const int lane = wv::lane();
+  const uint32_t idx = a.opidx[wid];
+  const Plan *pl = &a.plans[wid];
+  const uint32_t kind = pl->kind;
+  const unsigned long long key = make_key(a.round, idx);
+  const uint32_t tag = (uint32_t)(key >> 32);
+  bool fail = (kind == K_EXCL) || key_earlier(c->gbar[par], tag, idx);
+  bool stamp_bad = false;
+  const uint32_t me1 = idx + 1u;  // stamps hold (index + 1) of the latest committed toucher
+  const bool writes = kind_writes(kind);
+  if (writes) {
+    const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
+    for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) {
+      if (a.v.wres[leaf] != key) fail = true;                   // an earlier pending update writes it
+      if (key_earlier(a.v.rres[leaf], tag, idx)) fail = true;   // an earlier pending update reads it
+      if (a.wstamp[leaf] > me1 || a.rstamp[leaf] > me1) stamp_bad = true;  // a LATER update already touched it
+    }
+  }
+  const uint32_t nr = pl->nr;
+  for (uint32_t r = 0; r < nr; r++) {
+    const uint32_t lo = pl->rlo[r], hi = pl->rhi[r];
+    for (uint32_t leaf = lo + (uint32_t)lane; leaf <= hi; leaf += 64) {
+      if (key_earlier(a.v.wres[leaf], tag, idx)) fail = true;   // an earlier pending update writes what we read
+      if (a.wstamp[leaf] > me1) stamp_bad = true;               // a LATER update already wrote what we read
+    }
+  }
+  const bool anyfail = wv::ballot(fail) != 0;
+  const bool anybad = wv::ballot(stamp_bad) != 0;
+  uint32_t glo, ghi;
+  if (writes) {
+    glo = pl->wleaf_lo >> a.regshift;
+    ghi = pl->wleaf_hi >> a.regshift;
+  } else {
+    glo = ghi = (pl->index >> a.v.g.sh) >> a.regshift;
+  }
+  if (anyfail && kind != K_NOOP) {
+    for (uint32_t g = glo + (uint32_t)lane; g <= ghi; g += 64) wv::atomic_min_u64(&a.regfail[g], key);
+  }
+  if (lane == 0) a.status[wid] = (anyfail ? 0u : OS_PASS) | (anybad ? OS_STAMP_BAD : 0u);
+}
+
+PMA_KERNEL void o_apply(OptArgs a) {
+  PMA_SHARED uint32_t lds[4][192];
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  if (c->done || c->violation || c->excl || c->error) return;
+  const uint32_t hor = c->hor[par];
+  const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
+  if (wid >= hor) return;
+  const int lane = wv::lane();
+  const uint32_t st = a.status[wid];
+  if (!(st & OS_PASS)) return;
+  const uint32_t idx = a.opidx[wid];
+  const Plan *pl = &a.plans[wid];
+  const uint32_t kind = pl->kind;
+  const unsigned long long key = make_key(a.round, idx);
+  const uint32_t tag = (uint32_t)(key >> 32);
+  const bool writes = kind_writes(kind);
+  if (kind != K_NOOP) {
+    uint32_t glo, ghi;
+    if (writes) {
+      glo = pl->wleaf_lo >> a.regshift;
+      ghi = pl->wleaf_hi >> a.regshift;
+    } else {
+      glo = ghi = (pl->index >> a.v.g.sh) >> a.regshift;
+    }
+    bool blocked = false;
+    for (uint32_t g = glo + (uint32_t)lane; g <= ghi; g += 64)
+      if (key_earlier(a.regfail[g], tag, idx)) blocked = true;
+    if (wv::ballot(blocked) != 0) return;  // an earlier update of this region was deferred: keep stream order inside it
+  }
+  if (st & OS_STAMP_BAD) {
+    if (lane == 0) {
+      wv::atomic_min_u32(&c->viol_idx, idx);
+      wv::atomic_exch_u32(&c->violation, 1u);
+    }
+    return;
+  }
+  const Op op = a.ops[idx];
+#if defined(PPCSR_SIM)
+  if (lane == 0 && getenv("PPCSR_TRACE"))
+    fprintf(stderr, "R%u commit idx=%u op=(%u,%u,%u) kind=%u index=%u gap=%u win=(%u,%u) wleaf=[%u,%u] nr=%u\n", a.round, idx, op.src,
+            op.dst, op.op, kind, pl->index, pl->gap, pl->wstart, pl->wlen, pl->wleaf_lo, pl->wleaf_hi, pl->nr);
+#endif
+  dev::apply_op(a.v, op, pl, lds[wv::wave_in_block()], &a.stats[wv::block_idx() & (kStatShards - 1)]);
+  const uint32_t me1 = idx + 1u;
+  if (writes) {
+    const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
+    for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_max_u32(&a.wstamp[leaf], me1);
+  }
+  const uint32_t nr = pl->nr;
+  for (uint32_t r = 0; r < nr; r++) {
+    const uint32_t lo = pl->rlo[r], hi = pl->rhi[r];
+    for (uint32_t leaf = lo + (uint32_t)lane; leaf <= hi; leaf += 64) wv::atomic_max_u32(&a.rstamp[leaf], me1);
+  }
+  if (lane == 0) {
+    a.status[wid] = OS_COMMITTED;
+    wv::atomic_max_u32(&c->maxc, me1);
+  }
+}
+
+// one workgroup: stable compaction of the deferred updates into the next carry list + next round's bookkeeping
+PMA_KERNEL void o_compact(OptArgs a) {
+  PMA_SHARED uint32_t wsum[16];
+  PMA_SHARED uint32_t s_count;
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  if (c->done || c->violation || c->excl || c->error) return;
+  const uint32_t hor = c->hor[par], cn = c->carry_n[par], nf = c->next_fresh[par];
+  const uint32_t used = cn < hor ? cn : hor;
+  const uint32_t *cin = par ? a.carry1 : a.carry0;
+  uint32_t *cout = par ? a.carry0 : a.carry1;
+  const uint32_t tid = wv::thread_idx(), bd = wv::block_dim();
+  const int lane = wv::lane(), w = wv::wave_in_block();
+  const uint32_t nw = bd >> 6;
+  if (tid == 0) s_count = 0;
+  wv::block_sync();
+  uint32_t ncommitted = 0;
+  for (uint32_t base = 0; base < hor; base += bd) {
+    const uint32_t s = base + tid;
+    bool keep = false;
+    uint32_t idx = 0;
+    if (s < hor) {
+      keep = a.status[s] != OS_COMMITTED;
+      idx = a.opidx[s];
+    }
+    const uint64_t m = wv::ballot(keep);
+    const uint32_t wcnt = (uint32_t)wv::popc64(m);
+    if (lane == 0) wsum[w] = wcnt;
+    wv::block_sync();
+    uint32_t woff = 0, tot = 0;
+    for (uint32_t q = 0; q < nw; q++) {
+      if (q < (uint32_t)w) woff += wsum[q];
+      tot += wsum[q];
+    }
+    const uint32_t cbase = s_count;
+    if (keep) cout[cbase + woff + dev::lanemask_lt_count(m, lane)] = idx;
+    wv::block_sync();
+    if (tid == 0) s_count = cbase + tot;
+    const uint32_t inchunk = (hor - base < bd) ? hor - base : bd;
+    ncommitted += inchunk - tot;
+    wv::block_sync();
+  }
+  const uint32_t kept = s_count;
+  for (uint32_t i = used + tid; i < cn; i += bd) cout[kept + (i - used)] = cin[i];  // carry entries beyond the horizon
+  wv::block_sync();
+  if (tid == 0) {
+    const uint32_t new_cn = kept + (cn - used);
+    const uint32_t new_nf = nf + (hor - used);
+    uint32_t nh = new_cn + (c->e1 - new_nf);
+    if (nh > c->max_horizon) nh = c->max_horizon;
+    c->carry_n[par ^ 1u] = new_cn;
+    c->next_fresh[par ^ 1u] = new_nf;
+    c->hor[par ^ 1u] = nh;
+    const unsigned long long gb = c->gbar[par];
+    c->gbar[par ^ 1u] = ~0ull;
+    c->gbar[par] = ~0ull;
+    if (new_cn == 0 && new_nf == c->e1) c->done = 1;
+    const uint32_t lowest = new_cn ? cout[0] : new_nf;
+    const uint32_t tag = (uint32_t)(make_key(a.round, 0) >> 32);
+    if (!c->done && (uint32_t)(gb >> 32) == tag && (uint32_t)gb == lowest) {
+      c->excl = 1;
+      c->excl_idx = lowest;
+    }
+    c->rounds += 1ull;
+    c->committed += (unsigned long long)ncommitted;
+    c->planned += (unsigned long long)hor;
+  }
+}
+
 }  // namespace ppcsr

@@ -5,6 +5,7 @@
 // sim build is a separate .so that only tests/ load explicitly.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 

@@ -17,6 +17,26 @@ def pkg():
     return p
 
 
+# every parity test runs under both schedulers: strict prefix rounds (mode 0) and speculative rounds with
+# validated rollback (mode 1, the default); small horizons/epochs/regions force rollbacks to happen in the tests
+MODES = {
+    "strict": dict(mode=0),
+    "speculative": dict(mode=1),
+    "speculative-small": dict(mode=1, opt_horizon=1024, epoch_ops=4096, region_slots=256),
+}
+
+
+@pytest.fixture(params=list(MODES))
+def mk(request, pkg):
+    def make(n, lock=True):
+        e = pkg.PCSR(n, lock_search=lock)
+        for k, v in MODES[request.param].items():
+            e.set_option(k, v)
+        return e
+    make.mode = request.param
+    return make
+
+
 def _same(eng, o, label=""):
     assert eng.geometry() == o.geometry(), f"{label}: geometry {eng.geometry()} vs {o.geometry()}"
     ei, en = eng.state()
@@ -37,8 +57,8 @@ def _stats_match(eng, o):
 
 
 @pytest.mark.parametrize("name", GOLDEN_SINGLE)
-def test_golden(pkg, name):
-    eng = replay_golden(lambda n, lock: pkg.PCSR(n, lock_search=lock), name)
+def test_golden(mk, name):
+    eng = replay_golden(lambda n, lock: mk(n, lock), name)
     assert eng.check_invariants() == 0
 
 
@@ -73,11 +93,11 @@ def test_pppcsr_golden(pkg):
 
 @pytest.mark.parametrize("seed,n", [(0, 30), (1, 300), (2, 3000), (3, 20000), (4, 100000)])
 @pytest.mark.parametrize("lock", [True, False])
-def test_random_mixed_vs_oracle(pkg, streams, seed, n, lock):
+def test_random_mixed_vs_oracle(mk, streams, seed, n, lock):
     core = streams.random_stream(n, 60000, seed=100 + seed)
     fresh = streams.random_stream(n, 20000, seed=200 + seed)
     ops = np.concatenate([core, streams.mixed_existing_stream(core, fresh, seed=300 + seed)])
-    eng, o = pkg.PCSR(n, lock_search=lock), Oracle(n, lock_search=lock)
+    eng, o = mk(n, lock), Oracle(n, lock_search=lock)
     for lo in range(0, len(ops), 25000):
         eng.apply(ops[lo:lo + 25000])
         o.apply(ops[lo:lo + 25000])
@@ -85,7 +105,7 @@ def test_random_mixed_vs_oracle(pkg, streams, seed, n, lock):
     _stats_match(eng, o)
 
 
-def test_hubs_and_last_vertex(pkg, streams):
+def test_hubs_and_last_vertex(mk, streams):
     m = 20000
     for src_mode in ("last", "first", "tail"):
         hub = np.stack([np.full(m, 9), streams.uniform_ints(3, m, 1 << 30), np.ones(m)], 1).astype(np.uint32)
@@ -96,32 +116,32 @@ def test_hubs_and_last_vertex(pkg, streams):
         dele = hub.copy()
         dele[:, 2] = 0
         ops = np.concatenate([hub, dele[::-1]])
-        eng, o = pkg.PCSR(10), Oracle(10)
+        eng, o = mk(10), Oracle(10)
         eng.apply(ops)
         o.apply(ops)
         _same(eng, o, src_mode)
         _stats_match(eng, o)
 
 
-def test_ascending_and_descending_runs(pkg):
+def test_ascending_and_descending_runs(mk):
     """long slides (descending dests) and end-of-array inserts (ascending dests into the last vertex)"""
     m = 12000
     for order in ("asc", "desc"):
         d = np.arange(m) + 5 if order == "asc" else np.arange(m, 0, -1) + 5
         ops = np.stack([np.full(m, 9), d, np.ones(m)], 1).astype(np.uint32)
-        eng, o = pkg.PCSR(10), Oracle(10)
+        eng, o = mk(10), Oracle(10)
         eng.apply(ops)
         o.apply(ops)
         _same(eng, o, order)
 
 
-def test_rmat_core_plus_updates(pkg, streams):
+def test_rmat_core_plus_updates(mk, streams):
     s, d = streams.rmat_edges(16, 600000, seed=1)
     core = streams.adds(s, d)
     s2, d2 = streams.rmat_edges(16, 100000, seed=2)
     upd = streams.mixed_existing_stream(core, streams.adds(s2, d2), seed=3)
     n = 1 << 16
-    eng, o = pkg.PCSR(n), Oracle(n)
+    eng, o = mk(n), Oracle(n)
     eng.apply(core)
     o.apply(core)
     _same(eng, o, "core")

@@ -34,6 +34,10 @@ def sim():
 
     def make(n, lock=True, **opts):
         e = pkg.PCSR(n, lock_search=lock, lib=lib)
+        e.set_option("mode", opts.get("mode", 0))
+        e.set_option("opt_horizon", opts.get("opt_horizon", 64))
+        e.set_option("epoch_ops", opts.get("epoch_ops", 1024))
+        e.set_option("region_slots", opts.get("region_slots", 64))
         e.set_option("max_horizon", opts.get("max_horizon", 32))
         e.set_option("min_horizon", opts.get("min_horizon", 4))
         e.set_option("init_horizon", opts.get("init_horizon", 8))
@@ -78,3 +82,23 @@ def test_sim_mixed_with_resizes(sim, streams):
 def test_sim_golden_small(sim, name):
     eng = replay_golden(lambda n, lock: sim(n, lock), name, check_every=True)
     assert eng.check_invariants() == 0
+
+
+@pytest.mark.parametrize("name,region", [("random_2e4_n1000", 128), ("random_2e4_n1000", 16), ("dense_n40_grow_shrink", 64)])
+def test_sim_speculative_rounds(sim, name, region):
+    """speculative scheduler (mode 1) incl. validation failures -> rollback -> cut / strict replay"""
+    eng = replay_golden(lambda n, lock: sim(n, lock, mode=1, opt_horizon=256, epoch_ops=4096, region_slots=region), name)
+    st = eng.stats()
+    assert eng.check_invariants() == 0
+    assert st["rollbacks"] > 0  # the small regions / doublings of these fixtures must exercise the rollback path
+
+
+def test_sim_speculative_stats_survive_rollback(sim, streams):
+    ops = streams.random_stream(1000, 12000, seed=5, p_delete=0.2)
+    e, o = sim(1000, mode=1, opt_horizon=256, epoch_ops=2048, region_slots=32), Oracle(1000)
+    e.apply(ops)
+    o.apply(ops)
+    _same(e, o)
+    se, so = e.stats(), o.stats()
+    for k in ("redistribute_calls", "redistribute_slots", "double_calls", "not_found", "duplicates"):
+        assert se[k] == so[k], k
