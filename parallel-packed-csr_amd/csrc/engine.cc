@@ -2,11 +2,13 @@
 #include "engine.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <chrono>
 
 #include "gpu_rt.h"
+#define GPU_DFREE(x) gpu::dfree_named((x), #x, __LINE__)
 #include "pma_kernels.h"
 
 namespace ppcsr {
@@ -63,12 +65,13 @@ struct Engine::Impl {
   Snap snap, esnap;
   // speculative scheduler state
   OptCtl *d_octl = nullptr, *h_octl = nullptr;
+  uint32_t *d_vdbg = nullptr;
   uint32_t *d_opidx = nullptr, *d_status = nullptr, *d_carry0 = nullptr, *d_carry1 = nullptr;
   uint64_t carry_cap = 0, hslot_cap = 0;
-  unsigned long long *d_regfail = nullptr;
+  unsigned long long *d_regfail = nullptr, *d_pfail = nullptr;
   uint32_t *d_wstamp = nullptr, *d_rstamp = nullptr;
   uint32_t mode = 1;             // 0 = strict prefix rounds, 1 = speculative rounds with validated rollback
-  uint32_t epoch_ops = 1u << 18;  // rollback granularity
+  uint32_t epoch_ops = 1u << 20;  // rollback granularity
   uint32_t region_slots = 4096;  // per-region prefix rule (>= kBigWindow so a window never leaves its region)
   uint32_t opt_horizon = 32768;
   bool partial = false;
@@ -87,6 +90,8 @@ static int alloc_aux(Engine::Impl &p, View &v) {
   if ((e = gpu::dmalloc((void **)&p.d_wstamp, leaves * sizeof(uint32_t)))) return e;
   if ((e = gpu::dmalloc((void **)&p.d_rstamp, leaves * sizeof(uint32_t)))) return e;
   if ((e = gpu::dmalloc((void **)&p.d_regfail, (leaves + 1) * sizeof(unsigned long long)))) return e;
+  if ((e = gpu::dmalloc((void **)&p.d_pfail, (leaves + 1) * sizeof(unsigned long long)))) return e;
+  if ((e = gpu::dset(p.d_pfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream))) return e;
   if ((e = gpu::dset(v.wres, 0xFF, leaves * sizeof(unsigned long long), p.stream))) return e;
   if ((e = gpu::dset(v.rres, 0xFF, leaves * sizeof(unsigned long long), p.stream))) return e;
   if ((e = gpu::dset(p.d_regfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream))) return e;
@@ -97,11 +102,13 @@ static int alloc_aux(Engine::Impl &p, View &v) {
   return 0;
 }
 static void free_aux(Engine::Impl &p, View &v) {
-  gpu::dfree(v.wres);
-  gpu::dfree(v.rres);
-  gpu::dfree(p.d_wstamp);
-  gpu::dfree(p.d_rstamp);
-  gpu::dfree(p.d_regfail);
+  GPU_DFREE(v.wres);
+  GPU_DFREE(v.rres);
+  GPU_DFREE(p.d_wstamp);
+  GPU_DFREE(p.d_rstamp);
+  GPU_DFREE(p.d_regfail);
+  GPU_DFREE(p.d_pfail);
+  p.d_pfail = nullptr;
   v.wres = v.rres = nullptr;
   p.d_wstamp = p.d_rstamp = nullptr;
   p.d_regfail = nullptr;
@@ -146,6 +153,7 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   if (ndev <= 0) return fail(PPCSR_EHIP, "no HIP device visible: the MI355X engine has no CPU fallback");
   if (device < 0 || device >= ndev) return fail(PPCSR_EINVAL, "bad device ordinal");
   GCHK(gpu::set_device(device));
+  (void)gpu::last_error();  // drop any stale error left on this thread by earlier, unrelated runtime calls
   GCHK(gpu::stream_create(&p.stream));
   GCHK(p.timer.init());
   const uint64_t N = initial_N(init_n, src_n);
@@ -204,36 +212,37 @@ Engine::~Engine() {
   Impl &p = *p_;
   gpu::set_device(device_);
   gpu::sync(p.stream);
-  gpu::dfree(p.v.items);
-  gpu::dfree(p.v.nodes);
-  gpu::dfree(p.v.leafcnt);
+  GPU_DFREE(p.v.items);
+  GPU_DFREE(p.v.nodes);
+  GPU_DFREE(p.v.leafcnt);
   free_aux(p, p.v);
-  gpu::dfree(p.d_octl);
+  GPU_DFREE(p.d_octl);
   gpu::hfree(p.h_octl);
-  if (p.d_opidx) gpu::dfree(p.d_opidx);
-  if (p.d_status) gpu::dfree(p.d_status);
-  if (p.d_carry0) gpu::dfree(p.d_carry0);
-  if (p.d_carry1) gpu::dfree(p.d_carry1);
-  gpu::dfree(p.d_ctl);
+  if (p.d_opidx) GPU_DFREE(p.d_opidx);
+  if (p.d_status) GPU_DFREE(p.d_status);
+  if (p.d_vdbg) GPU_DFREE(p.d_vdbg);
+  if (p.d_carry0) GPU_DFREE(p.d_carry0);
+  if (p.d_carry1) GPU_DFREE(p.d_carry1);
+  GPU_DFREE(p.d_ctl);
   gpu::hfree(p.h_ctl);
-  gpu::dfree(p.d_stats);
+  GPU_DFREE(p.d_stats);
   gpu::hfree(p.h_stats);
-  gpu::dfree(p.d_stats_snap);
-  gpu::dfree(p.d_xout);
+  GPU_DFREE(p.d_stats_snap);
+  GPU_DFREE(p.d_xout);
   gpu::hfree(p.h_xout);
   gpu::hfree(p.h_op1);
-  gpu::dfree(p.d_total);
+  GPU_DFREE(p.d_total);
   gpu::hfree(p.h_total);
-  gpu::dfree(p.d_table);
-  gpu::dfree(p.d_plans);
-  if (p.d_ops) gpu::dfree(p.d_ops);
-  if (p.d_rank) gpu::dfree(p.d_rank);
-  if (p.d_tiles) gpu::dfree(p.d_tiles);
-  if (p.d_nbr) gpu::dfree(p.d_nbr);
+  GPU_DFREE(p.d_table);
+  GPU_DFREE(p.d_plans);
+  if (p.d_ops) GPU_DFREE(p.d_ops);
+  if (p.d_rank) GPU_DFREE(p.d_rank);
+  if (p.d_tiles) GPU_DFREE(p.d_tiles);
+  if (p.d_nbr) GPU_DFREE(p.d_nbr);
   for (Impl::Snap *sp : {&p.snap, &p.esnap}) {
-    if (sp->v.items) gpu::dfree(sp->v.items);
-    if (sp->v.nodes) gpu::dfree(sp->v.nodes);
-    if (sp->v.leafcnt) gpu::dfree(sp->v.leafcnt);
+    if (sp->v.items) GPU_DFREE(sp->v.items);
+    if (sp->v.nodes) GPU_DFREE(sp->v.nodes);
+    if (sp->v.leafcnt) GPU_DFREE(sp->v.leafcnt);
   }
   for (auto &e : p.events) e.destroy();
   p.timer.destroy();
@@ -250,7 +259,7 @@ int Engine::set_option(const char *key, int64_t value) {
     gpu::sync(p.stream);
     Plan *np = nullptr;
     GCHK(gpu::dmalloc((void **)&np, (uint64_t)value * sizeof(Plan)));
-    gpu::dfree(p.d_plans);
+    GPU_DFREE(p.d_plans);
     p.d_plans = np;
     p.max_horizon = (uint32_t)value;
     if (p.min_horizon > p.max_horizon) p.min_horizon = p.max_horizon;
@@ -308,7 +317,7 @@ int Engine::apply_batch_host(const Op *ops, uint64_t n) {
   if (!ops) return fail(PPCSR_EINVAL, "null ops");
   GCHK(gpu::set_device(device_));
   if (n > p.ops_cap) {
-    if (p.d_ops) gpu::dfree(p.d_ops);
+    if (p.d_ops) GPU_DFREE(p.d_ops);
     p.d_ops = nullptr;
     p.ops_cap = 0;
     GCHK(gpu::dmalloc((void **)&p.d_ops, n * sizeof(Op)));
@@ -432,20 +441,22 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
   Impl &p = *p_;
   // per-slot and carry arrays
   if (p.hslot_cap < p.opt_horizon) {
-    if (p.d_opidx) gpu::dfree(p.d_opidx);
-    if (p.d_status) gpu::dfree(p.d_status);
+    if (p.d_opidx) GPU_DFREE(p.d_opidx);
+    if (p.d_status) GPU_DFREE(p.d_status);
     p.d_opidx = p.d_status = nullptr;
     p.hslot_cap = 0;
     GCHK(gpu::dmalloc((void **)&p.d_opidx, (uint64_t)p.opt_horizon * sizeof(uint32_t)));
     GCHK(gpu::dmalloc((void **)&p.d_status, (uint64_t)p.opt_horizon * sizeof(uint32_t)));
-    gpu::dfree(p.d_plans);
+    if (p.d_vdbg) GPU_DFREE(p.d_vdbg);
+    GCHK(gpu::dmalloc((void **)&p.d_vdbg, (uint64_t)p.opt_horizon * 4 * sizeof(uint32_t)));
+    GPU_DFREE(p.d_plans);
     p.d_plans = nullptr;
     GCHK(gpu::dmalloc((void **)&p.d_plans, (uint64_t)std::max(p.opt_horizon, p.max_horizon) * sizeof(Plan)));
     p.hslot_cap = p.opt_horizon;
   }
   if (p.carry_cap < p.epoch_ops) {
-    if (p.d_carry0) gpu::dfree(p.d_carry0);
-    if (p.d_carry1) gpu::dfree(p.d_carry1);
+    if (p.d_carry0) GPU_DFREE(p.d_carry0);
+    if (p.d_carry1) GPU_DFREE(p.d_carry1);
     p.d_carry0 = p.d_carry1 = nullptr;
     p.carry_cap = 0;
     GCHK(gpu::dmalloc((void **)&p.d_carry0, (uint64_t)p.epoch_ops * sizeof(uint32_t)));
@@ -463,6 +474,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       GCHK(gpu::dset(p.v.wres, 0xFF, leaves * sizeof(unsigned long long), p.stream));
       GCHK(gpu::dset(p.v.rres, 0xFF, leaves * sizeof(unsigned long long), p.stream));
       GCHK(gpu::dset(p.d_regfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream));
+      GCHK(gpu::dset(p.d_pfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream));
       p.round = 0;
     }
     GCHK(snap_save(p, p.esnap));
@@ -494,11 +506,13 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       a.plans = p.d_plans;
       a.opidx = p.d_opidx;
       a.status = p.d_status;
+      a.vdbg = p.d_vdbg;
       a.carry0 = p.d_carry0;
       a.carry1 = p.d_carry1;
       a.ctl = p.d_octl;
       a.stats = p.d_stats;
       a.regfail = p.d_regfail;
+      a.pfail = p.d_pfail;
       a.wstamp = p.d_wstamp;
       a.rstamp = p.d_rstamp;
       a.regshift = rs;
@@ -536,6 +550,10 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         // and retry it cut right after that update (nothing can overtake the last update of an epoch); after
         // repeated failures replay the epoch with the strict prefix rounds
         p.st.rollbacks++;
+        if (getenv("PPCSR_TRACE_EPOCH"))
+          fprintf(stderr, "[ppcsr] rollback: epoch [%llu,%llu) viol_idx=%u excl=%u maxc=%u after %llu rounds; kind=%u leaf=%u stamp=%u what=%u wleaf=[%u,%u] index=%u nr=%u\n",
+                  (unsigned long long)e0, (unsigned long long)e1, c.viol_idx, c.excl, c.maxc, c.rounds, c.viol_info[0],
+                  c.viol_info[1], c.viol_info[2], c.viol_info[3], c.viol_info[4], c.viol_info[5], c.viol_info[6], c.viol_info[7]);
         GCHK(snap_load(p, p.esnap));
         GCHK(gpu::d2d(p.d_stats, p.d_stats_snap, kStatShards * sizeof(StatShard), p.stream));
         p.st.rounds += c.rounds;
@@ -564,6 +582,12 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         retries = 0;
         epoch_open = false;
       } else if (c.done) {
+        if (getenv("PPCSR_TRACE_EPOCH")) {
+          fprintf(stderr, "[ppcsr] epoch [%llu,%llu) rounds=%llu planned=%llu:", (unsigned long long)e0, (unsigned long long)e1,
+                  c.rounds, c.planned);
+          for (unsigned r = 0; r < 96 && r < c.rounds; r++) fprintf(stderr, " %u/%u", c.hist[2 * r + 1], c.hist[2 * r]);
+          fprintf(stderr, "\n");
+        }
         p.st.rounds += c.rounds;
         p.st.committed += c.committed;
         p.st.planned += c.planned;
@@ -612,7 +636,7 @@ int Engine::run_exclusive(Op op, uint32_t flags) {
 int Engine::ensure_scratch(uint64_t nleaves) {
   Impl &p = *p_;
   if (nleaves > p.rank_cap) {
-    if (p.d_rank) gpu::dfree(p.d_rank);
+    if (p.d_rank) GPU_DFREE(p.d_rank);
     p.d_rank = nullptr;
     p.rank_cap = 0;
     GCHK(gpu::dmalloc((void **)&p.d_rank, nleaves * sizeof(uint32_t)));
@@ -620,7 +644,7 @@ int Engine::ensure_scratch(uint64_t nleaves) {
   }
   const uint64_t ntiles = (nleaves + kScanTile - 1) / kScanTile;
   if (ntiles > p.tiles_cap) {
-    if (p.d_tiles) gpu::dfree(p.d_tiles);
+    if (p.d_tiles) GPU_DFREE(p.d_tiles);
     p.d_tiles = nullptr;
     p.tiles_cap = 0;
     GCHK(gpu::dmalloc((void **)&p.d_tiles, ntiles * sizeof(uint32_t)));
@@ -665,8 +689,8 @@ int Engine::resize(uint64_t newN) {
   GPU_LAUNCH(p.stream, k_recount, grid_for((newN + 63) / 64, 4), 256, nv, (uint64_t)0, newN);
   GCHK(gpu::sync(p.stream));
   GCHK(gpu::last_error());
-  gpu::dfree(old.items);
-  gpu::dfree(old.leafcnt);
+  GPU_DFREE(old.items);
+  GPU_DFREE(old.leafcnt);
   {
     View tmp = old;
     free_aux(p, tmp);
@@ -696,7 +720,7 @@ int Engine::big_redistribute(uint64_t wstart, uint64_t wlen) {
   GPU_LAUNCH(p.stream, k_recount, grid_for((wlen + 63) / 64, 4), 256, v, wstart, wlen);
   GCHK(gpu::sync(p.stream));
   GCHK(gpu::last_error());
-  gpu::dfree(tmp);
+  GPU_DFREE(tmp);
   p.st.big_redistributes++;
   return PPCSR_OK;
 }
@@ -723,7 +747,7 @@ int Engine::add_node() {  // PCSR.cpp:681-703
     GCHK(gpu::dmalloc((void **)&nn, ncap * sizeof(Node)));
     GCHK(gpu::d2d(nn, p.v.nodes, (uint64_t)len * sizeof(Node), p.stream));
     GCHK(gpu::sync(p.stream));
-    gpu::dfree(p.v.nodes);
+    GPU_DFREE(p.v.nodes);
     p.v.nodes = nn;
     p.n_cap = ncap;
   }
@@ -774,12 +798,7 @@ int Engine::get_neighbourhood(int src, int *out, uint64_t cap, uint64_t *count) 
   if (src < 0 || (uint64_t)src >= n()) return PPCSR_OK;  // reference returns an empty vector (PCSR.cpp:903)
   GCHK(gpu::set_device(device_));
   if (cap > p.nbr_cap) {
-    if (p.d_nbr) gpu::dfree(p.d_nbr);
-  for (Impl::Snap *sp : {&p.snap, &p.esnap}) {
-    if (sp->v.items) gpu::dfree(sp->v.items);
-    if (sp->v.nodes) gpu::dfree(sp->v.nodes);
-    if (sp->v.leafcnt) gpu::dfree(sp->v.leafcnt);
-  }
+    if (p.d_nbr) GPU_DFREE(p.d_nbr);
     p.d_nbr = nullptr;
     p.nbr_cap = 0;
     GCHK(gpu::dmalloc((void **)&p.d_nbr, cap * sizeof(int)));
@@ -824,9 +843,9 @@ int Engine::scan_all_device(double *ms, uint64_t *total) {
   GCHK(gpu::sync(p.stream));
   if (ms) *ms = p.timer.ms();
   if (total) *total = *p.h_total;
-  gpu::dfree(d_cc);
-  gpu::dfree(d_rows);
-  gpu::dfree(d_dst);
+  GPU_DFREE(d_cc);
+  GPU_DFREE(d_rows);
+  GPU_DFREE(d_dst);
   return PPCSR_OK;
 }
 
@@ -858,9 +877,9 @@ int Engine::scan_all(uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *
     GCHK(gpu::d2h(dests, d_dst, std::min(cap, tot) * sizeof(int), p.stream));
     GCHK(gpu::sync(p.stream));
   }
-  gpu::dfree(d_cc);
-  gpu::dfree(d_rows);
-  gpu::dfree(d_dst);
+  GPU_DFREE(d_cc);
+  GPU_DFREE(d_rows);
+  GPU_DFREE(d_dst);
   return (tot > cap && dests) ? PPCSR_ERANGE : PPCSR_OK;
 }
 
@@ -885,7 +904,7 @@ int Engine::check_invariants(uint64_t *bad) {
   GPU_LAUNCH(p.stream, k_recount, grid_for((N + 63) / 64, 4), 256, tmp, (uint64_t)0, N);
   GCHK(gpu::d2h(cnt2.data(), tmp.leafcnt, leaves * sizeof(uint32_t), p.stream));
   GCHK(gpu::sync(p.stream));
-  gpu::dfree(tmp.leafcnt);
+  GPU_DFREE(tmp.leafcnt);
   uint64_t b = 0;
   for (uint64_t i = 0; i < leaves; i++) b += cnt[i] != cnt2[i];
   *bad = b;
@@ -926,8 +945,8 @@ static int snap_save(Engine::Impl &p, Engine::Impl::Snap &sn) {
   const uint64_t N = p.v.g.N, leaves = N >> p.v.g.sh;
   int e;
   if (sn.cap_slots < N) {
-    if (sn.v.items) gpu::dfree(sn.v.items);
-    if (sn.v.leafcnt) gpu::dfree(sn.v.leafcnt);
+    if (sn.v.items) GPU_DFREE(sn.v.items);
+    if (sn.v.leafcnt) GPU_DFREE(sn.v.leafcnt);
     sn.v.items = nullptr;
     sn.v.leafcnt = nullptr;
     sn.cap_slots = 0;
@@ -936,7 +955,7 @@ static int snap_save(Engine::Impl &p, Engine::Impl::Snap &sn) {
     sn.cap_slots = N;
   }
   if (sn.cap_nodes < p.n_cap) {
-    if (sn.v.nodes) gpu::dfree(sn.v.nodes);
+    if (sn.v.nodes) GPU_DFREE(sn.v.nodes);
     sn.v.nodes = nullptr;
     sn.cap_nodes = 0;
     if ((e = gpu::dmalloc((void **)&sn.v.nodes, p.n_cap * sizeof(Node)))) return e;
@@ -953,8 +972,8 @@ static int snap_load(Engine::Impl &p, Engine::Impl::Snap &sn) {
   const uint64_t N = sn.v.g.N, leaves = N >> sn.v.g.sh;
   int e;
   if (p.v.g.N != N) {  // the array was resized since the snapshot: go back to buffers of the old size
-    gpu::dfree(p.v.items);
-    gpu::dfree(p.v.leafcnt);
+    GPU_DFREE(p.v.items);
+    GPU_DFREE(p.v.leafcnt);
     free_aux(p, p.v);
     if ((e = gpu::dmalloc((void **)&p.v.items, N * sizeof(Edge)))) return e;
     if ((e = gpu::dmalloc((void **)&p.v.leafcnt, leaves * sizeof(uint32_t)))) return e;

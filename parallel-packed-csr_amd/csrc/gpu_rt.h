@@ -20,6 +20,7 @@ inline int stream_create(stream_t *s) { *s = 0; return 0; }
 inline int stream_destroy(stream_t) { return 0; }
 inline int dmalloc(void **p, size_t b) { *p = ::malloc(b ? b : 1); return *p ? 0 : 2; }
 inline int dfree(void *p) { ::free(p); return 0; }
+inline int dfree_named(void *p, const char *, int) { ::free(p); return 0; }
 inline int hmalloc(void **p, size_t b) { *p = ::malloc(b ? b : 1); return *p ? 0 : 2; }
 inline int hfree(void *p) { ::free(p); return 0; }
 inline int h2d(void *d, const void *s, size_t b, stream_t) { memcpy(d, s, b); return 0; }
@@ -48,23 +49,35 @@ struct Event {
   sim::launch((uint32_t)(grid), (uint32_t)(block), [=]() { kernel(__VA_ARGS__); })
 #else
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 namespace gpu {
 typedef hipStream_t stream_t;
+inline int dbg_report(const char *what, int e) {
+  if (e && getenv("PPCSR_DEBUG")) fprintf(stderr, "[ppcsr] %s -> %s\n", what, hipGetErrorString((hipError_t)e));
+  return e;
+}
 inline const char *err_str(int e) { return hipGetErrorString((hipError_t)e); }
 inline int set_device(int d) { return (int)hipSetDevice(d); }
 inline int device_count(int *n) { return (int)hipGetDeviceCount(n); }
 inline int stream_create(stream_t *s) { return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
-inline int stream_destroy(stream_t s) { return (int)hipStreamDestroy(s); }
+inline int stream_destroy(stream_t s) { return dbg_report("hipStreamDestroy", (int)hipStreamDestroy(s)); }
 inline int dmalloc(void **p, size_t b) { return (int)hipMalloc(p, b ? b : 1); }
-inline int dfree(void *p) { return (int)hipFree(p); }
+inline int dfree(void *p) { return p ? dbg_report("hipFree", (int)hipFree(p)) : 0; }
+inline int dfree_named(void *p, const char *what, int line) {
+  if (!p) return 0;
+  int e = (int)hipFree(p);
+  if (e && getenv("PPCSR_DEBUG")) fprintf(stderr, "[ppcsr] hipFree(%s) at engine.cc:%d -> %s\n", what, line, hipGetErrorString((hipError_t)e));
+  return e;
+}
 inline int hmalloc(void **p, size_t b) { return (int)hipHostMalloc(p, b ? b : 1, hipHostMallocDefault); }
-inline int hfree(void *p) { return (int)hipHostFree(p); }
+inline int hfree(void *p) { return p ? dbg_report("hipHostFree", (int)hipHostFree(p)) : 0; }
 inline int h2d(void *d, const void *s, size_t b, stream_t st) { return (int)hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, st); }
 inline int d2h(void *d, const void *s, size_t b, stream_t st) { return (int)hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, st); }
 inline int d2d(void *d, const void *s, size_t b, stream_t st) { return (int)hipMemcpyAsync(d, s, b, hipMemcpyDeviceToDevice, st); }
 inline int dset(void *d, int v, size_t b, stream_t st) { return (int)hipMemsetAsync(d, v, b, st); }
 inline int sync(stream_t st) { return (int)hipStreamSynchronize(st); }
-inline int last_error() { return (int)hipGetLastError(); }
+inline int last_error() { return dbg_report("hipGetLastError", (int)hipGetLastError()); }
 struct Timer {
   hipEvent_t a = nullptr, b = nullptr;
   int init() {

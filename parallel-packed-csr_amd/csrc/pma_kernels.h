@@ -573,20 +573,25 @@ struct OptCtl {
   uint32_t viol_idx;  // smallest stream index whose commit-time validation failed
   unsigned long long gbar[2];  // keyed min index of a K_EXCL update in the horizon
   unsigned long long rounds, committed, planned, blocked, failed;
+  uint32_t viol_info[8];  // debug: kind, leaf, stamp, what(1=wstamp on W,2=rstamp on W,3=wstamp on R), wleaf_lo, wleaf_hi, index, round
+  uint32_t hist[192];  // debug: (horizon << 16 | committed) >> of the first rounds of the epoch
 };
 struct OptArgs {
   View v;
   const Op *ops;
   Plan *plans;
-  uint32_t *opidx, *status;
+  uint32_t *opidx, *status, *vdbg;
   uint32_t *carry0, *carry1;
   OptCtl *ctl;
   StatShard *stats;
   unsigned long long *regfail;
+  unsigned long long *pfail;  // per-leaf: smallest deferred update whose footprint may still grow over this leaf
   uint32_t *wstamp, *rstamp;
   uint32_t round;
   int regshift;
 };
+constexpr uint32_t kRegionPadLeaves = 2u;
+constexpr uint32_t kGrowLeaves = 8u;
 constexpr uint32_t OS_PASS = 1u, OS_STAMP_BAD = 2u, OS_COMMITTED = 4u;
 
 PMA_DEV bool key_earlier(unsigned long long k, uint32_t tag, uint32_t idx) { return (uint32_t)(k >> 32) == tag && (uint32_t)k < idx; }
@@ -616,6 +621,9 @@ PMA_KERNEL void o_plan(OptArgs a) {
   if (kind_writes(kind)) {
     const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_min_u64(&a.v.wres[leaf], key);
+    // an update whose window is already within two levels of the exclusive threshold is likely to turn exclusive
+    // once the earlier updates have landed: nothing later may overtake it (soft barrier)
+    if (pl->wlen >= kBigWindow / 4 && lane == 0) wv::atomic_min_u64(&c->gbar[par], key + 1ull);
   }
   const uint32_t nr = pl->nr;
   for (uint32_t r = 0; r < nr; r++) {
@@ -646,7 +654,12 @@ PMA_KERNEL void o_check(OptArgs a) {
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) {
       if (a.v.wres[leaf] != key) fail = true;                   // an earlier pending update writes it
       if (key_earlier(a.v.rres[leaf], tag, idx)) fail = true;   // an earlier pending update reads it
-      if (a.wstamp[leaf] > me1 || a.rstamp[leaf] > me1) stamp_bad = true;  // a LATER update already touched it
+      if (a.wstamp[leaf] > me1 || a.rstamp[leaf] > me1) {  // a LATER update already touched it
+        stamp_bad = true;
+        a.vdbg[4 * wid + 0] = leaf;
+        a.vdbg[4 * wid + 1] = a.wstamp[leaf] > me1 ? a.wstamp[leaf] : a.rstamp[leaf];
+        a.vdbg[4 * wid + 2] = a.wstamp[leaf] > me1 ? 1u : 2u;
+      }
     }
   }
   const uint32_t nr = pl->nr;
@@ -654,7 +667,12 @@ PMA_KERNEL void o_check(OptArgs a) {
     const uint32_t lo = pl->rlo[r], hi = pl->rhi[r];
     for (uint32_t leaf = lo + (uint32_t)lane; leaf <= hi; leaf += 64) {
       if (key_earlier(a.v.wres[leaf], tag, idx)) fail = true;   // an earlier pending update writes what we read
-      if (a.wstamp[leaf] > me1) stamp_bad = true;               // a LATER update already wrote what we read
+      if (a.wstamp[leaf] > me1) {  // a LATER update already wrote what we read
+        stamp_bad = true;
+        a.vdbg[4 * wid + 0] = leaf;
+        a.vdbg[4 * wid + 1] = a.wstamp[leaf];
+        a.vdbg[4 * wid + 2] = 3u + 16u * r;
+      }
     }
   }
   const bool anyfail = wv::ballot(fail) != 0;
@@ -667,7 +685,26 @@ PMA_KERNEL void o_check(OptArgs a) {
     glo = ghi = (pl->index >> a.v.g.sh) >> a.regshift;
   }
   if (anyfail && kind != K_NOOP) {
-    for (uint32_t g = glo + (uint32_t)lane; g <= ghi; g += 64) wv::atomic_min_u64(&a.regfail[g], key);
+    // a deferred update keeps later updates out of its region(s); its footprint may still creep over a region edge
+    // by a slide, so the mark is padded by kRegionPadLeaves leaves on both sides
+    const uint32_t nleaves = (uint32_t)(a.v.g.N >> a.v.g.sh);
+    uint32_t ll = writes ? pl->wleaf_lo : (pl->index >> a.v.g.sh), lh = writes ? pl->wleaf_hi : ll;
+    ll = (ll > kRegionPadLeaves) ? ll - kRegionPadLeaves : 0u;
+    lh = (lh + kRegionPadLeaves < nleaves) ? lh + kRegionPadLeaves : nleaves - 1u;
+    const uint32_t pglo = ll >> a.regshift, pghi = lh >> a.regshift;
+    for (uint32_t g = pglo + (uint32_t)lane; g <= pghi; g += 64) wv::atomic_min_u64(&a.regfail[g], key);
+    // leaf-level mark for later READERS: the deferred update's window can still grow to an ancestor block; cover
+    // the aligned block of 4x its tentative window (at least kGrowLeaves leaves) plus the slide pad
+    uint32_t wleaves = writes && pl->wlen ? (pl->wlen >> a.v.g.sh) : 1u;
+    if (wleaves < 1u) wleaves = 1u;
+    uint32_t blk = wleaves * 4u;
+    if (blk < kGrowLeaves) blk = kGrowLeaves;
+    const uint32_t anchor = writes && pl->wlen ? (pl->wstart >> a.v.g.sh) : (pl->index >> a.v.g.sh);
+    uint32_t bl = anchor & ~(blk - 1u), bh = bl + blk - 1u;
+    if (ll < bl) bl = ll;
+    if (lh > bh) bh = lh;
+    if (bh >= nleaves) bh = nleaves - 1u;
+    for (uint32_t leaf = bl + (uint32_t)lane; leaf <= bh; leaf += 64) wv::atomic_min_u64(&a.pfail[leaf], key);
   }
   if (lane == 0) a.status[wid] = (anyfail ? 0u : OS_PASS) | (anybad ? OS_STAMP_BAD : 0u);
 }
@@ -700,12 +737,28 @@ PMA_KERNEL void o_apply(OptArgs a) {
     bool blocked = false;
     for (uint32_t g = glo + (uint32_t)lane; g <= ghi; g += 64)
       if (key_earlier(a.regfail[g], tag, idx)) blocked = true;
+    const uint32_t nrr = pl->nr;
+    for (uint32_t r = 0; r < nrr; r++) {  // ... nor may we have READ a leaf an earlier deferred update may still grow over
+      const uint32_t lo = pl->rlo[r], hi = pl->rhi[r];
+      for (uint32_t leaf = lo + (uint32_t)lane; leaf <= hi; leaf += 64)
+        if (key_earlier(a.pfail[leaf], tag, idx)) blocked = true;
+    }
     if (wv::ballot(blocked) != 0) return;  // an earlier update of this region was deferred: keep stream order inside it
   }
   if (st & OS_STAMP_BAD) {
     if (lane == 0) {
-      wv::atomic_min_u32(&c->viol_idx, idx);
+      const uint32_t prev = wv::atomic_min_u32(&c->viol_idx, idx);
       wv::atomic_exch_u32(&c->violation, 1u);
+      if (idx < prev) {
+        c->viol_info[0] = kind;
+        c->viol_info[1] = a.vdbg[4 * wid + 0];
+        c->viol_info[2] = a.vdbg[4 * wid + 1];
+        c->viol_info[3] = a.vdbg[4 * wid + 2];
+        c->viol_info[4] = pl->wleaf_lo;
+        c->viol_info[5] = pl->wleaf_hi;
+        c->viol_info[6] = pl->index;
+        c->viol_info[7] = pl->nr;
+      }
     }
     return;
   }
@@ -794,6 +847,10 @@ PMA_KERNEL void o_compact(OptArgs a) {
     if (!c->done && (uint32_t)(gb >> 32) == tag && (uint32_t)gb == lowest) {
       c->excl = 1;
       c->excl_idx = lowest;
+    }
+    if (c->rounds < 96) {
+      c->hist[2 * c->rounds] = hor;
+      c->hist[2 * c->rounds + 1] = ncommitted;
     }
     c->rounds += 1ull;
     c->committed += (unsigned long long)ncommitted;
