@@ -30,6 +30,7 @@ struct View {
 constexpr uint32_t kBigWindow = 4096;  // windows larger than this run through the exclusive executor
 constexpr uint32_t kMaxSlide = 4096;   // slides longer than this too
 constexpr int kStatShards = 256;
+constexpr uint32_t kLdsWindow = 1024;  // windows up to this many slots are rebalanced inside one wave's LDS tile (12 KB)
 
 struct StatShard {
   unsigned long long redistribute_calls, redistribute_slots, not_found, duplicates, noops, slide_slots, committed, pad;
@@ -63,9 +64,11 @@ PMA_DEV void fix_sentinel(const View &v, const Edge &e, uint32_t in) {
   if (vid == v.g.n - 1) v.nodes[vid].end = (uint32_t)(v.g.N - 1);
 }
 
+constexpr uint32_t kLongRange = 8;  // read ranges spanning more leaves are walked by the whole wave
 struct RangeRec {  // read-leaf ranges collected by lane 0 into the plan record
   Plan *plan;
   uint32_t nr;
+  uint32_t nlong = 0;
 };
 PMA_DEV void rec_range(RangeRec &rr, const View &v, uint32_t slot_lo, uint32_t slot_hi) {
   if (!rr.plan) return;
@@ -75,12 +78,16 @@ PMA_DEV void rec_range(RangeRec &rr, const View &v, uint32_t slot_lo, uint32_t s
       rr.plan->rlo[rr.nr] = lo;
       rr.plan->rhi[rr.nr] = hi;
     }
+    if (hi - lo >= kLongRange) rr.nlong++;
     rr.nr++;
   } else if (wv::lane() == 0) {
     // overflow: widen the last range (conservative)
     uint32_t plo = rr.plan->rlo[kMaxR - 1], phi = rr.plan->rhi[kMaxR - 1];
     rr.plan->rlo[kMaxR - 1] = lo < plo ? lo : plo;
     rr.plan->rhi[kMaxR - 1] = hi > phi ? hi : phi;
+    rr.nlong++;
+  } else {
+    rr.nlong++;
   }
 }
 
@@ -308,7 +315,7 @@ PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index, RangeRec &rr) {
 // scatter staged through this wave's LDS tile, one coalesced store.  Larger windows (rare) are
 // streamed through the same wave in 64-slot chunks: stable in-place compaction to the left, null fill,
 // then spread right-to-left — the reference's own three phases, 64 slots at a time.
-PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, uint32_t *lds /* >= 3*64 u32 per wave */) {
+PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, uint32_t *lds /* 3*kLdsWindow u32 per wave */) {
   const int lane = wv::lane();
   Edge *items = v.items;
   const int sh = v.g.sh;
@@ -353,6 +360,98 @@ PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, ui
     if ((uint32_t)lane < nleaf) {
       const uint64_t sub = (logN >= 64) ? occ : ((occ >> ((uint32_t)lane * logN)) & ((1ull << logN) - 1ull));
       v.leafcnt[(wstart >> sh) + lane] = (uint32_t)wv::popc64(sub);
+    }
+    wv::fence();
+    return;
+  }
+  if (wlen <= kLdsWindow) {
+    // ---- LDS-staged path (64 < wlen <= kLdsWindow): the whole window lives in this wave's LDS tile ------
+    // global -> LDS (independent coalesced loads), stable in-place compaction, right-to-left spread with the
+    // exact position chain (the reference's three phases, PCSR.cpp:226-247, on LDS), LDS -> global.
+    uint32_t *ls = lds, *ld = lds + kLdsWindow, *lv = lds + 2 * kLdsWindow;
+    const uint32_t W = (uint32_t)wlen;
+    for (uint32_t o = (uint32_t)lane; o < W; o += 64) {
+      const Edge e = items[wstart + o];
+      ls[o] = e.src;
+      ld[o] = e.dest;
+      lv[o] = e.value;
+    }
+    wv::fence();
+    uint32_t j = 0;
+    for (uint32_t base = 0; base < W; base += 64) {  // compaction (chunk fully read before it is rewritten)
+      const uint32_t o = base + (uint32_t)lane;
+      const uint32_t es = ls[o], ed = ld[o], ev = lv[o];
+      const bool nn = ev != 0;
+      const uint64_t m = wv::ballot(nn);
+      const uint32_t k = j + lanemask_lt_count(m, lane);
+      wv::fence();
+      if (nn) {
+        ls[k] = es;
+        ld[k] = ed;
+        lv[k] = ev;
+      }
+      j += (uint32_t)wv::popc64(m);
+      wv::fence();
+    }
+    for (uint32_t o = j + (uint32_t)lane; o < W; o += 64) {
+      ls[o] = kMax;
+      ld[o] = 0;
+      lv[o] = 0;
+    }
+    wv::fence();
+    if (j >= 2) {
+      const double step = chain_step(wlen, j);
+      double x = chain_top(wstart, j, step);
+      uint32_t khi = j - 1;
+      while (khi >= 1) {
+        const uint32_t klo = (khi >= 64) ? khi - 63 : 1;
+        const uint32_t cntc = khi - klo + 1;
+        uint64_t mypos = 0;
+        for (uint32_t i = 0; i < cntc; i++) {
+          if ((uint32_t)lane == i) mypos = (uint64_t)x;
+          x = chain_sub(x, step);
+        }
+        const bool act = (uint32_t)lane < cntc;
+        const uint32_t so = khi - (uint32_t)lane;  // source offset in the compacted tile
+        uint32_t es = kMax, ed = 0, ev = 0;
+        if (act) {
+          es = ls[so];
+          ed = ld[so];
+          ev = lv[so];
+        }
+        wv::fence();
+        const uint32_t po = (uint32_t)(mypos - wstart);
+        if (act && po != so) {
+          ls[so] = kMax;
+          ld[so] = 0;
+          lv[so] = 0;
+        }
+        wv::fence();
+        if (act && po != so) {
+          ls[po] = es;
+          ld[po] = ed;
+          lv[po] = ev;
+        }
+        if (act) fix_sentinel(v, Edge{es, ed, ev}, (uint32_t)mypos);
+        wv::fence();
+        khi = klo - 1;
+      }
+    }
+    if (j >= 1 && lane == 0) fix_sentinel(v, Edge{ls[0], ld[0], lv[0]}, (uint32_t)wstart);
+    wv::fence();
+    for (uint32_t base = 0; base < W; base += 64) {  // LDS -> global + leaf counts
+      const uint32_t o = base + (uint32_t)lane;
+      Edge e;
+      e.src = ls[o];
+      e.dest = ld[o];
+      e.value = lv[o];
+      items[wstart + o] = e;
+      const uint64_t occ = wv::ballot(e.value != 0);
+      const uint32_t nleaf = (logN >= 64) ? 1u : (64u >> sh);
+      if ((uint32_t)lane < nleaf) {
+        const uint64_t sub = (logN >= 64) ? occ : ((occ >> ((uint32_t)lane * logN)) & ((1ull << logN) - 1ull));
+        v.leafcnt[((wstart + base) >> sh) + lane] = (uint32_t)wv::popc64(sub);
+      }
     }
     wv::fence();
     return;
@@ -528,6 +627,7 @@ PMA_DEV void plan_op(const View &v, const Op op, Plan *plan) {
     plan->alg_calls = acalls;
     plan->alg_slots = aslots;
     plan->nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
+    plan->nlong = rr.nlong;
   }
 }
 

@@ -12,6 +12,25 @@
 #pragma once
 #include "pma_device.h"
 
+// Visit every leaf of the plan's read ranges: lane r owns range r (ranges are almost always 1-2 leaves), so the
+// ranges are processed side by side instead of one dependent loop iteration after another.
+#define PMA_FOR_EACH_READ_LEAF(pl, lane, LEAFVAR, BODY)                                     \
+  do {                                                                                      \
+    const uint32_t _nr = (pl)->nr;                                                          \
+    for (uint32_t _r = (uint32_t)(lane); _r < _nr; _r += 64) {                              \
+      const uint32_t _lo = (pl)->rlo[_r], _hi = (pl)->rhi[_r];                              \
+      if (_hi - _lo < dev::kLongRange)                                                      \
+        for (uint32_t LEAFVAR = _lo; LEAFVAR <= _hi; LEAFVAR++) { BODY; }                   \
+    }                                                                                       \
+    if ((pl)->nlong) { /* rare: long ranges are walked by all lanes together */             \
+      for (uint32_t _r = 0; _r < _nr; _r++) {                                               \
+        const uint32_t _lo = (pl)->rlo[_r], _hi = (pl)->rhi[_r];                            \
+        if (_hi - _lo >= dev::kLongRange)                                                   \
+          for (uint32_t LEAFVAR = _lo + (uint32_t)(lane); LEAFVAR <= _hi; LEAFVAR += 64) { BODY; } \
+      }                                                                                     \
+    }                                                                                       \
+  } while (0)
+
 namespace ppcsr {
 
 struct RoundArgs {
@@ -68,19 +87,15 @@ PMA_KERNEL void k_check(RoundArgs a) {
     for (uint32_t leaf = wl + (uint32_t)wv::lane(); leaf <= wh; leaf += 64)
       if (a.v.wres[leaf] != key) fail = true;  // an earlier update writes this leaf
   }
-  const uint32_t nr = pl->nr;
-  for (uint32_t r = 0; r < nr; r++) {
-    const uint32_t lo = pl->rlo[r], hi = pl->rhi[r];
-    for (uint32_t leaf = lo + (uint32_t)wv::lane(); leaf <= hi; leaf += 64) {
-      const unsigned long long k = a.v.wres[leaf];
-      if ((uint32_t)(k >> 32) == tag && (uint32_t)k < idx) fail = true;  // an earlier update writes what we read
-    }
-  }
+  PMA_FOR_EACH_READ_LEAF(pl, wv::lane(), leaf, {
+    const unsigned long long k = a.v.wres[leaf];
+    if ((uint32_t)(k >> 32) == tag && (uint32_t)k < idx) fail = true;  // an earlier update writes what we read
+  });
   if (wv::ballot(fail) != 0 && wv::lane() == 0) wv::atomic_min_u32(&c->failmin[par], idx);
 }
 
 PMA_KERNEL void k_apply(RoundArgs a) {
-  PMA_SHARED uint32_t lds[4][192];
+  PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
   Control *c = a.ctl;
   const uint32_t par = a.round & 1u;
   if (c->error) return;
@@ -131,7 +146,7 @@ constexpr uint32_t XF_RESEARCH = 8u;      // add_node retry after double_list: s
 constexpr uint32_t kExclInWave = 1u << 16;
 
 PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatShard *st) {
-  PMA_SHARED uint32_t lds[192];
+  PMA_SHARED uint32_t lds[3 * kLdsWindow];
   const int lane = wv::lane();
   const Geometry &g = v.g;
   const int sh = g.sh;
@@ -594,6 +609,7 @@ constexpr uint32_t kRegionPadLeaves = 2u;
 constexpr uint32_t kGrowLeaves = 8u;
 constexpr uint32_t OS_PASS = 1u, OS_STAMP_BAD = 2u, OS_COMMITTED = 4u;
 
+
 PMA_DEV bool key_earlier(unsigned long long k, uint32_t tag, uint32_t idx) { return (uint32_t)(k >> 32) == tag && (uint32_t)k < idx; }
 
 PMA_KERNEL void o_plan(OptArgs a) {
@@ -625,11 +641,7 @@ PMA_KERNEL void o_plan(OptArgs a) {
     // once the earlier updates have landed: nothing later may overtake it (soft barrier)
     if (pl->wlen >= kBigWindow / 4 && lane == 0) wv::atomic_min_u64(&c->gbar[par], key + 1ull);
   }
-  const uint32_t nr = pl->nr;
-  for (uint32_t r = 0; r < nr; r++) {
-    const uint32_t lo = pl->rlo[r], hi = pl->rhi[r];
-    for (uint32_t leaf = lo + (uint32_t)lane; leaf <= hi; leaf += 64) wv::atomic_min_u64(&a.v.rres[leaf], key);
-  }
+  PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, wv::atomic_min_u64(&a.v.rres[leaf], key));
 }
 
 PMA_KERNEL void o_check(OptArgs a) {
@@ -662,19 +674,15 @@ PMA_KERNEL void o_check(OptArgs a) {
       }
     }
   }
-  const uint32_t nr = pl->nr;
-  for (uint32_t r = 0; r < nr; r++) {
-    const uint32_t lo = pl->rlo[r], hi = pl->rhi[r];
-    for (uint32_t leaf = lo + (uint32_t)lane; leaf <= hi; leaf += 64) {
-      if (key_earlier(a.v.wres[leaf], tag, idx)) fail = true;   // an earlier pending update writes what we read
-      if (a.wstamp[leaf] > me1) {  // a LATER update already wrote what we read
-        stamp_bad = true;
-        a.vdbg[4 * wid + 0] = leaf;
-        a.vdbg[4 * wid + 1] = a.wstamp[leaf];
-        a.vdbg[4 * wid + 2] = 3u + 16u * r;
-      }
+  PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, {
+    if (key_earlier(a.v.wres[leaf], tag, idx)) fail = true;  // an earlier pending update writes what we read
+    if (a.wstamp[leaf] > me1) {                               // a LATER update already wrote what we read
+      stamp_bad = true;
+      a.vdbg[4 * wid + 0] = leaf;
+      a.vdbg[4 * wid + 1] = a.wstamp[leaf];
+      a.vdbg[4 * wid + 2] = 3u;
     }
-  }
+  });
   const bool anyfail = wv::ballot(fail) != 0;
   const bool anybad = wv::ballot(stamp_bad) != 0;
   uint32_t glo, ghi;
@@ -710,7 +718,7 @@ PMA_KERNEL void o_check(OptArgs a) {
 }
 
 PMA_KERNEL void o_apply(OptArgs a) {
-  PMA_SHARED uint32_t lds[4][192];
+  PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
   if (c->done || c->violation || c->excl || c->error) return;
@@ -737,12 +745,8 @@ PMA_KERNEL void o_apply(OptArgs a) {
     bool blocked = false;
     for (uint32_t g = glo + (uint32_t)lane; g <= ghi; g += 64)
       if (key_earlier(a.regfail[g], tag, idx)) blocked = true;
-    const uint32_t nrr = pl->nr;
-    for (uint32_t r = 0; r < nrr; r++) {  // ... nor may we have READ a leaf an earlier deferred update may still grow over
-      const uint32_t lo = pl->rlo[r], hi = pl->rhi[r];
-      for (uint32_t leaf = lo + (uint32_t)lane; leaf <= hi; leaf += 64)
-        if (key_earlier(a.pfail[leaf], tag, idx)) blocked = true;
-    }
+    // ... nor may we have READ a leaf an earlier deferred update may still grow over
+    PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, { if (key_earlier(a.pfail[leaf], tag, idx)) blocked = true; });
     if (wv::ballot(blocked) != 0) return;  // an earlier update of this region was deferred: keep stream order inside it
   }
   if (st & OS_STAMP_BAD) {
@@ -774,11 +778,7 @@ PMA_KERNEL void o_apply(OptArgs a) {
     const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_max_u32(&a.wstamp[leaf], me1);
   }
-  const uint32_t nr = pl->nr;
-  for (uint32_t r = 0; r < nr; r++) {
-    const uint32_t lo = pl->rlo[r], hi = pl->rhi[r];
-    for (uint32_t leaf = lo + (uint32_t)lane; leaf <= hi; leaf += 64) wv::atomic_max_u32(&a.rstamp[leaf], me1);
-  }
+  PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, wv::atomic_max_u32(&a.rstamp[leaf], me1));
   if (lane == 0) {
     a.status[wid] = OS_COMMITTED;
     wv::atomic_max_u32(&c->maxc, me1);

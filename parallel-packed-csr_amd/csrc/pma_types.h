@@ -72,6 +72,7 @@ struct Plan {
   uint32_t wleaf_lo, wleaf_hi;  // inclusive leaf range written (slide + window)
   uint32_t alg_calls, alg_slots;  // redistribute() calls / slots the reference performs for this op
   uint32_t nr;
+  uint32_t nlong;  // number of read ranges spanning >= kLongRange leaves (0 for almost every update)
   uint32_t rlo[kMaxR], rhi[kMaxR];  // inclusive leaf ranges read by the search / vertex range lookup
 };
 
