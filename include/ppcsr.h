@@ -55,7 +55,7 @@ typedef struct {
   double last_batch_ms;     /* device-only time of the last batch (ops already in HBM)  */
   double last_batch_h2d_ms; /* H2D time of the op array when it came from a host buffer */
   /* option "profile"=1: HIP-event time spent in each round kernel, measured on the engine's own stream */
-  double prof_plan_ms, prof_check_ms, prof_apply_ms;
+  double prof_plan_ms, prof_check_ms, prof_apply_ms, prof_compact_ms;
   uint64_t prof_launches; /* launches of each of the three round kernels */
 } ppcsr_stats_t;
 

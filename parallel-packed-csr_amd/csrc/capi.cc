@@ -120,7 +120,7 @@ int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out) {
   out->double_calls = s.double_calls; out->half_calls = s.half_calls; out->big_redistributes = s.big_redistributes; out->rollbacks = s.rollbacks;
   out->not_found = s.not_found; out->duplicates = s.duplicates; out->noops = s.noops; out->slide_slots = s.slide_slots;
   out->ops_applied = s.ops_applied; out->last_batch_ms = s.last_batch_ms; out->last_batch_h2d_ms = s.last_batch_h2d_ms;
-  out->prof_plan_ms = s.prof_plan_ms; out->prof_check_ms = s.prof_check_ms; out->prof_apply_ms = s.prof_apply_ms;
+  out->prof_plan_ms = s.prof_plan_ms; out->prof_check_ms = s.prof_check_ms; out->prof_apply_ms = s.prof_apply_ms; out->prof_compact_ms = s.prof_compact_ms;
   out->prof_launches = s.prof_launches;
   return 0;
 }

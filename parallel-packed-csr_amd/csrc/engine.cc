@@ -73,7 +73,7 @@ struct Engine::Impl {
   uint32_t mode = 1;             // 0 = strict prefix rounds, 1 = speculative rounds with validated rollback
   uint32_t epoch_ops = 1u << 20;  // rollback granularity
   uint32_t region_slots = 4096;  // per-region prefix rule (>= kBigWindow so a window never leaves its region)
-  uint32_t opt_horizon = 32768;
+  uint32_t opt_horizon = 4096;   // rounds are bound by dependency chains, not by width: a wider horizon only re-plans more
   bool partial = false;
   bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
   std::vector<gpu::Event> events;  // init failed half-way: destructor frees only what exists
@@ -298,7 +298,7 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "profile") {
     p.profile = value != 0;
-    p.st.prof_plan_ms = p.st.prof_check_ms = p.st.prof_apply_ms = 0;
+    p.st.prof_plan_ms = p.st.prof_check_ms = p.st.prof_apply_ms = p.st.prof_compact_ms = 0;
     p.st.prof_launches = 0;
     return PPCSR_OK;
   }
@@ -526,16 +526,35 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         c.max_horizon = gh;
       }
       const uint32_t rounds = (gh == p.opt_horizon) ? std::max<uint32_t>(1u, p.rounds_per_sync / 4) : p.rounds_per_sync;
+      if (p.profile && p.events.size() < 5ull * rounds) {
+        const size_t oldn = p.events.size();
+        p.events.resize(5ull * rounds);
+        for (size_t i = oldn; i < p.events.size(); i++) GCHK(p.events[i].init());
+      }
       for (uint32_t r = 0; r < rounds; r++) {
         a.round = ++p.round;
+        if (p.profile) p.events[5 * r + 0].record(p.stream);
         GPU_LAUNCH(p.stream, o_plan, blocks, 256, a);
+        if (p.profile) p.events[5 * r + 1].record(p.stream);
         GPU_LAUNCH(p.stream, o_check, blocks, 256, a);
+        if (p.profile) p.events[5 * r + 2].record(p.stream);
         GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
+        if (p.profile) p.events[5 * r + 3].record(p.stream);
         GPU_LAUNCH(p.stream, o_compact, 1, 1024, a);
+        if (p.profile) p.events[5 * r + 4].record(p.stream);
       }
       GCHK(gpu::d2h(p.h_octl, p.d_octl, sizeof(OptCtl), p.stream));
       GCHK(gpu::sync(p.stream));
       GCHK(gpu::last_error());
+      if (p.profile) {
+        for (uint32_t r = 0; r < rounds; r++) {
+          p.st.prof_plan_ms += gpu::Event::elapsed_ms(p.events[5 * r + 0], p.events[5 * r + 1]);
+          p.st.prof_check_ms += gpu::Event::elapsed_ms(p.events[5 * r + 1], p.events[5 * r + 2]);
+          p.st.prof_apply_ms += gpu::Event::elapsed_ms(p.events[5 * r + 2], p.events[5 * r + 3]);
+          p.st.prof_compact_ms += gpu::Event::elapsed_ms(p.events[5 * r + 3], p.events[5 * r + 4]);
+          p.st.prof_launches += 1;
+        }
+      }
       p.st.round_syncs++;
       if (c.error) return fail(PPCSR_EINTERNAL, "device-side error " + std::to_string(c.error));
       const uint32_t npar = (p.round + 1) & 1u;

@@ -23,7 +23,7 @@ struct EngineStats {
   double last_batch_ms;      // device-only time of the last apply_batch (ops resident in HBM)
   double last_batch_h2d_ms;  // time of the H2D copy of the op array (host-buffer entry point)
   // profile mode (option "profile"=1): HIP-event time of each round kernel on the engine's stream
-  double prof_plan_ms, prof_check_ms, prof_apply_ms;
+  double prof_plan_ms, prof_check_ms, prof_apply_ms, prof_compact_ms;
   uint64_t prof_launches;  // launches of EACH of the three kernels
 };
 

@@ -30,7 +30,7 @@ struct View {
 constexpr uint32_t kBigWindow = 4096;  // windows larger than this run through the exclusive executor
 constexpr uint32_t kMaxSlide = 4096;   // slides longer than this too
 constexpr int kStatShards = 256;
-constexpr uint32_t kLdsWindow = 1024;  // windows up to this many slots are rebalanced inside one wave's LDS tile (12 KB)
+constexpr uint32_t kLdsWindow = 512;   // windows up to this many slots are rebalanced inside one wave's LDS tile (12 KB)
 
 struct StatShard {
   unsigned long long redistribute_calls, redistribute_slots, not_found, duplicates, noops, slide_slots, committed, pad;

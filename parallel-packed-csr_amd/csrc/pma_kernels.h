@@ -91,7 +91,7 @@ PMA_KERNEL void k_check(RoundArgs a) {
     const unsigned long long k = a.v.wres[leaf];
     if ((uint32_t)(k >> 32) == tag && (uint32_t)k < idx) fail = true;  // an earlier update writes what we read
   });
-  if (wv::ballot(fail) != 0 && wv::lane() == 0) wv::atomic_min_u32(&c->failmin[par], idx);
+  if (wv::ballot(fail) != 0 && wv::lane() == 0 && idx < c->failmin[par]) wv::atomic_min_u32(&c->failmin[par], idx);
 }
 
 PMA_KERNEL void k_apply(RoundArgs a) {
@@ -779,10 +779,8 @@ PMA_KERNEL void o_apply(OptArgs a) {
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_max_u32(&a.wstamp[leaf], me1);
   }
   PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, wv::atomic_max_u32(&a.rstamp[leaf], me1));
-  if (lane == 0) {
-    a.status[wid] = OS_COMMITTED;
-    wv::atomic_max_u32(&c->maxc, me1);
-  }
+  if (lane == 0) a.status[wid] = OS_COMMITTED;  // (the epoch's max committed index is reduced in o_compact: a
+                                                // per-update atomicMax on one word would serialise the whole round)
 }
 
 // one workgroup: stable compaction of the deferred updates into the next carry list + next round's bookkeeping
@@ -802,6 +800,7 @@ PMA_KERNEL void o_compact(OptArgs a) {
   if (tid == 0) s_count = 0;
   wv::block_sync();
   uint32_t ncommitted = 0;
+  uint32_t mymaxc = 0;
   for (uint32_t base = 0; base < hor; base += bd) {
     const uint32_t s = base + tid;
     bool keep = false;
@@ -809,6 +808,7 @@ PMA_KERNEL void o_compact(OptArgs a) {
     if (s < hor) {
       keep = a.status[s] != OS_COMMITTED;
       idx = a.opidx[s];
+      if (!keep && idx + 1u > mymaxc) mymaxc = idx + 1u;
     }
     const uint64_t m = wv::ballot(keep);
     const uint32_t wcnt = (uint32_t)wv::popc64(m);
@@ -828,6 +828,7 @@ PMA_KERNEL void o_compact(OptArgs a) {
     wv::block_sync();
   }
   const uint32_t kept = s_count;
+  if (mymaxc) wv::atomic_max_u32(&c->maxc, mymaxc);  // <= 1024 atomics per round, only by threads that saw a commit
   for (uint32_t i = used + tid; i < cn; i += bd) cout[kept + (i - used)] = cin[i];  // carry entries beyond the horizon
   wv::block_sync();
   if (tid == 0) {
