@@ -523,6 +523,8 @@ uint64_t po_get_neighbourhood(const po_pcsr *p, int src, int *out, uint64_t cap)
   }
   return k;
 }
+/* test hook: run the reference's redistribute() on an arbitrary aligned window */
+void po_debug_redistribute(po_pcsr *p, uint64_t index, uint64_t len) { po_redistribute(p, (int64_t)index, (int64_t)len); }
 void po_get_stats(const po_pcsr *p, po_stats *out) { *out = p->st; }
 void po_reset_stats(po_pcsr *p) { memset(&p->st, 0, sizeof(p->st)); }
 

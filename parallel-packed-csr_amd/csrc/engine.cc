@@ -49,6 +49,8 @@ struct Engine::Impl {
   uint64_t rank_cap = 0, tiles_cap = 0;
   unsigned long long *d_total = nullptr, *h_total = nullptr;
   ChainTable *d_table = nullptr;
+  Edge *d_scratch = nullptr;  // persistent destination of big in-place rebalances
+  uint64_t scratch_cap = 0;
   int *d_nbr = nullptr;
   uint64_t nbr_cap = 0;
   uint32_t round = 0;
@@ -239,6 +241,7 @@ Engine::~Engine() {
   if (p.d_rank) GPU_DFREE(p.d_rank);
   if (p.d_tiles) GPU_DFREE(p.d_tiles);
   if (p.d_nbr) GPU_DFREE(p.d_nbr);
+  if (p.d_scratch) GPU_DFREE(p.d_scratch);
   for (Impl::Snap *sp : {&p.snap, &p.esnap}) {
     if (sp->v.items) GPU_DFREE(sp->v.items);
     if (sp->v.nodes) GPU_DFREE(sp->v.nodes);
@@ -702,10 +705,11 @@ int Engine::resize(uint64_t newN) {
   int rc = rank_scan(old.leafcnt, old_leaves);
   if (rc != PPCSR_OK) return rc;
   GPU_LAUNCH(p.stream, k_chain_table, 1, 64, (uint64_t)0, newN, (const unsigned long long *)p.d_total, p.d_table);
-  GPU_LAUNCH(p.stream, k_fill_null, grid_for(newN * 3, 256 * 8), 256, nv.items, (uint64_t)0, newN);
-  GPU_LAUNCH(p.stream, k_scatter, grid_for((oldN + 63) / 64, 4), 256, nv, (const Edge *)old.items, (uint64_t)0, oldN, old.g.sh,
-             (const uint32_t *)p.d_rank, (const ChainTable *)p.d_table, nv.items, (uint64_t)0);
-  GPU_LAUNCH(p.stream, k_recount, grid_for((newN + 63) / 64, 4), 256, nv, (uint64_t)0, newN);
+  GCHK(gpu::dset(nv.leafcnt, 0, new_leaves * sizeof(uint32_t), p.stream));
+  // one fused pass: read the old array once, write every slot of the new array exactly once (elements + nulls)
+  GPU_LAUNCH(p.stream, k_scatter_fill, grid_for((oldN + 63) / 64, 4), 256, nv, (const Edge *)old.items, (uint64_t)0, oldN,
+             old.g.sh, (const uint32_t *)p.d_rank, (const ChainTable *)p.d_table, nv.items, (uint64_t)0, nv.leafcnt, nv.g.sh,
+             (uint64_t)0);
   GCHK(gpu::sync(p.stream));
   GCHK(gpu::last_error());
   GPU_DFREE(old.items);
@@ -722,24 +726,36 @@ int Engine::resize(uint64_t newN) {
   return PPCSR_OK;
 }
 
-// window rebalance too large for one wave: scan ranks, scatter into a scratch window, copy back
-int Engine::big_redistribute(uint64_t wstart, uint64_t wlen) {
+// window rebalance too large for one wave: leaf-rank scan + exact position table + ONE fused scatter/fill pass into a
+// persistent scratch array; a whole-array window then just swaps the buffers, a partial window is copied back
+int Engine::big_redistribute(uint64_t wstart, uint64_t wlen, bool sync) {
   Impl &p = *p_;
   const View v = p.v;
   const uint64_t leaf_lo = wstart >> v.g.sh, nleaves = wlen >> v.g.sh;
   int rc = rank_scan(v.leafcnt + leaf_lo, nleaves);
   if (rc != PPCSR_OK) return rc;
-  Edge *tmp = nullptr;
-  GCHK(gpu::dmalloc((void **)&tmp, wlen * sizeof(Edge)));
+  const bool whole = (wstart == 0 && wlen == v.g.N);
+  const uint64_t need = whole ? v.g.N : wlen;
+  if (whole ? (p.scratch_cap != need) : (p.scratch_cap < need)) {  // a swapped-in buffer must be exactly N slots
+    if (p.d_scratch) GPU_DFREE(p.d_scratch);
+    p.d_scratch = nullptr;
+    p.scratch_cap = 0;
+    GCHK(gpu::dmalloc((void **)&p.d_scratch, need * sizeof(Edge)));
+    p.scratch_cap = need;
+  }
   GPU_LAUNCH(p.stream, k_chain_table, 1, 64, wstart, wlen, (const unsigned long long *)p.d_total, p.d_table);
-  GPU_LAUNCH(p.stream, k_fill_null, grid_for(wlen * 3, 256 * 8), 256, tmp, (uint64_t)0, wlen);
-  GPU_LAUNCH(p.stream, k_scatter, grid_for((wlen + 63) / 64, 4), 256, v, (const Edge *)v.items, wstart, wlen, v.g.sh,
-             (const uint32_t *)p.d_rank, (const ChainTable *)p.d_table, tmp, wstart);
-  GPU_LAUNCH(p.stream, k_copy_slots, grid_for(wlen * 3, 256 * 8), 256, (const Edge *)tmp, v.items + wstart, wlen);
-  GPU_LAUNCH(p.stream, k_recount, grid_for((wlen + 63) / 64, 4), 256, v, wstart, wlen);
-  GCHK(gpu::sync(p.stream));
-  GCHK(gpu::last_error());
-  GPU_DFREE(tmp);
+  GCHK(gpu::dset(v.leafcnt + leaf_lo, 0, nleaves * sizeof(uint32_t), p.stream));
+  GPU_LAUNCH(p.stream, k_scatter_fill, grid_for((wlen + 63) / 64, 4), 256, v, (const Edge *)v.items, wstart, wlen, v.g.sh,
+             (const uint32_t *)p.d_rank, (const ChainTable *)p.d_table, p.d_scratch, wstart, v.leafcnt, v.g.sh, (uint64_t)0);
+  if (whole) {
+    std::swap(p.v.items, p.d_scratch);  // scratch_cap == N: the old array becomes the scratch
+  } else {
+    GPU_LAUNCH(p.stream, k_copy_slots, grid_for(wlen * 3, 256 * 8), 256, (const Edge *)p.d_scratch, v.items + wstart, wlen);
+  }
+  if (sync) {
+    GCHK(gpu::sync(p.stream));
+    GCHK(gpu::last_error());
+  }
   p.st.big_redistributes++;
   return PPCSR_OK;
 }
@@ -1028,14 +1044,17 @@ int Engine::rebalance_bench(uint64_t wlen, int iters, double *ms_per_call) {
   Impl &p = *p_;
   if (wlen == 0 || wlen > p.v.g.N || (wlen & (wlen - 1)) || wlen < (uint64_t)p.v.g.logN) return fail(PPCSR_EINVAL, "bad window");
   GCHK(gpu::set_device(device_));
-  int rc = big_redistribute(0, wlen);  // warm-up (and makes the window balanced)
+  int rc = big_redistribute(0, wlen, true);  // warm-up (also sizes the scratch array)
   if (rc != PPCSR_OK) return rc;
-  auto t0 = std::chrono::steady_clock::now();
+  p.timer.start(p.stream);  // device time of the whole pipeline: rank scan, position table, fused scatter/fill (+ copy-back)
   for (int i = 0; i < iters; i++) {
-    rc = big_redistribute(0, wlen);
+    rc = big_redistribute(0, wlen, false);
     if (rc != PPCSR_OK) return rc;
   }
-  *ms_per_call = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / iters;
+  p.timer.stop(p.stream);
+  GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
+  *ms_per_call = p.timer.ms() / iters;
   return PPCSR_OK;
 }
 

@@ -64,7 +64,7 @@ class Engine {
   int run_rounds(const Op *d_ops, uint64_t n);
   int run_exclusive(Op op, uint32_t flags);
   int resize(uint64_t newN);
-  int big_redistribute(uint64_t wstart, uint64_t wlen);
+  int big_redistribute(uint64_t wstart, uint64_t wlen, bool sync = true);
   int rank_scan(const uint32_t *d_cnt, uint64_t nleaves);  // -> d_rank_, d_total_
   int ensure_scratch(uint64_t nleaves);
   int fail(int code, const std::string &msg);

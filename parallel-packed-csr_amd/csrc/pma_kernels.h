@@ -472,6 +472,93 @@ PMA_KERNEL void k_scatter(View v, const Edge *src, uint64_t src_lo, uint64_t src
   }
 }
 
+// Fused rebalance scatter: like k_scatter, but every wave also writes the null slots that follow its elements
+// (element k owns output slots [pos_k, pos_{k+1})), so the destination needs no separate fill pass, every output slot
+// is written exactly once, and the wave's output stretch is staged in LDS and stored as one coalesced run.
+// Leaf counts of the destination are accumulated with one atomicAdd per element (dst leafcnt must be zeroed first).
+constexpr uint32_t kStageSlots = 768;  // LDS staging tile per wave (9 KB): 64 elements at step <= 12
+PMA_KERNEL void k_scatter_fill(View v, const Edge *src, uint64_t src_lo, uint64_t src_len, int src_sh, const uint32_t *rank,
+                               const ChainTable *tb, Edge *dst, uint64_t dst_bias, uint32_t *dst_leafcnt, int dst_sh,
+                               uint64_t dst_leaf_bias) {
+  PMA_SHARED ChainTable stb;
+  PMA_SHARED uint32_t stage[4][3 * kStageSlots];
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
+    uint32_t *s = reinterpret_cast<uint32_t *>(&stb);
+    for (uint32_t i = wv::thread_idx(); i < sizeof(ChainTable) / 4; i += wv::block_dim()) s[i] = g[i];
+  }
+  wv::block_sync();
+  const int lane = wv::lane();
+  uint32_t *ls = stage[wv::wave_in_block()], *ld = ls + kStageSlots, *lv = ls + 2 * kStageSlots;
+  const uint32_t slogN = 1u << src_sh;
+  const uint64_t j = stb.j;
+  const uint64_t wend = stb.index + stb.len;  // end of the destination window (absolute slot)
+  const uint64_t nchunks = (src_len + 63) / 64;
+  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
+  if (j == 0) {  // empty window: nothing owns the output slots, null them all
+    const uint64_t tstride = (uint64_t)wv::grid_dim() * wv::block_dim();
+    for (uint64_t t = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); t < stb.len; t += tstride)
+      dst[stb.index + t - dst_bias] = null_edge();
+    return;
+  }
+  int hint = 0, hint2 = 0;
+  for (uint64_t ch = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); ch < nchunks; ch += wstride) {
+    const uint64_t off = ch * 64 + (uint64_t)lane;
+    Edge e = null_edge();
+    if (off < src_len) e = src[src_lo + off];
+    const bool nn = e.value != 0;
+    const uint64_t m = wv::ballot(nn);
+    if (m == 0) continue;
+    uint64_t pos = 0, nxt = 0;
+    if (nn) {
+      const uint64_t lleaf = off >> src_sh;
+      uint64_t lmask;
+      if (slogN >= 64) {
+        lmask = ~0ull;
+      } else {
+        const uint32_t first = (uint32_t)(lane & ~(int)(slogN - 1));
+        lmask = ((1ull << slogN) - 1ull) << first;
+      }
+      const uint64_t k = (uint64_t)rank[lleaf] + (uint64_t)wv::popc64(m & lmask & ((1ull << lane) - 1ull));
+      pos = chain_pos(&stb, k, &hint);
+      nxt = (k + 1 < j) ? chain_pos(&stb, k + 1, &hint2) : wend;
+      dev::fix_sentinel(v, e, (uint32_t)pos);
+      wv::atomic_add_u32(&dst_leafcnt[(pos >> dst_sh) - dst_leaf_bias], 1u);
+    }
+    // output stretch of this chunk: [first element's pos, last element's nxt)
+    const int lfirst = wv::ctz64(m), llast = 63 - __builtin_clzll(m);
+    const uint64_t o_lo = ((uint64_t)wv::shfl((uint32_t)(pos >> 32), lfirst) << 32) | wv::shfl((uint32_t)pos, lfirst);
+    const uint64_t o_hi = ((uint64_t)wv::shfl((uint32_t)(nxt >> 32), llast) << 32) | wv::shfl((uint32_t)nxt, llast);
+    const uint64_t olen = o_hi - o_lo;
+    if (olen <= kStageSlots) {
+      for (uint32_t t = (uint32_t)lane; t < (uint32_t)olen; t += 64) {
+        ls[t] = kMax;
+        ld[t] = 0;
+        lv[t] = 0;
+      }
+      wv::fence();
+      if (nn) {
+        const uint32_t t = (uint32_t)(pos - o_lo);
+        ls[t] = e.src;
+        ld[t] = e.dest;
+        lv[t] = e.value;
+      }
+      wv::fence();
+      for (uint32_t t = (uint32_t)lane; t < (uint32_t)olen; t += 64) {
+        Edge o;
+        o.src = ls[t];
+        o.dest = ld[t];
+        o.value = lv[t];
+        dst[o_lo + t - dst_bias] = o;
+      }
+      wv::fence();
+    } else if (nn) {  // very sparse destination: each lane writes its own run
+      dst[pos - dst_bias] = e;
+      for (uint64_t s2 = pos + 1; s2 < nxt; s2++) dst[s2 - dst_bias] = null_edge();
+    }
+  }
+}
+
 PMA_KERNEL void k_copy_slots(const Edge *src, Edge *dst, uint64_t len) {
   const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
   uint32_t *d = reinterpret_cast<uint32_t *>(dst);

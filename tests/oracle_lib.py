@@ -46,6 +46,7 @@ def _load_oracle():
     L.po_get_neighbourhood.argtypes = [c_vp, c_int, c_vp, c_u64]
     L.po_get_stats.argtypes = [c_vp, c_vp]
     L.po_reset_stats.argtypes = [c_vp]
+    L.po_debug_redistribute.argtypes = [c_vp, c_u64, c_u64]
     L.po_redistribute_positions.argtypes = [c_u64, c_u64, c_u64, c_vp]
     L.pop_create.restype = c_vp
     L.pop_create.argtypes = [c_u32, c_u32, c_int, c_int, c_int]
@@ -140,6 +141,7 @@ class Oracle(_State):
         self.L.po_get_stats(self.h, buf)
         return dict(zip(STAT_FIELDS, list(buf)))
     def reset_stats(self): self.L.po_reset_stats(self.h)
+    def debug_redistribute(self, index, length): self.L.po_debug_redistribute(self.h, index, length)
 
 
 class OraclePPPCSR:

@@ -197,3 +197,23 @@ def test_seq_stress_edge_exists(pkg):
     eng.apply(dele)
     assert len(eng.get_neighbourhood(0)) == 0 and eng.get_n() == 10
     assert not eng.edge_exists(0, 5)
+
+
+def test_big_window_rebalance(pkg, streams):
+    """multi-workgroup rebalance kernels on 2^21..2^18-slot windows vs the oracle's redistribute()"""
+    n = 1 << 16
+    s, d = streams.rmat_edges(16, 500000, seed=4)
+    ops = streams.adds(s, d)
+    e, o = pkg.PCSR(n), Oracle(n)
+    e.apply(ops)
+    o.apply(ops)
+    N = e.geometry()[0]
+    for w in (N, N // 2, N // 8):
+        e.bench_rebalance(w, 1)
+        o.debug_redistribute(0, w)
+        _same(e, o, f"window {w}")
+    s2, d2 = streams.rmat_edges(16, 100000, seed=5)
+    more = streams.adds(s2, d2)
+    e.apply(more)
+    o.apply(more)
+    _same(e, o, "updates after the rebalances")

@@ -102,3 +102,21 @@ def test_sim_speculative_stats_survive_rollback(sim, streams):
     se, so = e.stats(), o.stats()
     for k in ("redistribute_calls", "redistribute_slots", "double_calls", "not_found", "duplicates"):
         assert se[k] == so[k], k
+
+
+def test_sim_big_window_rebalance(sim, streams):
+    """the multi-workgroup rebalance (rank scan + exact position table + fused scatter/fill) on whole-array and
+    partial windows, against the reference's redistribute() run by the oracle on the same window"""
+    ops = streams.random_stream(300, 6000, seed=9)
+    e, o = sim(300), Oracle(300)
+    e.apply(ops)
+    o.apply(ops)
+    N = e.geometry()[0]
+    for w in (N, N // 2, N // 8):
+        e.bench_rebalance(w, 1)
+        o.debug_redistribute(0, w)
+        _same(e, o, f"window {w}")
+    more = streams.random_stream(300, 2000, seed=10, p_delete=0.3)
+    e.apply(more)
+    o.apply(more)
+    _same(e, o, "updates after a rebalance")
