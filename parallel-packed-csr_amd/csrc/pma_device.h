@@ -341,7 +341,7 @@ PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, ui
     lds[lane] = kMax;
     lds[64 + lane] = 0;
     lds[128 + lane] = 0;
-    wv::fence();
+    wv::lds_fence();
     if (nn) {
       const uint32_t o = (uint32_t)(mypos - wstart);
       lds[o] = e.src;
@@ -349,7 +349,7 @@ PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, ui
       lds[128 + o] = e.value;
       fix_sentinel(v, e, (uint32_t)mypos);
     }
-    wv::fence();
+    wv::lds_fence();
     Edge out;
     out.src = lds[lane];
     out.dest = lds[64 + lane];
@@ -376,7 +376,7 @@ PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, ui
       ld[o] = e.dest;
       lv[o] = e.value;
     }
-    wv::fence();
+    wv::lds_fence();
     uint32_t j = 0;
     for (uint32_t base = 0; base < W; base += 64) {  // compaction (chunk fully read before it is rewritten)
       const uint32_t o = base + (uint32_t)lane;
@@ -384,21 +384,21 @@ PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, ui
       const bool nn = ev != 0;
       const uint64_t m = wv::ballot(nn);
       const uint32_t k = j + lanemask_lt_count(m, lane);
-      wv::fence();
+      wv::lds_fence();
       if (nn) {
         ls[k] = es;
         ld[k] = ed;
         lv[k] = ev;
       }
       j += (uint32_t)wv::popc64(m);
-      wv::fence();
+      wv::lds_fence();
     }
     for (uint32_t o = j + (uint32_t)lane; o < W; o += 64) {
       ls[o] = kMax;
       ld[o] = 0;
       lv[o] = 0;
     }
-    wv::fence();
+    wv::lds_fence();
     if (j >= 2) {
       const double step = chain_step(wlen, j);
       double x = chain_top(wstart, j, step);
@@ -419,26 +419,26 @@ PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, ui
           ed = ld[so];
           ev = lv[so];
         }
-        wv::fence();
+        wv::lds_fence();
         const uint32_t po = (uint32_t)(mypos - wstart);
         if (act && po != so) {
           ls[so] = kMax;
           ld[so] = 0;
           lv[so] = 0;
         }
-        wv::fence();
+        wv::lds_fence();
         if (act && po != so) {
           ls[po] = es;
           ld[po] = ed;
           lv[po] = ev;
         }
         if (act) fix_sentinel(v, Edge{es, ed, ev}, (uint32_t)mypos);
-        wv::fence();
+        wv::lds_fence();
         khi = klo - 1;
       }
     }
     if (j >= 1 && lane == 0) fix_sentinel(v, Edge{ls[0], ld[0], lv[0]}, (uint32_t)wstart);
-    wv::fence();
+    wv::lds_fence();
     for (uint32_t base = 0; base < W; base += 64) {  // LDS -> global + leaf counts
       const uint32_t o = base + (uint32_t)lane;
       Edge e;

@@ -476,7 +476,7 @@ PMA_KERNEL void k_scatter(View v, const Edge *src, uint64_t src_lo, uint64_t src
 // (element k owns output slots [pos_k, pos_{k+1})), so the destination needs no separate fill pass, every output slot
 // is written exactly once, and the wave's output stretch is staged in LDS and stored as one coalesced run.
 // Leaf counts of the destination are accumulated with one atomicAdd per element (dst leafcnt must be zeroed first).
-constexpr uint32_t kStageSlots = 768;  // LDS staging tile per wave (9 KB): 64 elements at step <= 12
+constexpr uint32_t kStageSlots = 384;  // LDS staging tile per wave (4.5 KB): 64 elements at step <= 6
 PMA_KERNEL void k_scatter_fill(View v, const Edge *src, uint64_t src_lo, uint64_t src_len, int src_sh, const uint32_t *rank,
                                const ChainTable *tb, Edge *dst, uint64_t dst_bias, uint32_t *dst_leafcnt, int dst_sh,
                                uint64_t dst_leaf_bias) {
@@ -523,12 +523,21 @@ PMA_KERNEL void k_scatter_fill(View v, const Edge *src, uint64_t src_lo, uint64_
       pos = chain_pos(&stb, k, &hint);
       nxt = (k + 1 < j) ? chain_pos(&stb, k + 1, &hint2) : wend;
       dev::fix_sentinel(v, e, (uint32_t)pos);
-      wv::atomic_add_u32(&dst_leafcnt[(pos >> dst_sh) - dst_leaf_bias], 1u);
     }
     // output stretch of this chunk: [first element's pos, last element's nxt)
     const int lfirst = wv::ctz64(m), llast = 63 - __builtin_clzll(m);
     const uint64_t o_lo = ((uint64_t)wv::shfl((uint32_t)(pos >> 32), lfirst) << 32) | wv::shfl((uint32_t)pos, lfirst);
     const uint64_t o_hi = ((uint64_t)wv::shfl((uint32_t)(nxt >> 32), llast) << 32) | wv::shfl((uint32_t)nxt, llast);
+    const uint64_t p_hi = ((uint64_t)wv::shfl((uint32_t)(pos >> 32), llast) << 32) | wv::shfl((uint32_t)pos, llast);
+    // destination leaf counts: the chunk's elements land in a handful of consecutive leaves -> one atomic per leaf
+    {
+      const uint64_t l0 = o_lo >> dst_sh, l1 = p_hi >> dst_sh;
+      const uint64_t mylf = pos >> dst_sh;
+      for (uint64_t L = l0; L <= l1; L++) {
+        const uint64_t mm = wv::ballot(nn && mylf == L);
+        if (mm && lane == 0) wv::atomic_add_u32(&dst_leafcnt[L - dst_leaf_bias], (uint32_t)wv::popc64(mm));
+      }
+    }
     const uint64_t olen = o_hi - o_lo;
     if (olen <= kStageSlots) {
       for (uint32_t t = (uint32_t)lane; t < (uint32_t)olen; t += 64) {
@@ -536,14 +545,14 @@ PMA_KERNEL void k_scatter_fill(View v, const Edge *src, uint64_t src_lo, uint64_
         ld[t] = 0;
         lv[t] = 0;
       }
-      wv::fence();
+      wv::lds_fence();
       if (nn) {
         const uint32_t t = (uint32_t)(pos - o_lo);
         ls[t] = e.src;
         ld[t] = e.dest;
         lv[t] = e.value;
       }
-      wv::fence();
+      wv::lds_fence();
       for (uint32_t t = (uint32_t)lane; t < (uint32_t)olen; t += 64) {
         Edge o;
         o.src = ls[t];
@@ -551,7 +560,7 @@ PMA_KERNEL void k_scatter_fill(View v, const Edge *src, uint64_t src_lo, uint64_
         o.value = lv[t];
         dst[o_lo + t - dst_bias] = o;
       }
-      wv::fence();
+      wv::lds_fence();
     } else if (nn) {  // very sparse destination: each lane writes its own run
       dst[pos - dst_bias] = e;
       for (uint64_t s2 = pos + 1; s2 < nxt; s2++) dst[s2 - dst_bias] = null_edge();

@@ -26,6 +26,9 @@ PMA_DEV uint32_t reduce_add(uint32_t v) {
 }
 // orders this wave's LDS + global accesses among its own lanes (same CU: L1 is shared)
 PMA_DEV void fence() { __threadfence_block(); }
+// orders this wave's LDS accesses only (one wave's DS operations execute in order; this is a compiler barrier that
+// does not wait for outstanding global loads / stores / atomics)
+PMA_DEV void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 PMA_DEV void block_sync() { __syncthreads(); }
 PMA_DEV uint32_t atomic_min_u32(uint32_t *p, uint32_t v) { return atomicMin(p, v); }
 PMA_DEV unsigned long long atomic_min_u64(unsigned long long *p, unsigned long long v) { return atomicMin(p, v); }

@@ -38,6 +38,7 @@ inline uint32_t shfl(uint32_t v, int src) { return (uint32_t)sim::shfl64(v, src)
 inline uint32_t first(uint32_t v) { return v; }  // callers only pass wave-uniform values
 inline uint32_t reduce_add(uint32_t v) { return (uint32_t)sim::reduce_add64(v); }
 inline void fence() { (void)sim::shfl64(0, 0); }  // lanes run sequentially between collectives: a fence must be a rendezvous
+inline void lds_fence() { (void)sim::shfl64(0, 0); }
 inline void block_sync() { sim::block_sync(); }
 inline uint32_t atomic_min_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 inline unsigned long long atomic_min_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
