@@ -676,13 +676,13 @@ int Engine::ensure_scratch(uint64_t nleaves) {
 }
 
 // exclusive prefix sum of d_cnt[0..nleaves) into d_rank_, grand total into d_total_
-int Engine::rank_scan(const uint32_t *d_cnt, uint64_t nleaves) {
+int Engine::rank_scan(const uint32_t *d_cnt, uint64_t nleaves, bool table, uint64_t tb_index, uint64_t tb_len) {
   Impl &p = *p_;
   int rc = ensure_scratch(nleaves);
   if (rc != PPCSR_OK) return rc;
   const uint64_t ntiles = (nleaves + kScanTile - 1) / kScanTile;
   GPU_LAUNCH(p.stream, k_scan_tiles, ntiles, 256, d_cnt, nleaves, p.d_tiles);
-  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, 64, p.d_tiles, ntiles, p.d_total);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, 64, p.d_tiles, ntiles, p.d_total, table ? p.d_table : (ChainTable *)nullptr, tb_index, tb_len);
   GPU_LAUNCH(p.stream, k_scan_apply, ntiles, 256, d_cnt, nleaves, (const uint32_t *)p.d_tiles, p.d_rank);
   return PPCSR_OK;
 }
@@ -702,9 +702,8 @@ int Engine::resize(uint64_t newN) {
   const uint64_t new_leaves = newN >> g.sh;
   GCHK(gpu::dmalloc((void **)&nv.items, newN * sizeof(Edge)));
   GCHK(gpu::dmalloc((void **)&nv.leafcnt, new_leaves * sizeof(uint32_t)));
-  int rc = rank_scan(old.leafcnt, old_leaves);
+  int rc = rank_scan(old.leafcnt, old_leaves, true, 0, newN);
   if (rc != PPCSR_OK) return rc;
-  GPU_LAUNCH(p.stream, k_chain_table, 1, 64, (uint64_t)0, newN, (const unsigned long long *)p.d_total, p.d_table);
   GCHK(gpu::dset(nv.leafcnt, 0, new_leaves * sizeof(uint32_t), p.stream));
   // one fused pass: read the old array once, write every slot of the new array exactly once (elements + nulls)
   GPU_LAUNCH(p.stream, k_scatter_fill, grid_for((oldN + 63) / 64, 4), 256, nv, (const Edge *)old.items, (uint64_t)0, oldN,
@@ -732,7 +731,7 @@ int Engine::big_redistribute(uint64_t wstart, uint64_t wlen, bool sync) {
   Impl &p = *p_;
   const View v = p.v;
   const uint64_t leaf_lo = wstart >> v.g.sh, nleaves = wlen >> v.g.sh;
-  int rc = rank_scan(v.leafcnt + leaf_lo, nleaves);
+  int rc = rank_scan(v.leafcnt + leaf_lo, nleaves, true, wstart, wlen);
   if (rc != PPCSR_OK) return rc;
   const bool whole = (wstart == 0 && wlen == v.g.N);
   const uint64_t need = whole ? v.g.N : wlen;
@@ -743,7 +742,6 @@ int Engine::big_redistribute(uint64_t wstart, uint64_t wlen, bool sync) {
     GCHK(gpu::dmalloc((void **)&p.d_scratch, need * sizeof(Edge)));
     p.scratch_cap = need;
   }
-  GPU_LAUNCH(p.stream, k_chain_table, 1, 64, wstart, wlen, (const unsigned long long *)p.d_total, p.d_table);
   GCHK(gpu::dset(v.leafcnt + leaf_lo, 0, nleaves * sizeof(uint32_t), p.stream));
   GPU_LAUNCH(p.stream, k_scatter_fill, grid_for((wlen + 63) / 64, 4), 256, v, (const Edge *)v.items, wstart, wlen, v.g.sh,
              (const uint32_t *)p.d_rank, (const ChainTable *)p.d_table, p.d_scratch, wstart, v.leafcnt, v.g.sh, (uint64_t)0);
@@ -860,16 +858,20 @@ int Engine::scan_all_device(double *ms, uint64_t *total) {
   Impl &p = *p_;
   GCHK(gpu::set_device(device_));
   const uint64_t N = p.v.g.N, nchunks = (N + 63) / 64;
-  uint32_t *d_cc = nullptr;
+  const uint32_t nn = n();
+  uint32_t *d_cc = nullptr, *d_cs = nullptr;
   unsigned long long *d_rows = nullptr;
   int *d_dst = nullptr;
   GCHK(gpu::dmalloc((void **)&d_cc, nchunks * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&d_cs, nchunks * sizeof(uint32_t)));
   GCHK(gpu::dmalloc((void **)&d_rows, ((uint64_t)n() + 1) * sizeof(unsigned long long)));
   GCHK(gpu::dmalloc((void **)&d_dst, N * sizeof(int)));
   int rc = ensure_scratch(nchunks);
   if (rc != PPCSR_OK) return rc;
   p.timer.start(p.stream);
-  GPU_LAUNCH(p.stream, k_scan_count, grid_for(nchunks, 4), 256, p.v, d_cc);
+  GCHK(gpu::dset(d_cs, 0, nchunks * sizeof(uint32_t), p.stream));
+  GPU_LAUNCH(p.stream, k_chunk_sentinels, grid_for(nn, 256), 256, p.v, d_cs);
+  GPU_LAUNCH(p.stream, k_chunk_counts, grid_for(nchunks, 256), 256, p.v, (const uint32_t *)d_cs, d_cc);
   rc = rank_scan(d_cc, nchunks);
   if (rc != PPCSR_OK) return rc;
   GPU_LAUNCH(p.stream, k_scan_write, grid_for(nchunks, 4), 256, p.v, (const uint32_t *)p.d_rank, d_rows, d_dst, N);
@@ -879,6 +881,7 @@ int Engine::scan_all_device(double *ms, uint64_t *total) {
   if (ms) *ms = p.timer.ms();
   if (total) *total = *p.h_total;
   GPU_DFREE(d_cc);
+  GPU_DFREE(d_cs);
   GPU_DFREE(d_rows);
   GPU_DFREE(d_dst);
   return PPCSR_OK;
@@ -889,13 +892,16 @@ int Engine::scan_all(uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *
   GCHK(gpu::set_device(device_));
   const uint64_t N = p.v.g.N, nchunks = (N + 63) / 64;
   const uint32_t nn = n();
-  uint32_t *d_cc = nullptr;
+  uint32_t *d_cc = nullptr, *d_cs = nullptr;
   unsigned long long *d_rows = nullptr;
   int *d_dst = nullptr;
   GCHK(gpu::dmalloc((void **)&d_cc, nchunks * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&d_cs, nchunks * sizeof(uint32_t)));
   GCHK(gpu::dmalloc((void **)&d_rows, ((uint64_t)nn + 1) * sizeof(unsigned long long)));
   GCHK(gpu::dmalloc((void **)&d_dst, std::max<uint64_t>(cap, 1) * sizeof(int)));
-  GPU_LAUNCH(p.stream, k_scan_count, grid_for(nchunks, 4), 256, p.v, d_cc);
+  GCHK(gpu::dset(d_cs, 0, nchunks * sizeof(uint32_t), p.stream));
+  GPU_LAUNCH(p.stream, k_chunk_sentinels, grid_for(nn, 256), 256, p.v, d_cs);
+  GPU_LAUNCH(p.stream, k_chunk_counts, grid_for(nchunks, 256), 256, p.v, (const uint32_t *)d_cs, d_cc);
   int rc = rank_scan(d_cc, nchunks);
   if (rc != PPCSR_OK) return rc;
   GPU_LAUNCH(p.stream, k_scan_write, grid_for(nchunks, 4), 256, p.v, (const uint32_t *)p.d_rank, d_rows, d_dst, cap);
@@ -913,6 +919,7 @@ int Engine::scan_all(uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *
     GCHK(gpu::sync(p.stream));
   }
   GPU_DFREE(d_cc);
+  GPU_DFREE(d_cs);
   GPU_DFREE(d_rows);
   GPU_DFREE(d_dst);
   return (tot > cap && dests) ? PPCSR_ERANGE : PPCSR_OK;

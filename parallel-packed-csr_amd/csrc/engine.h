@@ -65,7 +65,7 @@ class Engine {
   int run_exclusive(Op op, uint32_t flags);
   int resize(uint64_t newN);
   int big_redistribute(uint64_t wstart, uint64_t wlen, bool sync = true);
-  int rank_scan(const uint32_t *d_cnt, uint64_t nleaves);  // -> d_rank_, d_total_
+  int rank_scan(const uint32_t *d_cnt, uint64_t nleaves, bool table = false, uint64_t tb_index = 0, uint64_t tb_len = 0);
   int ensure_scratch(uint64_t nleaves);
   int fail(int code, const std::string &msg);
   int pull_stats();

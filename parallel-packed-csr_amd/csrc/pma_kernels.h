@@ -387,7 +387,8 @@ PMA_KERNEL void k_scan_tiles(const uint32_t *cnt, uint64_t nleaves, uint32_t *ti
   wv::block_sync();
   if (wv::thread_idx() == 0) tilesum[b] = red[0] + red[1] + red[2] + red[3];
 }
-PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned long long *total) {
+PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned long long *total, ChainTable *tb,
+                                uint64_t tb_index, uint64_t tb_len) {
   // single wave, serial over chunks of 64 (ntiles <= 2^31/ (8*1024) — tiny)
   const int lane = wv::lane();
   unsigned long long run = 0;
@@ -403,7 +404,10 @@ PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned lon
     if (i < ntiles) tilesum[i] = (uint32_t)(run + incl - x);
     run += wv::shfl(incl, 63);
   }
-  if (lane == 0) *total = run;
+  if (lane == 0) {
+    *total = run;
+    if (tb) build_chain_table(tb_index, tb_len, (uint64_t)run, tb);  // the rebalance's exact position table (saves a launch)
+  }
 }
 PMA_KERNEL void k_scan_apply(const uint32_t *cnt, uint64_t nleaves, const uint32_t *tilesum, uint32_t *rank) {
   PMA_SHARED uint32_t wsum[4];
@@ -633,6 +637,35 @@ PMA_KERNEL void k_scan_count(View v, uint32_t *chunkcnt) {
     }
     const uint64_t m = wv::ballot(live);
     if (lane == 0) chunkcnt[ch] = (uint32_t)wv::popc64(m);
+  }
+}
+// live edges per 64-slot chunk WITHOUT reading the edge array: leaf counts minus the sentinels that sit in the chunk
+// (one atomic per vertex on a 4 B/chunk histogram), minus slot N-1 which is never part of a neighbourhood
+PMA_KERNEL void k_chunk_sentinels(View v, uint32_t *chunk_sent) {
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t k = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); k < v.g.n; k += stride)
+    wv::atomic_add_u32(&chunk_sent[v.nodes[k].beginning >> 6], 1u);
+}
+PMA_KERNEL void k_chunk_counts(View v, const uint32_t *chunk_sent, uint32_t *chunkcnt) {
+  const uint64_t N = v.g.N, nchunks = (N + 63) / 64;
+  const uint32_t lpc = (v.g.logN >= 64) ? 1u : (64u >> v.g.sh);  // leaves per chunk
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t ch = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); ch < nchunks; ch += stride) {
+    uint32_t c = 0;
+    if (v.g.logN >= 64) {
+      c = v.leafcnt[(ch * 64) >> v.g.sh];  // (logN = 64 only for N >= 2^32: not reachable, kept for completeness)
+    } else {
+      for (uint32_t q = 0; q < lpc; q++) {
+        const uint64_t leaf = ch * lpc + q;
+        if ((leaf << v.g.sh) < N) c += v.leafcnt[leaf];
+      }
+    }
+    c -= chunk_sent[ch];
+    if (ch == nchunks - 1) {
+      const Edge e = v.items[N - 1];
+      if (e.value != 0 && !is_sentinel(e)) c -= 1u;
+    }
+    chunkcnt[ch] = c;
   }
 }
 PMA_KERNEL void k_scan_write(View v, const uint32_t *chunkoff, unsigned long long *row_offsets, int *dests, uint64_t cap) {

@@ -120,3 +120,17 @@ def test_sim_big_window_rebalance(sim, streams):
     e.apply(more)
     o.apply(more)
     _same(e, o, "updates after a rebalance")
+
+
+def test_sim_scan_all_and_queries(sim, streams):
+    ops = streams.random_stream(120, 4000, seed=11, p_delete=0.2)
+    e, o = sim(120), Oracle(120)
+    e.apply(ops)
+    o.apply(ops)
+    rows, dests = e.scan_all()
+    for v in range(120):
+        ref = o.get_neighbourhood(v)
+        np.testing.assert_array_equal(e.get_neighbourhood(v), ref)
+        np.testing.assert_array_equal(dests[int(rows[v]):int(rows[v + 1])], ref)
+    for s, d in [(0, 1), (5, 77), (119, 3)]:
+        assert e.edge_exists(s, d) == o.edge_exists(s, d)
