@@ -49,6 +49,8 @@ struct Engine::Impl {
   uint64_t rank_cap = 0, tiles_cap = 0;
   unsigned long long *d_total = nullptr, *h_total = nullptr;
   ChainTable *d_table = nullptr;
+  unsigned long long *d_scan_state = nullptr;
+  uint64_t scan_state_cap = 0;
   Edge *d_scratch = nullptr;  // persistent destination of big in-place rebalances
   uint64_t scratch_cap = 0;
   int *d_nbr = nullptr;
@@ -242,6 +244,7 @@ Engine::~Engine() {
   if (p.d_tiles) GPU_DFREE(p.d_tiles);
   if (p.d_nbr) GPU_DFREE(p.d_nbr);
   if (p.d_scratch) GPU_DFREE(p.d_scratch);
+  if (p.d_scan_state) GPU_DFREE(p.d_scan_state);
   for (Impl::Snap *sp : {&p.snap, &p.esnap}) {
     if (sp->v.items) GPU_DFREE(sp->v.items);
     if (sp->v.nodes) GPU_DFREE(sp->v.nodes);
@@ -854,34 +857,44 @@ int Engine::read_neighbourhood(int src) {
   return get_neighbourhood(src, nullptr, 0, &c);
 }
 
+// bulk neighbour scan = ONE kernel (decoupled look-back stream compaction, pma_kernels.h): reads the edge array once
+int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap) {
+  Impl &p = *p_;
+  const uint64_t N = p.v.g.N, ntiles = (N + kScanTileSlots - 1) / kScanTileSlots;
+  if (p.scan_state_cap < ntiles + 1) {
+    if (p.d_scan_state) GPU_DFREE(p.d_scan_state);
+    p.d_scan_state = nullptr;
+    p.scan_state_cap = 0;
+    GCHK(gpu::dmalloc((void **)&p.d_scan_state, (ntiles + 1) * sizeof(unsigned long long)));
+    p.scan_state_cap = ntiles + 1;
+  }
+  // tile words + the ticket (last word) are zeroed every call
+  GCHK(gpu::dset(p.d_scan_state, 0, (ntiles + 1) * sizeof(unsigned long long), p.stream));
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, 256 * 6);
+  GPU_LAUNCH(p.stream, k_scan_onepass, grid, 256, p.v, p.d_scan_state, reinterpret_cast<uint32_t *>(p.d_scan_state + ntiles),
+             d_rows, d_dst, cap, p.d_total);
+  return PPCSR_OK;
+}
+
 int Engine::scan_all_device(double *ms, uint64_t *total) {
   Impl &p = *p_;
   GCHK(gpu::set_device(device_));
-  const uint64_t N = p.v.g.N, nchunks = (N + 63) / 64;
-  const uint32_t nn = n();
-  uint32_t *d_cc = nullptr, *d_cs = nullptr;
+  const uint64_t N = p.v.g.N;
   unsigned long long *d_rows = nullptr;
   int *d_dst = nullptr;
-  GCHK(gpu::dmalloc((void **)&d_cc, nchunks * sizeof(uint32_t)));
-  GCHK(gpu::dmalloc((void **)&d_cs, nchunks * sizeof(uint32_t)));
   GCHK(gpu::dmalloc((void **)&d_rows, ((uint64_t)n() + 1) * sizeof(unsigned long long)));
   GCHK(gpu::dmalloc((void **)&d_dst, N * sizeof(int)));
-  int rc = ensure_scratch(nchunks);
+  int rc = scan_launch(d_rows, d_dst, N);  // warm-up (sizes the tile-state array)
   if (rc != PPCSR_OK) return rc;
   p.timer.start(p.stream);
-  GCHK(gpu::dset(d_cs, 0, nchunks * sizeof(uint32_t), p.stream));
-  GPU_LAUNCH(p.stream, k_chunk_sentinels, grid_for(nn, 256), 256, p.v, d_cs);
-  GPU_LAUNCH(p.stream, k_chunk_counts, grid_for(nchunks, 256), 256, p.v, (const uint32_t *)d_cs, d_cc);
-  rc = rank_scan(d_cc, nchunks);
+  rc = scan_launch(d_rows, d_dst, N);
   if (rc != PPCSR_OK) return rc;
-  GPU_LAUNCH(p.stream, k_scan_write, grid_for(nchunks, 4), 256, p.v, (const uint32_t *)p.d_rank, d_rows, d_dst, N);
   p.timer.stop(p.stream);
   GCHK(gpu::d2h(p.h_total, p.d_total, sizeof(unsigned long long), p.stream));
   GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
   if (ms) *ms = p.timer.ms();
   if (total) *total = *p.h_total;
-  GPU_DFREE(d_cc);
-  GPU_DFREE(d_cs);
   GPU_DFREE(d_rows);
   GPU_DFREE(d_dst);
   return PPCSR_OK;
@@ -890,23 +903,16 @@ int Engine::scan_all_device(double *ms, uint64_t *total) {
 int Engine::scan_all(uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *total) {
   Impl &p = *p_;
   GCHK(gpu::set_device(device_));
-  const uint64_t N = p.v.g.N, nchunks = (N + 63) / 64;
   const uint32_t nn = n();
-  uint32_t *d_cc = nullptr, *d_cs = nullptr;
   unsigned long long *d_rows = nullptr;
   int *d_dst = nullptr;
-  GCHK(gpu::dmalloc((void **)&d_cc, nchunks * sizeof(uint32_t)));
-  GCHK(gpu::dmalloc((void **)&d_cs, nchunks * sizeof(uint32_t)));
   GCHK(gpu::dmalloc((void **)&d_rows, ((uint64_t)nn + 1) * sizeof(unsigned long long)));
   GCHK(gpu::dmalloc((void **)&d_dst, std::max<uint64_t>(cap, 1) * sizeof(int)));
-  GCHK(gpu::dset(d_cs, 0, nchunks * sizeof(uint32_t), p.stream));
-  GPU_LAUNCH(p.stream, k_chunk_sentinels, grid_for(nn, 256), 256, p.v, d_cs);
-  GPU_LAUNCH(p.stream, k_chunk_counts, grid_for(nchunks, 256), 256, p.v, (const uint32_t *)d_cs, d_cc);
-  int rc = rank_scan(d_cc, nchunks);
+  int rc = scan_launch(d_rows, d_dst, cap);
   if (rc != PPCSR_OK) return rc;
-  GPU_LAUNCH(p.stream, k_scan_write, grid_for(nchunks, 4), 256, p.v, (const uint32_t *)p.d_rank, d_rows, d_dst, cap);
   GCHK(gpu::d2h(p.h_total, p.d_total, sizeof(unsigned long long), p.stream));
   GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
   const uint64_t tot = *p.h_total;
   if (total) *total = tot;
   if (row_offsets && nn) {
@@ -918,8 +924,6 @@ int Engine::scan_all(uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *
     GCHK(gpu::d2h(dests, d_dst, std::min(cap, tot) * sizeof(int), p.stream));
     GCHK(gpu::sync(p.stream));
   }
-  GPU_DFREE(d_cc);
-  GPU_DFREE(d_cs);
   GPU_DFREE(d_rows);
   GPU_DFREE(d_dst);
   return (tot > cap && dests) ? PPCSR_ERANGE : PPCSR_OK;

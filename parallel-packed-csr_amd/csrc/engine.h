@@ -71,6 +71,7 @@ class Engine {
   int pull_stats();
 
   int run_speculative(const Op *d_ops, uint64_t n);
+  int scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap);
 
  public:
   struct Impl;

@@ -642,9 +642,17 @@ PMA_KERNEL void k_scan_count(View v, uint32_t *chunkcnt) {
 // live edges per 64-slot chunk WITHOUT reading the edge array: leaf counts minus the sentinels that sit in the chunk
 // (one atomic per vertex on a 4 B/chunk histogram), minus slot N-1 which is never part of a neighbourhood
 PMA_KERNEL void k_chunk_sentinels(View v, uint32_t *chunk_sent) {
+  // sentinel positions increase with the vertex id, so the sentinels of one chunk are a run of consecutive vertices:
+  // the first vertex of each run counts the run and stores it (no atomics; chunks without sentinels stay 0)
   const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
-  for (uint64_t k = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); k < v.g.n; k += stride)
-    wv::atomic_add_u32(&chunk_sent[v.nodes[k].beginning >> 6], 1u);
+  const uint64_t n = v.g.n;
+  for (uint64_t k = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); k < n; k += stride) {
+    const uint32_t ch = v.nodes[k].beginning >> 6;
+    if (k > 0 && (v.nodes[k - 1].beginning >> 6) == ch) continue;
+    uint32_t run = 1;
+    while (k + run < n && (v.nodes[k + run].beginning >> 6) == ch) run++;
+    chunk_sent[ch] = run;
+  }
 }
 PMA_KERNEL void k_chunk_counts(View v, const uint32_t *chunk_sent, uint32_t *chunkcnt) {
   const uint64_t N = v.g.N, nchunks = (N + 63) / 64;
@@ -985,6 +993,86 @@ PMA_KERNEL void o_compact(OptArgs a) {
     c->rounds += 1ull;
     c->committed += (unsigned long long)ncommitted;
     c->planned += (unsigned long long)hor;
+  }
+}
+
+// ---- one-pass bulk neighbour scan -------------------------------------------------------------------------------
+// Stream compaction of the live edges in array order (== CSR order) with a decoupled look-back prefix: every
+// workgroup takes the next 4096-slot tile (atomic ticket), counts its live edges while loading it ONCE, publishes
+// {flag, count} in one 64-bit word, sums the published words of the preceding tiles, and writes its dests / row
+// offsets.  A tile only ever waits for tiles with smaller tickets, which have already started: no deadlock.
+constexpr uint32_t kScanChunks = 16;               // 64-slot chunks per wave
+constexpr uint32_t kScanTileSlots = 4 * 64 * kScanChunks;  // 4096 slots per workgroup
+constexpr unsigned long long kFlagAgg = 1ull << 62, kFlagPre = 2ull << 62, kFlagMask = 3ull << 62;
+PMA_KERNEL void k_scan_onepass(View v, unsigned long long *tile_state, uint32_t *ticket, unsigned long long *row_offsets,
+                               int *dests, uint64_t cap, unsigned long long *total) {
+  PMA_SHARED uint32_t s_tile;
+  PMA_SHARED unsigned long long s_excl;
+  PMA_SHARED uint32_t s_wsum[4];
+  const int lane = wv::lane(), w = wv::wave_in_block();
+  const uint64_t N = v.g.N;
+  const uint64_t ntiles = (N + kScanTileSlots - 1) / kScanTileSlots;
+  for (;;) {
+    if (wv::thread_idx() == 0) s_tile = wv::atomic_add_u32(ticket, 1u);
+    wv::block_sync();
+    const uint64_t tile = s_tile;
+    if (tile >= ntiles) return;
+    const uint64_t wbase = tile * kScanTileSlots + (uint64_t)w * 64 * kScanChunks;
+    uint32_t dst[kScanChunks], val[kScanChunks];
+    uint64_t lm[kScanChunks];
+    uint32_t wcount = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < kScanChunks; c++) {
+      const uint64_t s = wbase + (uint64_t)c * 64 + (uint64_t)lane;
+      Edge e = null_edge();
+      if (s < N) e = v.items[s];
+      dst[c] = e.dest;
+      val[c] = e.value;
+      const bool live = e.value != 0 && !is_sentinel(e) && (s + 1 < N);
+      lm[c] = wv::ballot(live);
+      wcount += (uint32_t)wv::popc64(lm[c]);
+    }
+    if (lane == 0) s_wsum[w] = wcount;
+    wv::block_sync();
+    if (wv::thread_idx() == 0) {
+      const unsigned long long agg = (unsigned long long)s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+      unsigned long long excl = 0;
+      if (tile == 0) {
+        wv::agent_store_u64(&tile_state[0], kFlagPre | agg);
+      } else {
+        wv::agent_store_u64(&tile_state[tile], kFlagAgg | agg);
+        uint64_t t = tile;
+        for (;;) {  // look back
+          t--;
+          unsigned long long st;
+          do {
+            st = wv::agent_load_u64(&tile_state[t]);
+            if ((st & kFlagMask) == 0) wv::spin_pause();
+          } while ((st & kFlagMask) == 0);
+          excl += st & ~kFlagMask;
+          if ((st & kFlagMask) == kFlagPre) break;
+        }
+        wv::agent_store_u64(&tile_state[tile], kFlagPre | (excl + agg));
+      }
+      s_excl = excl;
+      if (tile == ntiles - 1) *total = excl + agg;
+    }
+    wv::block_sync();
+    unsigned long long run = s_excl;
+    for (int q = 0; q < w; q++) run += s_wsum[q];
+#pragma unroll
+    for (uint32_t c = 0; c < kScanChunks; c++) {
+      const uint64_t s = wbase + (uint64_t)c * 64 + (uint64_t)lane;
+      const bool live = (lm[c] >> lane) & 1ull;
+      const unsigned long long o = run + dev::lanemask_lt_count(lm[c], lane);
+      if (live && o < cap) dests[o] = (int)dst[c];
+      if (s < N && val[c] != 0 && (dst[c] == kMax || val[c] == kMax)) {  // sentinel: its live rank is the row offset
+        const uint32_t vid = (val[c] == kMax) ? 0u : val[c];
+        row_offsets[vid] = o;
+      }
+      run += (unsigned long long)wv::popc64(lm[c]);
+    }
+    wv::block_sync();  // s_tile / s_wsum are reused by the next tile
   }
 }
 
