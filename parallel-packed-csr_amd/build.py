@@ -37,6 +37,21 @@ def build_engine(force=False, verbose=False):
     return LIB
 
 
+HOST_DIR = os.path.join(HERE, "host")
+CLI = os.path.join(HOST_DIR, "ppcsr_cli")
+CPP_TEST = os.path.join(ROOT, "tests", "cpp", "test_datastructure")
+
+
+def build_host():
+    """the C++ host side above the C ABI: CLI with the reference's flags + the restated DataStructureTest binary"""
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + HOST_DIR]
+    link = ["-L" + CSRC, "-lppcsr_hip", "-Wl,-rpath," + CSRC]
+    base = ["g++", "-std=c++17", "-O2", "-Wall"]
+    subprocess.run(base + inc + [os.path.join(HOST_DIR, "main.cpp")] + link + ["-o", CLI], check=True)
+    subprocess.run(base + inc + [os.path.join(ROOT, "tests", "cpp", "test_datastructure.cpp")] + link + ["-o", CPP_TEST], check=True)
+    return CLI
+
+
 def build_oracle():
     """test infrastructure: the C restatement and (when /root/reference exists) the real reference"""
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True)

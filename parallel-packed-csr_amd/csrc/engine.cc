@@ -857,22 +857,29 @@ int Engine::read_neighbourhood(int src) {
   return get_neighbourhood(src, nullptr, 0, &c);
 }
 
-// bulk neighbour scan = ONE kernel (decoupled look-back stream compaction, pma_kernels.h): reads the edge array once
+// bulk neighbour scan: live-edge count per 64-slot chunk from the leaf counts and the sentinel positions (no pass over
+// the edge array), exclusive scan, then ONE streaming pass that writes dests (array order == CSR order) and row offsets.
+// (A single-kernel decoupled look-back variant, k_scan_onepass, is kept in pma_kernels.h: it measured slower on MI355X —
+//  110 us vs 85 us at N = 2^24 — because 1.5 K polling workgroups disturb the streaming loads.)
 int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap) {
   Impl &p = *p_;
-  const uint64_t N = p.v.g.N, ntiles = (N + kScanTileSlots - 1) / kScanTileSlots;
-  if (p.scan_state_cap < ntiles + 1) {
+  const uint64_t N = p.v.g.N, nchunks = (N + 63) / 64;
+  if (p.scan_state_cap < 2 * nchunks) {
     if (p.d_scan_state) GPU_DFREE(p.d_scan_state);
     p.d_scan_state = nullptr;
     p.scan_state_cap = 0;
-    GCHK(gpu::dmalloc((void **)&p.d_scan_state, (ntiles + 1) * sizeof(unsigned long long)));
-    p.scan_state_cap = ntiles + 1;
+    GCHK(gpu::dmalloc((void **)&p.d_scan_state, 2 * nchunks * sizeof(uint32_t) + 64));
+    p.scan_state_cap = 2 * nchunks;
   }
-  // tile words + the ticket (last word) are zeroed every call
-  GCHK(gpu::dset(p.d_scan_state, 0, (ntiles + 1) * sizeof(unsigned long long), p.stream));
-  const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, 256 * 6);
-  GPU_LAUNCH(p.stream, k_scan_onepass, grid, 256, p.v, p.d_scan_state, reinterpret_cast<uint32_t *>(p.d_scan_state + ntiles),
-             d_rows, d_dst, cap, p.d_total);
+  uint32_t *d_cs = reinterpret_cast<uint32_t *>(p.d_scan_state), *d_cc = d_cs + nchunks;
+  int rc = ensure_scratch(nchunks);
+  if (rc != PPCSR_OK) return rc;
+  GCHK(gpu::dset(d_cs, 0, nchunks * sizeof(uint32_t), p.stream));
+  GPU_LAUNCH(p.stream, k_chunk_sentinels, grid_for(n(), 256), 256, p.v, d_cs);
+  GPU_LAUNCH(p.stream, k_chunk_counts, grid_for(nchunks, 256), 256, p.v, (const uint32_t *)d_cs, d_cc);
+  rc = rank_scan(d_cc, nchunks);
+  if (rc != PPCSR_OK) return rc;
+  GPU_LAUNCH(p.stream, k_scan_write, grid_for(nchunks, 4), 256, p.v, (const uint32_t *)p.d_rank, d_rows, d_dst, cap);
   return PPCSR_OK;
 }
 

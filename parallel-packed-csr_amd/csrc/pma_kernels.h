@@ -1022,40 +1022,60 @@ PMA_KERNEL void k_scan_onepass(View v, unsigned long long *tile_state, uint32_t 
     uint64_t lm[kScanChunks];
     uint32_t wcount = 0;
 #pragma unroll
+    for (uint32_t c = 0; c < kScanChunks; c++) {  // all loads of the tile are issued before any is consumed
+      const uint64_t s = wbase + (uint64_t)c * 64 + (uint64_t)lane;
+      dst[c] = 0;
+      val[c] = 0;
+      if (s < N) {
+        dst[c] = v.items[s].dest;
+        val[c] = v.items[s].value;
+      }
+    }
+#pragma unroll
     for (uint32_t c = 0; c < kScanChunks; c++) {
       const uint64_t s = wbase + (uint64_t)c * 64 + (uint64_t)lane;
-      Edge e = null_edge();
-      if (s < N) e = v.items[s];
-      dst[c] = e.dest;
-      val[c] = e.value;
-      const bool live = e.value != 0 && !is_sentinel(e) && (s + 1 < N);
+      const bool live = val[c] != 0 && dst[c] != kMax && val[c] != kMax && (s + 1 < N);
       lm[c] = wv::ballot(live);
       wcount += (uint32_t)wv::popc64(lm[c]);
     }
     if (lane == 0) s_wsum[w] = wcount;
     wv::block_sync();
-    if (wv::thread_idx() == 0) {
+    if (w == 0) {  // wave 0 resolves the tile's exclusive prefix: 64 predecessors per look-back step
       const unsigned long long agg = (unsigned long long)s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
       unsigned long long excl = 0;
       if (tile == 0) {
-        wv::agent_store_u64(&tile_state[0], kFlagPre | agg);
+        if (lane == 0) wv::agent_store_u64(&tile_state[0], kFlagPre | agg);
       } else {
-        wv::agent_store_u64(&tile_state[tile], kFlagAgg | agg);
-        uint64_t t = tile;
-        for (;;) {  // look back
-          t--;
-          unsigned long long st;
-          do {
-            st = wv::agent_load_u64(&tile_state[t]);
-            if ((st & kFlagMask) == 0) wv::spin_pause();
-          } while ((st & kFlagMask) == 0);
-          excl += st & ~kFlagMask;
-          if ((st & kFlagMask) == kFlagPre) break;
+        if (lane == 0) wv::agent_store_u64(&tile_state[tile], kFlagAgg | agg);
+        uint64_t hi = tile;  // predecessors [hi-64, hi) are inspected next
+        for (;;) {
+          const bool have = (uint64_t)lane < hi;
+          const uint64_t t = hi - 1 - (uint64_t)lane;  // lane 0 = nearest predecessor
+          unsigned long long st = 0;
+          uint64_t ready, pre;
+          for (;;) {
+            st = have ? wv::agent_load_u64(&tile_state[t]) : kFlagPre;  // beyond tile 0: a zero-valued "prefix"
+            ready = wv::ballot((st & kFlagMask) != 0);
+            pre = wv::ballot((st & kFlagMask) == kFlagPre);
+            // usable once every lane up to the nearest published prefix is ready
+            const int fp = pre ? wv::ctz64(pre) : 63;
+            const uint64_t need = (fp >= 63) ? ~0ull : ((2ull << fp) - 1ull);
+            if ((ready & need) == need) break;
+            wv::spin_pause();
+          }
+          const int fp = pre ? wv::ctz64(pre) : 63;
+          const unsigned long long mine = (lane <= fp) ? (st & ~kFlagMask) : 0ull;
+          const uint32_t lo = wv::reduce_add((uint32_t)mine), hi32 = wv::reduce_add((uint32_t)(mine >> 32));
+          excl += (unsigned long long)lo + ((unsigned long long)hi32 << 32);
+          if (pre) break;
+          hi -= 64;
         }
-        wv::agent_store_u64(&tile_state[tile], kFlagPre | (excl + agg));
+        if (lane == 0) wv::agent_store_u64(&tile_state[tile], kFlagPre | (excl + agg));
       }
-      s_excl = excl;
-      if (tile == ntiles - 1) *total = excl + agg;
+      if (lane == 0) {
+        s_excl = excl;
+        if (tile == ntiles - 1) *total = excl + agg;
+      }
     }
     wv::block_sync();
     unsigned long long run = s_excl;

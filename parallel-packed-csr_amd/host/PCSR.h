@@ -1,0 +1,180 @@
+// Host-side mirror of the reference class PCSR (reference: src/pcsr/PCSR.h:64-202) over the MI355X engine's C ABI.
+// Same type names, method names, argument meaning and observable behaviour as the reference so that code written
+// against the reference (tests, bfs.h / pagerank.h templates, thread pools, main.cpp) compiles against this header.
+// The state lives in HBM; writers enqueue into a batch that is applied — with the reference's sequential
+// stream-order semantics — at the next read, at flush(), or when the batch reaches kAutoFlush updates.
+#ifndef PPCSR_HOST_PCSR_H
+#define PPCSR_HOST_PCSR_H
+#include <ppcsr.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <iostream>
+#include <memory>
+#include <vector>
+
+typedef struct _node {  // reference PCSR.h:18-23
+  uint32_t beginning;
+  uint32_t end;
+  uint32_t num_neighbors;
+} node_t;
+typedef struct _edge {  // reference PCSR.h:30-35
+  uint32_t src;
+  uint32_t dest;
+  uint32_t value;
+} edge_t;
+
+// The reference exposes its locks through `edges` (PCSR.h:37-44) and its tests poke them
+// (DataStructureTest.cpp:58-62, 86-92).  The GPU engine has no host locks: these are inert stand-ins.
+struct FastLock {
+  void registerThread() {}
+  void unregisterThread() {}
+  bool lockable() { return true; }
+};
+struct HybridLock {
+  bool lockable() { return true; }
+};
+typedef struct edge_list {
+  uint64_t N = 0;
+  int H = 0;
+  int logN = 0;
+  std::shared_ptr<FastLock> global_lock = std::make_shared<FastLock>();
+  HybridLock **node_locks = nullptr;  // node_locks[i] is valid for i < N / logN
+  edge_t *items = nullptr;            // host mirror, valid after PCSR::download()
+} edge_list_t;
+
+class PCSR {
+ public:
+  edge_list_t edges;  // N / logN / H are refreshed after every flush
+
+  // reference: PCSR(uint32_t init_n, uint32_t src_n, bool lock_search, int domain = 0)   PCSR.cpp:775
+  // `domain` selected the NUMA node; here it selects the GPU (negative = device 0)
+  PCSR(uint32_t init_n, uint32_t src_n, bool lock_search, int domain = 0) {
+    check(ppcsr_create(init_n, src_n, lock_search ? 1 : 0, domain < 0 ? 0 : domain, &h_));
+    refresh_geometry(true);
+  }
+  ~PCSR() {
+    ppcsr_destroy(h_);
+    delete[] lock_store_;
+    delete[] lock_ptrs_;
+  }
+  PCSR(const PCSR &) = delete;
+  PCSR &operator=(const PCSR &) = delete;
+  PCSR(PCSR &&o) noexcept { *this = std::move(o); }
+  PCSR &operator=(PCSR &&o) noexcept {
+    std::swap(h_, o.h_);
+    std::swap(edges, o.edges);
+    std::swap(pending_, o.pending_);
+    std::swap(items_host_, o.items_host_);
+    std::swap(lock_store_, o.lock_store_);
+    std::swap(lock_ptrs_, o.lock_ptrs_);
+    std::swap(lock_cap_, o.lock_cap_);
+    return *this;
+  }
+
+  /** Public API (reference PCSR.h:72-124) */
+  bool edge_exists(uint32_t src, uint32_t dest) {  // PCSR.cpp:860
+    flush();
+    int e = 0;
+    check(ppcsr_edge_exists(h_, src, dest, &e));
+    return e != 0;
+  }
+  void add_node() {  // PCSR.cpp:681
+    flush();
+    check(ppcsr_add_node(h_));
+    refresh_geometry(false);
+  }
+  void add_edge(uint32_t src, uint32_t dest, uint32_t value) {  // PCSR.cpp:706 (value 0 / src >= n: silently ignored)
+    if (value == 0) return;
+    pending_.push_back(ppcsr_op{src, dest, value});
+    if (pending_.size() >= kAutoFlush) flush();
+  }
+  void remove_edge(uint32_t src, uint32_t dest) {  // PCSR.cpp:709
+    pending_.push_back(ppcsr_op{src, dest, 0u});
+    if (pending_.size() >= kAutoFlush) flush();
+  }
+  void read_neighbourhood(int src) {  // PCSR.cpp:892
+    flush();
+    check(ppcsr_read_neighbourhood(h_, src));
+  }
+  std::vector<int> get_neighbourhood(int src) {  // PCSR.cpp:901
+    flush();
+    uint64_t c = 0;
+    check(ppcsr_get_neighbourhood(h_, src, nullptr, 0, &c));
+    std::vector<int> out(c);
+    if (c) check(ppcsr_get_neighbourhood(h_, src, out.data(), c, &c));
+    return out;
+  }
+  uint64_t get_n() {  // PCSR.cpp:100
+    uint64_t n = 0;
+    check(ppcsr_get_n(h_, &n));
+    return n;
+  }
+  // reference returns node_t& into host memory (PCSR.h:118); the state is in HBM, so this is a copy
+  node_t getNode(int id) {
+    flush();
+    ppcsr_node nd;
+    check(ppcsr_get_node(h_, (uint32_t)id, &nd));
+    return node_t{nd.beginning, nd.end, nd.num_neighbors};
+  }
+
+  /** additions that have no reference equivalent */
+  void flush() {  // apply everything enqueued so far, in order
+    if (pending_.empty()) return;
+    check(ppcsr_apply_batch(h_, pending_.data(), pending_.size()));
+    pending_.clear();
+    refresh_geometry(false);
+  }
+  void download(std::vector<edge_t> *items, std::vector<node_t> *nodes) {  // raw state, reference byte layout
+    flush();
+    items->resize(edges.N);
+    nodes->resize(get_n());
+    check(ppcsr_export_state(h_, reinterpret_cast<ppcsr_edge *>(items->data()), reinterpret_cast<ppcsr_node *>(nodes->data())));
+  }
+  ppcsr_t handle() { return h_; }
+  size_t pending() const { return pending_.size(); }
+  static bool &quiet() {
+    static bool q = false;
+    return q;
+  }
+
+ private:
+  static constexpr size_t kAutoFlush = 1u << 22;
+  static void check(int rc) {
+    if (rc != 0) {  // the reference exits on failure (PCSR.cpp:49-54); keep that behaviour at this level
+      std::cout << "ppcsr: " << ppcsr_strerror(rc) << ": " << ppcsr_last_error() << std::endl;
+      std::exit(EXIT_FAILURE);
+    }
+  }
+  void refresh_geometry(bool first) {
+    uint64_t N = 0;
+    int lg = 0, H = 0;
+    check(ppcsr_geometry(h_, &N, &lg, &H));
+    if (first || N != edges.N) {
+      edges.N = N;
+      edges.logN = lg;
+      edges.H = H;
+      // same line the reference prints from resizeEdgeArray (PCSR.cpp:72); intermediate sizes inside one batch are not shown
+      if (!quiet()) std::cout << "Edges: " << N << " logN: " << lg << " #count: " << N / lg << std::endl;
+      const uint64_t nl = N / (uint64_t)lg;
+      if (nl > lock_cap_) {
+        delete[] lock_store_;
+        delete[] lock_ptrs_;
+        lock_store_ = new HybridLock[nl];
+        lock_ptrs_ = new HybridLock *[nl];
+        for (uint64_t i = 0; i < nl; i++) lock_ptrs_[i] = &lock_store_[i];
+        lock_cap_ = nl;
+      }
+      edges.node_locks = lock_ptrs_;
+    }
+  }
+
+  ppcsr_t h_ = nullptr;
+  std::vector<ppcsr_op> pending_;
+  std::vector<edge_t> items_host_;
+  HybridLock *lock_store_ = nullptr;
+  HybridLock **lock_ptrs_ = nullptr;
+  uint64_t lock_cap_ = 0;
+};
+
+#endif  // PPCSR_HOST_PCSR_H
