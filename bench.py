@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--mixed", action="store_true", help="config #3: alternate insert / delete-existing")
     ap.add_argument("--labels", choices=["permuted", "raw"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-cli", action="store_true", help="skip the multi-threaded run of the reference's own CLI binary")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket round kernels with HIP events")
     ap.add_argument("--mode", type=int, default=-1, help="0 strict prefix rounds, 1 speculative rounds (engine default)")
     ap.add_argument("--opt-horizon", type=int, default=0)
@@ -257,6 +258,35 @@ def main():
             assert eng.geometry() == c2.geometry() and np.array_equal(ei, oi) and np.array_equal(en, on), "PARITY FAILURE"
             extra["parity_checked"] = True
         c.close()
+        # the reference's own binary with its thread pools (the north_star's "-pppcsrnuma CPU path on the same box"):
+        # text edge lists in /tmp, phase-2 time = the SECOND "Elapsed wall clock time" line (reference bench protocol)
+        ref_cli = os.path.join(ROOT, "oracle", "_ref", "ref_cli")
+        if os.path.exists(ref_cli) and not args.no_ref_cli and not args.mixed:
+            try:
+                import subprocess
+                import pandas as pd
+                cores = os.cpu_count() or 1
+                try:
+                    cores = len(os.sched_getaffinity(0))
+                except Exception:
+                    pass
+                cf, uf = "/tmp/ppcsr_bench_core.txt", "/tmp/ppcsr_bench_upd.txt"
+                pd.DataFrame(core_blk[:, :2]).to_csv(cf, sep=" ", header=False, index=False)
+                pd.DataFrame(upd[args.warmup][:, :2]).to_csv(uf, sep=" ", header=False, index=False)
+                runs = {}
+                for label, flags in (("ppcsr", ["-ppcsr"]), ("pppcsrnuma", ["-pppcsrnuma", "-partitions_per_domain=8"])):
+                    r = subprocess.run([ref_cli, f"-threads={cores}", f"-size={args.batch}", "-insert"] + flags +
+                                       [f"-core_graph={cf}", f"-update_file={uf}"], capture_output=True, text=True, timeout=600)
+                    el = [int(l.split(":")[1]) for l in r.stdout.splitlines() if l.startswith("Elapsed wall clock time")]
+                    if len(el) >= 2 and el[1] > 0:
+                        runs[label] = {"updates_per_s": args.batch / (el[1] * 1e-3), "ms": el[1], "core_load_ms": el[0]}
+                extra["cpu_reference_cli"] = {"cores": cores, "threads": cores, "runs": runs,
+                                              "note": "unmodified reference binary (oracle/_ref/ref_cli); multi-threaded runs are "
+                                                      "not deterministic in layout (SURVEY.md §8c)"}
+                os.remove(cf)
+                os.remove(uf)
+            except Exception as e:
+                extra["cpu_reference_cli_error"] = str(e)
 
     # ---- secondary kernels: bulk neighbour scan + whole-window rebalance (HBM-roofline kernels) ----
     if rank == 0:
