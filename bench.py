@@ -274,13 +274,17 @@ def main():
                 pd.DataFrame(core_blk[:, :2]).to_csv(cf, sep=" ", header=False, index=False)
                 pd.DataFrame(upd[args.warmup][:, :2]).to_csv(uf, sep=" ", header=False, index=False)
                 runs = {}
-                for label, flags in (("ppcsr", ["-ppcsr"]), ("pppcsrnuma", ["-pppcsrnuma", "-partitions_per_domain=8"])):
-                    r = subprocess.run([ref_cli, f"-threads={cores}", f"-size={args.batch}", "-insert"] + flags +
+                share = min(cores, 16)  # the box's CPU share for one GPU
+                for label, thr, flags in (("ppcsr_t8", 8, ["-ppcsr"]), (f"ppcsr_t{share}", share, ["-ppcsr"]),
+                                          (f"pppcsrnuma_t{share}", share, ["-pppcsrnuma", "-partitions_per_domain=8"])):
+                    r = subprocess.run([ref_cli, f"-threads={thr}", f"-size={args.batch}", "-insert"] + flags +
                                        [f"-core_graph={cf}", f"-update_file={uf}"], capture_output=True, text=True, timeout=600)
                     el = [int(l.split(":")[1]) for l in r.stdout.splitlines() if l.startswith("Elapsed wall clock time")]
                     if len(el) >= 2 and el[1] > 0:
-                        runs[label] = {"updates_per_s": args.batch / (el[1] * 1e-3), "ms": el[1], "core_load_ms": el[0]}
-                extra["cpu_reference_cli"] = {"cores": cores, "threads": cores, "runs": runs,
+                        runs[label] = {"updates_per_s": args.batch / (el[1] * 1e-3), "ms": el[1], "core_load_ms": el[0], "threads": thr}
+                    else:
+                        runs[label] = {"failed": r.returncode, "stderr": r.stderr[-200:], "stdout_tail": r.stdout[-200:]}
+                extra["cpu_reference_cli"] = {"cores_visible": cores, "runs": runs,
                                               "note": "unmodified reference binary (oracle/_ref/ref_cli); multi-threaded runs are "
                                                       "not deterministic in layout (SURVEY.md §8c)"}
                 os.remove(cf)
