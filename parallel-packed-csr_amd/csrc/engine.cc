@@ -56,7 +56,7 @@ struct Engine::Impl {
   int *d_nbr = nullptr;
   uint64_t nbr_cap = 0;
   uint32_t round = 0;
-  uint32_t max_horizon = 4096, min_horizon = 64, rounds_per_sync = 16, init_horizon = 256;
+  uint32_t max_horizon = 4096, min_horizon = 64, rounds_per_sync = 32, init_horizon = 256;
   gpu::Timer timer;
   EngineStats st{};
   // snapshots: second copies of the state in HBM.  `snap` = user snapshot()/restore(); `esnap` = rollback
@@ -531,7 +531,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         GCHK(gpu::h2d(&p.d_octl->max_horizon, &gh, sizeof(uint32_t), p.stream));
         c.max_horizon = gh;
       }
-      const uint32_t rounds = (gh == p.opt_horizon) ? std::max<uint32_t>(1u, p.rounds_per_sync / 4) : p.rounds_per_sync;
+      const uint32_t rounds = p.rounds_per_sync;
       if (p.profile && p.events.size() < 5ull * rounds) {
         const size_t oldn = p.events.size();
         p.events.resize(5ull * rounds);

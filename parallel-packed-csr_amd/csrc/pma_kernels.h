@@ -934,36 +934,38 @@ PMA_KERNEL void o_compact(OptArgs a) {
   const uint32_t tid = wv::thread_idx(), bd = wv::block_dim();
   const int lane = wv::lane(), w = wv::wave_in_block();
   const uint32_t nw = bd >> 6;
-  if (tid == 0) s_count = 0;
-  wv::block_sync();
-  uint32_t ncommitted = 0;
-  uint32_t mymaxc = 0;
-  for (uint32_t base = 0; base < hor; base += bd) {
-    const uint32_t s = base + tid;
-    bool keep = false;
-    uint32_t idx = 0;
-    if (s < hor) {
-      keep = a.status[s] != OS_COMMITTED;
-      idx = a.opidx[s];
-      if (!keep && idx + 1u > mymaxc) mymaxc = idx + 1u;
+  // each thread owns a run of consecutive slots, so ONE block-wide exclusive scan orders the whole horizon
+  const uint32_t per = (hor + bd - 1) / bd;
+  const uint32_t s0 = tid * per;
+  uint32_t mykeep = 0, mymaxc = 0;
+  for (uint32_t q = 0; q < per; q++) {
+    const uint32_t sl = s0 + q;
+    if (sl < hor) {
+      if (a.status[sl] != OS_COMMITTED) mykeep++;
+      else if (a.opidx[sl] + 1u > mymaxc) mymaxc = a.opidx[sl] + 1u;
     }
-    const uint64_t m = wv::ballot(keep);
-    const uint32_t wcnt = (uint32_t)wv::popc64(m);
-    if (lane == 0) wsum[w] = wcnt;
-    wv::block_sync();
-    uint32_t woff = 0, tot = 0;
-    for (uint32_t q = 0; q < nw; q++) {
-      if (q < (uint32_t)w) woff += wsum[q];
-      tot += wsum[q];
-    }
-    const uint32_t cbase = s_count;
-    if (keep) cout[cbase + woff + dev::lanemask_lt_count(m, lane)] = idx;
-    wv::block_sync();
-    if (tid == 0) s_count = cbase + tot;
-    const uint32_t inchunk = (hor - base < bd) ? hor - base : bd;
-    ncommitted += inchunk - tot;
-    wv::block_sync();
   }
+  // wave-level inclusive scan of the per-thread counts, then wave totals through LDS
+  uint32_t incl = mykeep;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) wsum[w] = incl;
+  wv::block_sync();
+  uint32_t woff = 0, tot = 0;
+  for (uint32_t q = 0; q < nw; q++) {
+    if (q < (uint32_t)w) woff += wsum[q];
+    tot += wsum[q];
+  }
+  uint32_t o = woff + incl - mykeep;
+  for (uint32_t q = 0; q < per; q++) {
+    const uint32_t sl = s0 + q;
+    if (sl < hor && a.status[sl] != OS_COMMITTED) cout[o++] = a.opidx[sl];
+  }
+  const uint32_t ncommitted = hor - tot;
+  if (tid == 0) s_count = tot;
+  wv::block_sync();
   const uint32_t kept = s_count;
   if (mymaxc) wv::atomic_max_u32(&c->maxc, mymaxc);  // <= 1024 atomics per round, only by threads that saw a commit
   for (uint32_t i = used + tid; i < cn; i += bd) cout[kept + (i - used)] = cin[i];  // carry entries beyond the horizon
