@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <map>
 #include <chrono>
 
 #include "gpu_rt.h"
@@ -73,17 +74,33 @@ struct Engine::Impl {
   uint32_t *d_opidx = nullptr, *d_status = nullptr, *d_carry0 = nullptr, *d_carry1 = nullptr;
   uint64_t carry_cap = 0, hslot_cap = 0;
   unsigned long long *d_regfail = nullptr, *d_pfail = nullptr;
+  uint32_t *d_vws = nullptr, *d_vrs = nullptr;  // per-vertex sentinel stamps (capacity n_cap + 1)
   uint32_t *d_wstamp = nullptr, *d_rstamp = nullptr;
   uint32_t mode = 1;             // 0 = strict prefix rounds, 1 = speculative rounds with validated rollback
   uint32_t epoch_ops = 1u << 20;  // rollback granularity
   uint32_t region_slots = 4096;  // per-region prefix rule (>= kBigWindow so a window never leaves its region)
   uint32_t opt_horizon = 4096;   // rounds are bound by dependency chains, not by width: a wider horizon only re-plans more
+  bool carry_dumped = false;
   bool partial = false;
   bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
   std::vector<gpu::Event> events;  // init failed half-way: destructor frees only what exists
 };
 
 Engine::Engine() : p_(new Impl()) {}
+
+// every round-tagged reservation array restarts together with the round counter (stale keys must never meet a reused tag)
+static int reset_tags(Engine::Impl &p) {
+  const uint64_t leaves = p.v.g.N >> p.v.g.sh;
+  int e;
+  if (p.v.wres && (e = gpu::dset(p.v.wres, 0xFF, leaves * sizeof(unsigned long long), p.stream))) return e;
+  if (p.v.rres && (e = gpu::dset(p.v.rres, 0xFF, leaves * sizeof(unsigned long long), p.stream))) return e;
+  if (p.d_regfail && (e = gpu::dset(p.d_regfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream))) return e;
+  if (p.d_pfail && (e = gpu::dset(p.d_pfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream))) return e;
+  if (p.v.vw && (e = gpu::dset(p.v.vw, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
+  if (p.v.vr && (e = gpu::dset(p.v.vr, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
+  p.round = 0;
+  return 0;
+}
 
 // per-leaf auxiliary arrays that follow the geometry of `v` (reservations, stamps, region fail-mins)
 static int alloc_aux(Engine::Impl &p, View &v) {
@@ -103,6 +120,28 @@ static int alloc_aux(Engine::Impl &p, View &v) {
   if ((e = gpu::dset(p.d_rstamp, 0, leaves * sizeof(uint32_t), p.stream))) return e;
   p.leaves_cap = leaves;
   p.round = 0;
+  if (v.vw && (e = gpu::dset(v.vw, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
+  if (v.vr && (e = gpu::dset(v.vr, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
+  return 0;
+}
+// per-vertex sentinel reservation / stamp arrays (follow the capacity of nodes[])
+static int alloc_vertex_aux(Engine::Impl &p, View &v) {
+  const uint64_t cap = p.n_cap + 1;
+  int e;
+  if (v.vw) GPU_DFREE(v.vw);
+  if (v.vr) GPU_DFREE(v.vr);
+  if (p.d_vws) GPU_DFREE(p.d_vws);
+  if (p.d_vrs) GPU_DFREE(p.d_vrs);
+  v.vw = v.vr = nullptr;
+  p.d_vws = p.d_vrs = nullptr;
+  if ((e = gpu::dmalloc((void **)&v.vw, cap * sizeof(unsigned long long)))) return e;
+  if ((e = gpu::dmalloc((void **)&v.vr, cap * sizeof(unsigned long long)))) return e;
+  if ((e = gpu::dmalloc((void **)&p.d_vws, cap * sizeof(uint32_t)))) return e;
+  if ((e = gpu::dmalloc((void **)&p.d_vrs, cap * sizeof(uint32_t)))) return e;
+  if ((e = gpu::dset(v.vw, 0xFF, cap * sizeof(unsigned long long), p.stream))) return e;
+  if ((e = gpu::dset(v.vr, 0xFF, cap * sizeof(unsigned long long), p.stream))) return e;
+  if ((e = gpu::dset(p.d_vws, 0, cap * sizeof(uint32_t), p.stream))) return e;
+  if ((e = gpu::dset(p.d_vrs, 0, cap * sizeof(uint32_t), p.stream))) return e;
   return 0;
 }
 static void free_aux(Engine::Impl &p, View &v) {
@@ -170,6 +209,7 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   GCHK(gpu::dmalloc((void **)&p.v.nodes, p.n_cap * sizeof(Node)));
   GCHK(gpu::dmalloc((void **)&p.v.leafcnt, p.leaves_cap * sizeof(uint32_t)));
   GCHK(alloc_aux(p, p.v));
+  GCHK(alloc_vertex_aux(p, p.v));
   GCHK(gpu::dmalloc((void **)&p.d_octl, sizeof(OptCtl)));
   GCHK(gpu::hmalloc((void **)&p.h_octl, sizeof(OptCtl)));
   GCHK(gpu::dmalloc((void **)&p.d_ctl, sizeof(Control)));
@@ -220,6 +260,10 @@ Engine::~Engine() {
   GPU_DFREE(p.v.nodes);
   GPU_DFREE(p.v.leafcnt);
   free_aux(p, p.v);
+  if (p.v.vw) GPU_DFREE(p.v.vw);
+  if (p.v.vr) GPU_DFREE(p.v.vr);
+  if (p.d_vws) GPU_DFREE(p.d_vws);
+  if (p.d_vrs) GPU_DFREE(p.d_vrs);
   GPU_DFREE(p.d_octl);
   gpu::hfree(p.h_octl);
   if (p.d_opidx) GPU_DFREE(p.d_opidx);
@@ -355,10 +399,7 @@ int Engine::apply_batch_device(const Op *d_ops, uint64_t n) {
 
 int Engine::run_rounds(const Op *d_ops, uint64_t n) {
   Impl &p = *p_;
-  if (p.round > 0xFFFF0000u) {  // reservation tags would wrap: start a fresh epoch
-    GCHK(gpu::dset(p.v.wres, 0xFF, p.leaves_cap * sizeof(unsigned long long), p.stream));
-    p.round = 0;
-  }
+  if (p.round > 0xFFFF0000u) GCHK(reset_tags(p));  // reservation tags would wrap
   uint64_t cur = 0;
   uint32_t hor = (uint32_t)std::min<uint64_t>(p.init_horizon, n);
   while (cur < n) {
@@ -475,20 +516,16 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
   while (e0 < n) {
     uint64_t e1 = std::min<uint64_t>(e0 + p.epoch_ops, n);
     if (forced_e1 > e0 && forced_e1 < e1) e1 = forced_e1;
-    if (p.round > 0xFFFF0000u) {
-      const uint64_t leaves = p.v.g.N >> p.v.g.sh;
-      GCHK(gpu::dset(p.v.wres, 0xFF, leaves * sizeof(unsigned long long), p.stream));
-      GCHK(gpu::dset(p.v.rres, 0xFF, leaves * sizeof(unsigned long long), p.stream));
-      GCHK(gpu::dset(p.d_regfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream));
-      GCHK(gpu::dset(p.d_pfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream));
-      p.round = 0;
-    }
+    if (p.round > 0xFFFF0000u) GCHK(reset_tags(p));
+    p.carry_dumped = false;
     GCHK(snap_save(p, p.esnap));
     GCHK(gpu::d2d(p.d_stats_snap, p.d_stats, kStatShards * sizeof(StatShard), p.stream));
     {
       const uint64_t leaves = p.v.g.N >> p.v.g.sh;
       GCHK(gpu::dset(p.d_wstamp, 0, leaves * sizeof(uint32_t), p.stream));
       GCHK(gpu::dset(p.d_rstamp, 0, leaves * sizeof(uint32_t), p.stream));
+      GCHK(gpu::dset(p.d_vws, 0, (p.n_cap + 1) * sizeof(uint32_t), p.stream));
+      GCHK(gpu::dset(p.d_vrs, 0, (p.n_cap + 1) * sizeof(uint32_t), p.stream));
     }
     OptCtl &c = *p.h_octl;
     memset(&c, 0, sizeof(c));
@@ -521,6 +558,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       a.pfail = p.d_pfail;
       a.wstamp = p.d_wstamp;
       a.rstamp = p.d_rstamp;
+      a.vws = p.d_vws;
+      a.vrs = p.d_vrs;
       a.regshift = rs;
       // grid sized for the horizon the device last reported (it can only shrink within a chunk when fresh
       // updates run out; it never exceeds opt_horizon)
@@ -620,6 +659,25 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         retries = 0;
         epoch_open = false;
       } else {
+        if (const char *tc = getenv("PPCSR_TRACE_CARRY")) {  // debug: who is stuck?  histogram of src over the carry list
+          const uint32_t cn = c.carry_n[npar];
+          if (c.rounds >= (unsigned long long)atoi(tc) && cn > 0 && !p.carry_dumped) {
+            p.carry_dumped = true;
+            std::vector<uint32_t> idxs(cn);
+            GCHK(gpu::d2h(idxs.data(), npar ? p.d_carry1 : p.d_carry0, cn * sizeof(uint32_t), p.stream));
+            GCHK(gpu::sync(p.stream));
+            std::vector<Op> hops(cn);
+            for (uint32_t i = 0; i < cn; i++) GCHK(gpu::d2h(&hops[i], d_ops + idxs[i], sizeof(Op), p.stream));
+            GCHK(gpu::sync(p.stream));
+            std::map<uint32_t, uint32_t> hist;
+            for (auto &o : hops) hist[o.src]++;
+            std::vector<std::pair<uint32_t, uint32_t>> hv(hist.begin(), hist.end());
+            std::sort(hv.begin(), hv.end(), [](auto &a, auto &b) { return a.second > b.second; });
+            fprintf(stderr, "[ppcsr] carry after %llu rounds: %u stuck updates over %zu sources; top:", c.rounds, cn, hv.size());
+            for (size_t i = 0; i < hv.size() && i < 24; i++) fprintf(stderr, " src%u:%u", hv[i].first, hv[i].second);
+            fprintf(stderr, "\n");
+          }
+        }
         hint_hor = c.hor[npar];
         if (hint_hor > gh) {
           // the grid of the next chunk must cover the horizon the device chose
@@ -786,6 +844,7 @@ int Engine::add_node() {  // PCSR.cpp:681-703
     GPU_DFREE(p.v.nodes);
     p.v.nodes = nn;
     p.n_cap = ncap;
+    GCHK(alloc_vertex_aux(p, p.v));
   }
   Node nd;
   uint32_t sval = len;

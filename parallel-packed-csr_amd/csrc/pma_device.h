@@ -24,6 +24,8 @@ struct View {
   uint32_t *leafcnt;
   unsigned long long *wres;  // per-leaf write reservation key of the current round
   unsigned long long *rres;  // per-leaf read reservation key (optimistic mode)
+  unsigned long long *vw;    // per-vertex: earliest pending update that may MOVE this vertex's sentinel
+  unsigned long long *vr;    // per-vertex: earliest pending update that READS this sentinel's position
   Geometry g;
 };
 
@@ -544,11 +546,13 @@ PMA_DEV void plan_op(const View &v, const Op op, Plan *plan) {
   rr.plan = plan;
   rr.nr = 0;
   uint32_t kind = K_NOOP, index = 0, gap = 0, wstart = 0, wlen = 0, wl = 1, wh = 0, acalls = 0, aslots = 0;
+  uint32_t sleaf_b = 0, sleaf_e = 0, mv_lo = 1, mv_hi = 0;
   if (op.src < g.n) {
     const Node nd = v.nodes[op.src];
-    // nodes[src].{beginning,end} move only when the sentinels of src / src+1 move: read dependency on their leaves
-    rec_range(rr, v, nd.beginning, nd.beginning);
-    rec_range(rr, v, nd.end, nd.end);
+    // nodes[src].{beginning,end} are the positions of sentinels src / src+1: that dependency is tracked per vertex
+    // (Plan::mv_lo/mv_hi of the writers, View::vw/vr), not through the leaves that hold them
+    sleaf_b = nd.beginning >> g.sh;
+    sleaf_e = nd.end >> g.sh;
     index = pma_search(v, op.dst, nd.beginning + 1, nd.end, rr);
     const Edge at = v.items[index];
     const bool occupied = !is_null(at);
@@ -616,7 +620,40 @@ PMA_DEV void plan_op(const View &v, const Op op, Plan *plan) {
   } else if (op.op == 0) {
     kind = K_NOOP;  // reference: unchecked out-of-range delete is UB; we ignore it
   }
+  if (kind == K_INSERT || kind == K_REMOVE) {
+    // sentinels inside [lo, hi] = slide range U window.  Sentinel positions increase with the vertex id and
+    // beg(src) < index <= beg(src+1), so they are the vertices src, src-1, ... and src+1, src+2, ... around `src`.
+    const uint32_t lo = (wstart < index) ? wstart : index;
+    const uint32_t whi = wstart + wlen - 1u;
+    const uint32_t hi = (kind == K_INSERT && gap > whi) ? gap : whi;
+    uint32_t down = 0, up = 0;
+    for (uint32_t base = 0;; base += 64) {  // downwards: src, src-1, ...
+      const uint32_t k = base + (uint32_t)lane;
+      bool in = false;
+      if (k <= op.src) in = v.nodes[op.src - k].beginning >= lo;
+      const uint64_t m = wv::ballot(in);
+      down += (uint32_t)wv::popc64(m);
+      if (m != ~0ull) break;
+    }
+    for (uint32_t base = 0;; base += 64) {  // upwards: src+1, src+2, ...
+      const uint64_t u = (uint64_t)op.src + 1ull + base + (uint64_t)lane;
+      bool in = false;
+      if (u < g.n) in = v.nodes[u].beginning <= hi;
+      const uint64_t m = wv::ballot(in);
+      up += (uint32_t)wv::popc64(m);
+      if (m != ~0ull) break;
+    }
+    mv_lo = op.src + 1u - down;
+    mv_hi = op.src + up;
+    // the element at the first slot of the rebalance window keeps its slot (PCSR.cpp:240: "already in the correct
+    // position"); a sentinel sitting there does not move unless the insert/slide displaces it
+    if (mv_lo <= mv_hi && v.nodes[mv_lo].beginning == wstart && (kind == K_REMOVE || index > wstart)) mv_lo++;
+  }
   if (lane == 0) {
+    plan->mv_lo = mv_lo;
+    plan->mv_hi = mv_hi;
+    plan->sleaf_b = sleaf_b;
+    plan->sleaf_e = sleaf_e;
     plan->kind = kind;
     plan->index = index;
     plan->gap = gap;

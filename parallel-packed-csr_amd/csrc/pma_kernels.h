@@ -66,6 +66,8 @@ PMA_KERNEL void k_plan(RoundArgs a) {
     const unsigned long long key = make_key(a.round, idx);
     const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
     for (uint32_t leaf = wl + (uint32_t)wv::lane(); leaf <= wh; leaf += 64) wv::atomic_min_u64(&a.v.wres[leaf], key);
+    const uint32_t ml = pl->mv_lo, mh = pl->mv_hi;  // sentinels this update may move
+    for (uint64_t u = (uint64_t)ml + (uint64_t)wv::lane(); u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_min_u64(&a.v.vw[u], key);
   }
 }
 
@@ -91,6 +93,17 @@ PMA_KERNEL void k_check(RoundArgs a) {
     const unsigned long long k = a.v.wres[leaf];
     if ((uint32_t)(k >> 32) == tag && (uint32_t)k < idx) fail = true;  // an earlier update writes what we read
   });
+  if (kind != K_NOOP) {  // nodes[src].beginning / .end: an earlier update moves sentinel src or src+1
+    const uint32_t src = a.ops[idx].src;
+    if (src < a.v.g.n) {
+      const unsigned long long k0 = a.v.vw[src];
+      if ((uint32_t)(k0 >> 32) == tag && (uint32_t)k0 < idx) fail = true;
+      if (src + 1u < a.v.g.n) {
+        const unsigned long long k1 = a.v.vw[src + 1u];
+        if ((uint32_t)(k1 >> 32) == tag && (uint32_t)k1 < idx) fail = true;
+      }
+    }
+  }
   if (wv::ballot(fail) != 0 && wv::lane() == 0 && idx < c->failmin[par]) wv::atomic_min_u32(&c->failmin[par], idx);
 }
 
@@ -739,6 +752,7 @@ struct OptArgs {
   unsigned long long *regfail;
   unsigned long long *pfail;  // per-leaf: smallest deferred update whose footprint may still grow over this leaf
   uint32_t *wstamp, *rstamp;
+  uint32_t *vws, *vrs;  // per vertex: 1 + latest committed update that moved / read the position of its sentinel
   uint32_t round;
   int regshift;
 };
@@ -777,8 +791,14 @@ PMA_KERNEL void o_plan(OptArgs a) {
     // an update whose window is already within two levels of the exclusive threshold is likely to turn exclusive
     // once the earlier updates have landed: nothing later may overtake it (soft barrier)
     if (pl->wlen >= kBigWindow / 4 && lane == 0) wv::atomic_min_u64(&c->gbar[par], key + 1ull);
+    const uint32_t ml = pl->mv_lo, mh = pl->mv_hi;
+    for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_min_u64(&a.v.vw[u], key);
   }
   PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, wv::atomic_min_u64(&a.v.rres[leaf], key));
+  if (kind != K_NOOP && op.src < a.v.g.n) {  // readers of the positions of sentinels src and src+1
+    if (lane == 0) wv::atomic_min_u64(&a.v.vr[op.src], key);
+    if (lane == 1 && op.src + 1u < a.v.g.n) wv::atomic_min_u64(&a.v.vr[op.src + 1u], key);
+  }
 }
 
 PMA_KERNEL void o_check(OptArgs a) {
@@ -820,6 +840,31 @@ PMA_KERNEL void o_check(OptArgs a) {
       a.vdbg[4 * wid + 2] = 3u;
     }
   });
+  if (kind != K_NOOP) {
+    const uint32_t src = a.ops[idx].src;
+    if (src < a.v.g.n && lane < 2 && src + (uint32_t)lane < a.v.g.n) {  // lane 0: sentinel src, lane 1: sentinel src+1
+      const uint32_t u = src + (uint32_t)lane;
+      if (key_earlier(a.v.vw[u], tag, idx)) fail = true;  // an earlier pending update moves a sentinel we located by
+      if (a.vws[u] > me1) {                                // a LATER update already moved it
+        stamp_bad = true;
+        a.vdbg[4 * wid + 0] = u;
+        a.vdbg[4 * wid + 1] = a.vws[u];
+        a.vdbg[4 * wid + 2] = 4u;
+      }
+    }
+    if (writes) {
+      const uint32_t ml = pl->mv_lo, mh = pl->mv_hi;
+      for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) {
+        if (key_earlier(a.v.vr[u], tag, idx)) fail = true;  // an earlier pending update still needs the old position
+        if (a.vrs[u] > me1 || a.vws[u] > me1) {              // a LATER update already used / moved it
+          stamp_bad = true;
+          a.vdbg[4 * wid + 0] = (uint32_t)u;
+          a.vdbg[4 * wid + 1] = a.vrs[u] > me1 ? a.vrs[u] : a.vws[u];
+          a.vdbg[4 * wid + 2] = 5u;
+        }
+      }
+    }
+  }
   const bool anyfail = wv::ballot(fail) != 0;
   const bool anybad = wv::ballot(stamp_bad) != 0;
   uint32_t glo, ghi;
@@ -884,6 +929,9 @@ PMA_KERNEL void o_apply(OptArgs a) {
       if (key_earlier(a.regfail[g], tag, idx)) blocked = true;
     // ... nor may we have READ a leaf an earlier deferred update may still grow over
     PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, { if (key_earlier(a.pfail[leaf], tag, idx)) blocked = true; });
+    // ... nor located our range by a sentinel inside the block a deferred earlier update may still grow over
+    if (lane == 0 && key_earlier(a.pfail[pl->sleaf_b], tag, idx)) blocked = true;
+    if (lane == 1 && key_earlier(a.pfail[pl->sleaf_e], tag, idx)) blocked = true;
     if (wv::ballot(blocked) != 0) return;  // an earlier update of this region was deferred: keep stream order inside it
   }
   if (st & OS_STAMP_BAD) {
@@ -916,6 +964,13 @@ PMA_KERNEL void o_apply(OptArgs a) {
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_max_u32(&a.wstamp[leaf], me1);
   }
   PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, wv::atomic_max_u32(&a.rstamp[leaf], me1));
+  if (kind != K_NOOP && op.src < a.v.g.n) {
+    if (lane < 2 && op.src + (uint32_t)lane < a.v.g.n) wv::atomic_max_u32(&a.vrs[op.src + (uint32_t)lane], me1);
+    if (writes) {
+      const uint32_t ml = pl->mv_lo, mh = pl->mv_hi;
+      for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_max_u32(&a.vws[u], me1);
+    }
+  }
   if (lane == 0) a.status[wid] = OS_COMMITTED;  // (the epoch's max committed index is reduced in o_compact: a
                                                 // per-update atomicMax on one word would serialise the whole round)
 }

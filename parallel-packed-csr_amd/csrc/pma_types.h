@@ -70,6 +70,11 @@ struct Plan {
   uint32_t gap;               // first null slot at or right of index (== index if items[index] is null)
   uint32_t wstart, wlen;      // the single window rebalance that the op performs
   uint32_t wleaf_lo, wleaf_hi;  // inclusive leaf range written (slide + window)
+  // sentinel dependencies, tracked per VERTEX instead of through the leaf that happens to hold the sentinel:
+  // the update reads the positions of sentinels `src` and `src+1` (nodes[src].beginning / .end) and may move the
+  // sentinels of vertices [mv_lo, mv_hi] (those inside its slide range / rebalance window; empty if mv_lo > mv_hi)
+  uint32_t mv_lo, mv_hi;
+  uint32_t sleaf_b, sleaf_e;  // leaves currently holding sentinel src / src+1 (growth-zone check of deferred writers)
   uint32_t alg_calls, alg_slots;  // redistribute() calls / slots the reference performs for this op
   uint32_t nr;
   uint32_t nlong;  // number of read ranges spanning >= kLongRange leaves (0 for almost every update)
