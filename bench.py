@@ -141,6 +141,8 @@ def main():
         """bucket by owner + all-to-all (N > 1), then apply in stream order on this rank's partition"""
         if P > 1:
             mine = exch.exchange_ops(ops_dev, n_global, P, dist.group.WORLD)
+            # the exchange ran on torch's stream; the engine applies on its own HIP stream
+            torch.cuda.current_stream().synchronize()
         else:
             mine = ops_dev
         if mine.shape[0]:

@@ -94,6 +94,7 @@ static int reset_tags(Engine::Impl &p) {
   int e;
   if (p.v.wres && (e = gpu::dset(p.v.wres, 0xFF, leaves * sizeof(unsigned long long), p.stream))) return e;
   if (p.v.rres && (e = gpu::dset(p.v.rres, 0xFF, leaves * sizeof(unsigned long long), p.stream))) return e;
+  if (p.v.dres && (e = gpu::dset(p.v.dres, 0xFF, leaves * sizeof(unsigned long long), p.stream))) return e;
   if (p.d_regfail && (e = gpu::dset(p.d_regfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream))) return e;
   if (p.d_pfail && (e = gpu::dset(p.d_pfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream))) return e;
   if (p.v.vw && (e = gpu::dset(p.v.vw, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
@@ -108,6 +109,8 @@ static int alloc_aux(Engine::Impl &p, View &v) {
   int e;
   if ((e = gpu::dmalloc((void **)&v.wres, leaves * sizeof(unsigned long long)))) return e;
   if ((e = gpu::dmalloc((void **)&v.rres, leaves * sizeof(unsigned long long)))) return e;
+  if ((e = gpu::dmalloc((void **)&v.dres, leaves * sizeof(unsigned long long)))) return e;
+  if ((e = gpu::dset(v.dres, 0xFF, leaves * sizeof(unsigned long long), p.stream))) return e;
   if ((e = gpu::dmalloc((void **)&p.d_wstamp, leaves * sizeof(uint32_t)))) return e;
   if ((e = gpu::dmalloc((void **)&p.d_rstamp, leaves * sizeof(uint32_t)))) return e;
   if ((e = gpu::dmalloc((void **)&p.d_regfail, (leaves + 1) * sizeof(unsigned long long)))) return e;
@@ -147,6 +150,8 @@ static int alloc_vertex_aux(Engine::Impl &p, View &v) {
 static void free_aux(Engine::Impl &p, View &v) {
   GPU_DFREE(v.wres);
   GPU_DFREE(v.rres);
+  GPU_DFREE(v.dres);
+  v.dres = nullptr;
   GPU_DFREE(p.d_wstamp);
   GPU_DFREE(p.d_rstamp);
   GPU_DFREE(p.d_regfail);

@@ -24,6 +24,7 @@ struct View {
   uint32_t *leafcnt;
   unsigned long long *wres;  // per-leaf write reservation key of the current round
   unsigned long long *rres;  // per-leaf read reservation key (optimistic mode)
+  unsigned long long *dres;  // per-leaf: earliest pending DUPLICATE update (overwrites one slot's value, moves nothing)
   unsigned long long *vw;    // per-vertex: earliest pending update that may MOVE this vertex's sentinel
   unsigned long long *vr;    // per-vertex: earliest pending update that READS this sentinel's position
   Geometry g;

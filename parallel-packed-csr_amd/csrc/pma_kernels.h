@@ -47,6 +47,10 @@ PMA_DEV unsigned long long make_key(uint32_t round, uint32_t idx) {
   return ((unsigned long long)(0xFFFFFFFFu - round) << 32) | (unsigned long long)idx;
 }
 PMA_DEV bool kind_writes(uint32_t k) { return k == K_INSERT || k == K_DUP || k == K_REMOVE; }
+// A duplicate insert (K_DUP, PCSR.cpp:529-532) only overwrites the `value` of one existing slot: searches test
+// value != 0 and compare `dest`, neither of which changes, so it conflicts with updates that MOVE or rewrite slots of
+// that leaf (same round only; across rounds they commute) but never with readers.  Strong writers move slots.
+PMA_DEV bool kind_strong(uint32_t k) { return k == K_INSERT || k == K_REMOVE; }
 
 PMA_KERNEL void k_plan(RoundArgs a) {
   Control *c = a.ctl;
@@ -62,7 +66,9 @@ PMA_KERNEL void k_plan(RoundArgs a) {
   dev::plan_op(a.v, op, pl);
   wv::fence();
   const uint32_t kind = pl->kind;
-  if (kind_writes(kind)) {
+  if (kind == K_DUP) {
+    if (wv::lane() == 0) wv::atomic_min_u64(&a.v.dres[pl->wleaf_lo], make_key(a.round, idx));
+  } else if (kind_strong(kind)) {
     const unsigned long long key = make_key(a.round, idx);
     const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
     for (uint32_t leaf = wl + (uint32_t)wv::lane(); leaf <= wh; leaf += 64) wv::atomic_min_u64(&a.v.wres[leaf], key);
@@ -84,10 +90,18 @@ PMA_KERNEL void k_check(RoundArgs a) {
   const unsigned long long key = make_key(a.round, idx);
   const uint32_t tag = (uint32_t)(key >> 32);
   bool fail = (kind == K_EXCL);
-  if (kind_writes(kind)) {
+  if (kind == K_DUP) {
+    const uint32_t leaf = pl->wleaf_lo;
+    const unsigned long long kw = a.v.wres[leaf];
+    if ((uint32_t)(kw >> 32) == tag && (uint32_t)kw < idx) fail = true;  // an earlier update moves slots of this leaf
+    if (a.v.dres[leaf] != key) fail = true;                               // an earlier duplicate on this leaf
+  } else if (kind_strong(kind)) {
     const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
-    for (uint32_t leaf = wl + (uint32_t)wv::lane(); leaf <= wh; leaf += 64)
+    for (uint32_t leaf = wl + (uint32_t)wv::lane(); leaf <= wh; leaf += 64) {
       if (a.v.wres[leaf] != key) fail = true;  // an earlier update writes this leaf
+      const unsigned long long kd = a.v.dres[leaf];
+      if ((uint32_t)(kd >> 32) == tag && (uint32_t)kd < idx) fail = true;  // an earlier duplicate overwrites a slot here
+    }
   }
   PMA_FOR_EACH_READ_LEAF(pl, wv::lane(), leaf, {
     const unsigned long long k = a.v.wres[leaf];
@@ -445,51 +459,9 @@ PMA_KERNEL void k_scan_apply(const uint32_t *cnt, uint64_t nleaves, const uint32
   }
 }
 
-PMA_KERNEL void k_chain_table(uint64_t index, uint64_t len, const unsigned long long *j, ChainTable *tb) {
-  if (wv::block_idx() == 0 && wv::thread_idx() == 0) build_chain_table(index, len, (uint64_t)*j, tb);
-}
-
-// Rebalance scatter: every live element of src window [src_lo, src_lo+src_len) goes to
-// dst[pos_k - dst_bias] where k = its rank among the live elements (rank[] = exclusive leaf prefix).
-// `v` carries the NEW geometry (n, N) for the sentinel back-pointers.
-PMA_KERNEL void k_scatter(View v, const Edge *src, uint64_t src_lo, uint64_t src_len, int src_sh, const uint32_t *rank,
-                          const ChainTable *tb, Edge *dst, uint64_t dst_bias) {
-  PMA_SHARED ChainTable stb;
-  {
-    const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
-    uint32_t *s = reinterpret_cast<uint32_t *>(&stb);
-    for (uint32_t i = wv::thread_idx(); i < sizeof(ChainTable) / 4; i += wv::block_dim()) s[i] = g[i];
-  }
-  wv::block_sync();
-  const int lane = wv::lane();
-  const uint32_t slogN = 1u << src_sh;
-  const uint64_t nchunks = (src_len + 63) / 64;
-  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
-  int hint = 0;
-  for (uint64_t ch = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); ch < nchunks; ch += wstride) {
-    const uint64_t off = ch * 64 + (uint64_t)lane;
-    Edge e = null_edge();
-    if (off < src_len) e = src[src_lo + off];
-    const bool nn = e.value != 0;
-    const uint64_t m = wv::ballot(nn);
-    if (nn) {
-      const uint64_t lleaf = off >> src_sh;  // leaf index inside the window
-      uint64_t lmask;
-      if (slogN >= 64) {
-        lmask = ~0ull;
-      } else {
-        const uint32_t first = (uint32_t)(lane & ~(int)(slogN - 1));
-        lmask = ((1ull << slogN) - 1ull) << first;
-      }
-      const uint64_t k = (uint64_t)rank[lleaf] + (uint64_t)wv::popc64(m & lmask & ((1ull << lane) - 1ull));
-      const uint64_t pos = chain_pos(&stb, k, &hint);
-      dst[pos - dst_bias] = e;
-      dev::fix_sentinel(v, e, (uint32_t)pos);
-    }
-  }
-}
-
-// Fused rebalance scatter: like k_scatter, but every wave also writes the null slots that follow its elements
+// Fused rebalance scatter: every live element of src window [src_lo, src_lo+src_len) goes to dst[pos_k - dst_bias]
+// where k = its rank among the live elements (rank[] = exclusive leaf prefix) and pos_k comes from the exact chain
+// table; `v` carries the NEW geometry (n, N) for the sentinel back-pointers.  Every wave also writes the null slots that follow its elements
 // (element k owns output slots [pos_k, pos_{k+1})), so the destination needs no separate fill pass, every output slot
 // is written exactly once, and the wave's output stretch is staged in LDS and stored as one coalesced run.
 // Leaf counts of the destination are accumulated with one atomicAdd per element (dst leafcnt must be zeroed first).
@@ -633,25 +605,6 @@ PMA_KERNEL void k_neighbourhood(View v, uint32_t src, int *outbuf, uint64_t cap,
   if (lane == 0) *count = run;
 }
 
-// bulk neighbour scan (CSR export): pass 1 counts live edges per 64-slot chunk (slot N-1 is never part of a
-// neighbourhood: the last vertex's end is N-1 exclusive), pass 2 (after an exclusive scan of the chunk counts)
-// writes dests in array order == CSR order and row offsets at the sentinels.
-PMA_KERNEL void k_scan_count(View v, uint32_t *chunkcnt) {
-  const int lane = wv::lane();
-  const uint64_t N = v.g.N;
-  const uint64_t nchunks = (N + 63) / 64;
-  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
-  for (uint64_t ch = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); ch < nchunks; ch += wstride) {
-    const uint64_t s = ch * 64 + (uint64_t)lane;
-    bool live = false;
-    if (s + 1 < N) {
-      const Edge e = v.items[s];
-      live = e.value != 0 && !is_sentinel(e);
-    }
-    const uint64_t m = wv::ballot(live);
-    if (lane == 0) chunkcnt[ch] = (uint32_t)wv::popc64(m);
-  }
-}
 // live edges per 64-slot chunk WITHOUT reading the edge array: leaf counts minus the sentinels that sit in the chunk
 // (one atomic per vertex on a 4 B/chunk histogram), minus slot N-1 which is never part of a neighbourhood
 PMA_KERNEL void k_chunk_sentinels(View v, uint32_t *chunk_sent) {
@@ -689,6 +642,9 @@ PMA_KERNEL void k_chunk_counts(View v, const uint32_t *chunk_sent, uint32_t *chu
     chunkcnt[ch] = c;
   }
 }
+// bulk neighbour scan (CSR export), final streaming pass: after the exclusive scan of the per-chunk live-edge counts
+// (k_chunk_sentinels / k_chunk_counts below + the rank scan) write dests in array order == CSR order and the row
+// offsets at the sentinels.  Slot N-1 is never part of a neighbourhood (the last vertex's end is N-1, exclusive).
 PMA_KERNEL void k_scan_write(View v, const uint32_t *chunkoff, unsigned long long *row_offsets, int *dests, uint64_t cap) {
   const int lane = wv::lane();
   const uint64_t N = v.g.N;
@@ -785,7 +741,9 @@ PMA_KERNEL void o_plan(OptArgs a) {
     if (lane == 0) wv::atomic_min_u64(&c->gbar[par], key);
     return;
   }
-  if (kind_writes(kind)) {
+  if (kind == K_DUP) {
+    if (lane == 0) wv::atomic_min_u64(&a.v.dres[pl->wleaf_lo], key);
+  } else if (kind_strong(kind)) {
     const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_min_u64(&a.v.wres[leaf], key);
     // an update whose window is already within two levels of the exclusive threshold is likely to turn exclusive
@@ -818,10 +776,17 @@ PMA_KERNEL void o_check(OptArgs a) {
   bool stamp_bad = false;
   const uint32_t me1 = idx + 1u;  // stamps hold (index + 1) of the latest committed toucher
   const bool writes = kind_writes(kind);
-  if (writes) {
+  const bool strong = kind_strong(kind);
+  if (kind == K_DUP) {
+    const uint32_t leaf = pl->wleaf_lo;
+    if (key_earlier(a.v.wres[leaf], tag, idx)) fail = true;  // an earlier pending update moves slots of this leaf
+    if (a.v.dres[leaf] != key) fail = true;                   // an earlier pending duplicate on this leaf
+  }
+  if (strong) {
     const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) {
       if (a.v.wres[leaf] != key) fail = true;                   // an earlier pending update writes it
+      if (key_earlier(a.v.dres[leaf], tag, idx)) fail = true;   // an earlier pending duplicate overwrites a slot here
       if (key_earlier(a.v.rres[leaf], tag, idx)) fail = true;   // an earlier pending update reads it
       if (a.wstamp[leaf] > me1 || a.rstamp[leaf] > me1) {  // a LATER update already touched it
         stamp_bad = true;
@@ -852,7 +817,7 @@ PMA_KERNEL void o_check(OptArgs a) {
         a.vdbg[4 * wid + 2] = 4u;
       }
     }
-    if (writes) {
+    if (strong) {
       const uint32_t ml = pl->mv_lo, mh = pl->mv_hi;
       for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) {
         if (key_earlier(a.v.vr[u], tag, idx)) fail = true;  // an earlier pending update still needs the old position
@@ -959,14 +924,14 @@ PMA_KERNEL void o_apply(OptArgs a) {
 #endif
   dev::apply_op(a.v, op, pl, lds[wv::wave_in_block()], &a.stats[wv::block_idx() & (kStatShards - 1)]);
   const uint32_t me1 = idx + 1u;
-  if (writes) {
+  if (kind_strong(kind)) {  // (a duplicate's value overwrite commutes with everything it can be reordered with: no stamp)
     const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_max_u32(&a.wstamp[leaf], me1);
   }
   PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, wv::atomic_max_u32(&a.rstamp[leaf], me1));
   if (kind != K_NOOP && op.src < a.v.g.n) {
     if (lane < 2 && op.src + (uint32_t)lane < a.v.g.n) wv::atomic_max_u32(&a.vrs[op.src + (uint32_t)lane], me1);
-    if (writes) {
+    if (kind_strong(kind)) {
       const uint32_t ml = pl->mv_lo, mh = pl->mv_hi;
       for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_max_u32(&a.vws[u], me1);
     }
