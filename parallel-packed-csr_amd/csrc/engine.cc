@@ -79,7 +79,8 @@ struct Engine::Impl {
   uint32_t mode = 1;             // 0 = strict prefix rounds, 1 = speculative rounds with validated rollback
   uint32_t epoch_ops = 1u << 20;  // rollback granularity
   uint32_t region_slots = 4096;  // per-region prefix rule (>= kBigWindow so a window never leaves its region)
-  uint32_t opt_horizon = 4096;   // rounds are bound by dependency chains, not by width: a wider horizon only re-plans more
+  uint32_t opt_horizon = 16384;  // upper bound of the adaptive round width (OptCtl::cur_horizon)
+  uint32_t start_horizon = 4096;
   bool carry_dumped = false;
   bool partial = false;
   bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
@@ -349,6 +350,12 @@ int Engine::set_option(const char *key, int64_t value) {
   if (k == "opt_horizon") {
     if (value < 1 || value > (1 << 20)) return fail(PPCSR_EINVAL, "opt_horizon out of range");
     p.opt_horizon = (uint32_t)value;
+    p.start_horizon = std::min<uint32_t>(p.start_horizon, p.opt_horizon);
+    return PPCSR_OK;
+  }
+  if (k == "start_horizon") {
+    if (value < 1 || value > (1 << 20)) return fail(PPCSR_EINVAL, "start_horizon out of range");
+    p.start_horizon = (uint32_t)value;
     return PPCSR_OK;
   }
   if (k == "profile") {
@@ -537,7 +544,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     const uint32_t par = (p.round + 1) & 1u;
     c.carry_n[0] = c.carry_n[1] = 0;
     c.next_fresh[0] = c.next_fresh[1] = (uint32_t)e0;
-    c.hor[par] = (uint32_t)std::min<uint64_t>(p.opt_horizon, e1 - e0);
+    c.cur_horizon = std::min(p.start_horizon, p.opt_horizon);
+    c.hor[par] = (uint32_t)std::min<uint64_t>(c.cur_horizon, e1 - e0);
     c.e1 = (uint32_t)e1;
     c.max_horizon = p.opt_horizon;
     c.gbar[0] = c.gbar[1] = ~0ull;
@@ -663,6 +671,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         e0 = e1;
         retries = 0;
         epoch_open = false;
+        if (c.cur_horizon) p.start_horizon = c.cur_horizon;  // keep the adapted width for the next epoch
       } else {
         if (const char *tc = getenv("PPCSR_TRACE_CARRY")) {  // debug: who is stuck?  histogram of src over the carry list
           const uint32_t cn = c.carry_n[npar];
