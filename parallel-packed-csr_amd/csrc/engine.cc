@@ -79,8 +79,10 @@ struct Engine::Impl {
   uint32_t mode = 1;             // 0 = strict prefix rounds, 1 = speculative rounds with validated rollback
   uint32_t epoch_ops = 1u << 20;  // rollback granularity
   uint32_t region_slots = 4096;  // per-region prefix rule (>= kBigWindow so a window never leaves its region)
-  uint32_t opt_horizon = 16384;  // upper bound of the adaptive round width (OptCtl::cur_horizon)
-  uint32_t start_horizon = 4096;
+  uint32_t opt_horizon = 6144;  // round width (upper bound when `adaptive` is on); dependency chains bound the number
+                                // of rounds, so a wider horizon mostly re-plans more: 6144 measured best on config #2
+  uint32_t start_horizon = 6144;
+  uint32_t adaptive = 0;
   bool carry_dumped = false;
   bool partial = false;
   bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
@@ -351,6 +353,11 @@ int Engine::set_option(const char *key, int64_t value) {
     if (value < 1 || value > (1 << 20)) return fail(PPCSR_EINVAL, "opt_horizon out of range");
     p.opt_horizon = (uint32_t)value;
     p.start_horizon = std::min<uint32_t>(p.start_horizon, p.opt_horizon);
+    if (!p.adaptive) p.start_horizon = p.opt_horizon;
+    return PPCSR_OK;
+  }
+  if (k == "adaptive") {
+    p.adaptive = value != 0;
     return PPCSR_OK;
   }
   if (k == "start_horizon") {
@@ -544,7 +551,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     const uint32_t par = (p.round + 1) & 1u;
     c.carry_n[0] = c.carry_n[1] = 0;
     c.next_fresh[0] = c.next_fresh[1] = (uint32_t)e0;
-    c.cur_horizon = std::min(p.start_horizon, p.opt_horizon);
+    c.adaptive = p.adaptive;
+    c.cur_horizon = p.adaptive ? std::min(p.start_horizon, p.opt_horizon) : p.opt_horizon;
     c.hor[par] = (uint32_t)std::min<uint64_t>(c.cur_horizon, e1 - e0);
     c.e1 = (uint32_t)e1;
     c.max_horizon = p.opt_horizon;

@@ -692,6 +692,7 @@ struct OptCtl {
   uint32_t max_horizon, excl_idx;
   uint32_t maxc;  // 1 + largest stream index committed in this epoch
   uint32_t viol_idx;  // smallest stream index whose commit-time validation failed
+  uint32_t adaptive;     // 1: adapt cur_horizon (experimental; a fixed width of 6144 measured best on config #2)
   uint32_t cur_horizon;  // adaptive round width (<= max_horizon): grows while most of the round commits, shrinks otherwise
   unsigned long long gbar[2];  // keyed min index of a K_EXCL update in the horizon
   unsigned long long rounds, committed, planned, blocked, failed;
@@ -997,9 +998,9 @@ PMA_KERNEL void o_compact(OptArgs a) {
     // adaptive width: dependency chains bound the number of rounds, so planning far more updates than can commit only
     // makes every round slower; widen by 1/8 when > 85 % of the round committed, narrow by 1/8 when < 65 % did
     uint32_t ch = c->cur_horizon ? c->cur_horizon : c->max_horizon;
-    if (hor >= ch) {  // only full-width rounds carry information about the width
-      if (ncommitted * 100u > hor * 85u) ch += ch / 8u;
-      else if (ncommitted * 100u < hor * 65u) ch -= ch / 8u;
+    if (c->adaptive && hor >= ch) {  // only full-width rounds carry information about the width
+      if (ncommitted * 100u > hor * 92u) ch += ch / 16u;
+      else if (ncommitted * 100u < hor * 80u) ch -= ch / 16u;
     }
     if (ch < 1024u) ch = 1024u;
     if (ch > c->max_horizon) ch = c->max_horizon;
