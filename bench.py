@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--max-horizon", type=int, default=0)
     ap.add_argument("--rounds-per-sync", type=int, default=0)
     ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (slow)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' only for functional tests of the N > 1 path on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -91,11 +92,13 @@ def main():
         raise SystemExit(f"--gpus {P} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {P}")
     if not torch.cuda.is_available():
         raise SystemExit("no GPU: the engine is HIP-only (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_id = local_rank % max(ndev, 1)  # (one rank per GPU in real runs; ranks share a GPU only in the gloo functional test)
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
     if P > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     pkg = _load("ppcsr_amd", os.path.join(ROOT, "parallel-packed-csr_amd", "__init__.py"), pkg=True)
     streams = _load("ppcsr_streams", os.path.join(ROOT, "parallel-packed-csr_amd", "streams.py"))
@@ -120,7 +123,7 @@ def main():
     log(rank, f"generated core {len(core_blk)} + {nsteps} x {args.batch} updates per rank in {time.time() - t0:.1f}s "
               f"(n_global={n_global}, labels={'permuted' if permute else 'raw'})")
 
-    eng = pkg.PCSR(my_n, device=local_rank)
+    eng = pkg.PCSR(my_n, device=dev_id)
     if args.mode >= 0:
         eng.set_option("mode", args.mode)
     if args.opt_horizon:
@@ -134,15 +137,20 @@ def main():
     if args.rounds_per_sync:
         eng.set_option("rounds_per_sync", args.rounds_per_sync)
 
+    xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the exchange runs
+
     def to_dev(a):
-        return torch.from_numpy(a.view(np.int32)).to(dev)
+        return torch.from_numpy(a.view(np.int32)).to(xdev if P > 1 else dev)
+
+    keep_alive = []  # device tensors handed to the engine must outlive the (asynchronous) apply
 
     def run_step(ops_dev):
         """bucket by owner + all-to-all (N > 1), then apply in stream order on this rank's partition"""
         if P > 1:
-            mine = exch.exchange_ops(ops_dev, n_global, P, dist.group.WORLD)
+            mine = exch.exchange_ops(ops_dev, n_global, P, dist.group.WORLD).to(dev)
             # the exchange ran on torch's stream; the engine applies on its own HIP stream
             torch.cuda.current_stream().synchronize()
+            keep_alive.append(mine)
         else:
             mine = ops_dev
         if mine.shape[0]:
@@ -183,7 +191,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     s1 = eng.stats()
     if P > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_updates = args.batch * P * args.steps
@@ -313,6 +321,35 @@ def main():
         except Exception as e:  # never let a secondary measurement kill the headline
             extra["secondary_error"] = str(e)
 
+    if P > 1 and args.check:
+        # tier-A parity per partition: this rank's partition must equal the oracle fed with the partition's subsequence
+        # of the GLOBAL stream (block r of every batch is regenerated from its counters)
+        from oracle_lib import Oracle
+        o = Oracle(my_n)
+
+        def mine_of(kind_, count, seed, mixed_seed=0, corefor=None):
+            parts = []
+            for r in range(P):
+                cb = None
+                if kind_ == "mixed":
+                    cb = gen_block(streams, "insert", gscale, args.core_edges, 1, r * args.core_edges, n_global, permute)
+                parts.append(gen_block(streams, kind_, gscale, count, seed, r * count, n_global, permute, core=cb, mixed_seed=mixed_seed))
+            g = np.concatenate(parts)
+            ps = n_global // P
+            own = np.minimum(g[:, 0].astype(np.int64) // ps, P - 1)
+            sub = g[own == rank].copy()
+            sub[:, 0] -= np.uint32(starts[rank])
+            return sub
+        o.apply(mine_of("insert", args.core_edges, 1))
+        k = args.warmup + args.steps - 1
+        o.apply(mine_of(kind, args.batch, 2 + 10 * k, mixed_seed=3 + 10 * k))
+        ei, en = eng.state()
+        oi, on = o.state()
+        okp = eng.geometry() == o.geometry() and np.array_equal(ei, oi) and np.array_equal(en, on)
+        t = torch.tensor([1 if okp else 0], dtype=torch.int64, device=xdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        extra["parity_checked_all_partitions"] = bool(t.item())
+        assert t.item() == 1, "PARITY FAILURE on some partition"
     if rank == 0:
         out = {
             "metric": "edge-updates/sec", "value": value, "unit": "edge-updates/s", "n_gpus": P, "steps": args.steps,
