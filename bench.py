@@ -302,25 +302,6 @@ def main():
             except Exception as e:
                 extra["cpu_reference_cli_error"] = str(e)
 
-    # ---- secondary kernels: bulk neighbour scan + whole-window rebalance (HBM-roofline kernels, SURVEY §8d) ----
-    if rank == 0:
-        try:
-            ms, tot = eng.bench_scan_all()
-            ms, tot = eng.bench_scan_all()
-            stt = eng.stats()
-            scan_bytes = 12.0 * stt["N"] + 12.0 * stt["n"] + 4.0 * tot
-            extra["neighbour_scan"] = {"edges_per_s": tot / (ms * 1e-3), "ms": ms, "edges": int(tot),
-                                       "alg_GBps": scan_bytes / (ms * 1e-3) / 1e9,
-                                       "frac_of_peak": scan_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            for label, w in (("window_rebalance", int(stt["N"])), ("window_rebalance_half", int(stt["N"]) // 2)):
-                rms = eng.bench_rebalance(w, 5)
-                extra[label] = {"window_slots": w, "ms_per_call": rms, "alg_GBps": 24.0 * w / (rms * 1e-3) / 1e9,
-                                "frac_of_peak": 24.0 * w / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "note": "device time (HIP events) of rank scan + position table + fused scatter/fill"
-                                        + ("" if w == int(stt["N"]) else " + copy-back")}
-        except Exception as e:  # never let a secondary measurement kill the headline
-            extra["secondary_error"] = str(e)
-
     if P > 1 and args.check:
         # tier-A parity per partition: this rank's partition must equal the oracle fed with the partition's subsequence
         # of the GLOBAL stream (block r of every batch is regenerated from its counters)
@@ -350,6 +331,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         extra["parity_checked_all_partitions"] = bool(t.item())
         assert t.item() == 1, "PARITY FAILURE on some partition"
+    # ---- secondary kernels: bulk neighbour scan + whole-window rebalance (HBM-roofline kernels, SURVEY §8d) ----
+    if rank == 0:
+        try:
+            ms, tot = eng.bench_scan_all()
+            ms, tot = eng.bench_scan_all()
+            stt = eng.stats()
+            scan_bytes = 12.0 * stt["N"] + 12.0 * stt["n"] + 4.0 * tot
+            extra["neighbour_scan"] = {"edges_per_s": tot / (ms * 1e-3), "ms": ms, "edges": int(tot),
+                                       "alg_GBps": scan_bytes / (ms * 1e-3) / 1e9,
+                                       "frac_of_peak": scan_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            for label, w in (("window_rebalance", int(stt["N"])), ("window_rebalance_half", int(stt["N"]) // 2)):
+                rms = eng.bench_rebalance(w, 5)
+                extra[label] = {"window_slots": w, "ms_per_call": rms, "alg_GBps": 24.0 * w / (rms * 1e-3) / 1e9,
+                                "frac_of_peak": 24.0 * w / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "device time (HIP events) of rank scan + position table + fused scatter/fill"
+                                        + ("" if w == int(stt["N"]) else " + copy-back")}
+        except Exception as e:  # never let a secondary measurement kill the headline
+            extra["secondary_error"] = str(e)
+
     if rank == 0:
         out = {
             "metric": "edge-updates/sec", "value": value, "unit": "edge-updates/s", "n_gpus": P, "steps": args.steps,
