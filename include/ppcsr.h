@@ -133,6 +133,11 @@ int pppcsr_apply_batch(pppcsr_t h, const ppcsr_op *ops, uint64_t n);
 int pppcsr_bucket_ops(uint32_t init_n, uint64_t n_parts, const ppcsr_op *ops, uint64_t n, ppcsr_op *bucketed,
                       uint64_t *counts);
 
+/* the same routing for a block of the stream already resident in HBM (multi-GPU exchange): stable counting sort by
+ * owner on `stream` (a hipStream_t, may be NULL); d_counts[p] (device memory, n_parts <= 64 entries) receives the bucket sizes */
+int pppcsr_bucket_ops_device(uint32_t init_n, uint64_t n_parts, const ppcsr_op *d_ops, uint64_t n, ppcsr_op *d_bucketed,
+                             uint64_t *d_counts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,7 +43,7 @@ EXPORTED = [
     "ppcsr_last_error", "ppcsr_device_count", "pppcsr_create", "pppcsr_destroy", "pppcsr_num_partitions",
     "pppcsr_get_partition", "pppcsr_partition_start", "pppcsr_partition", "pppcsr_add_edge", "pppcsr_remove_edge",
     "pppcsr_edge_exists", "pppcsr_get_neighbourhood", "pppcsr_get_node", "pppcsr_get_n", "pppcsr_add_node",
-    "pppcsr_apply_batch", "pppcsr_bucket_ops",
+    "pppcsr_apply_batch", "pppcsr_bucket_ops", "pppcsr_bucket_ops_device",
 ]
 
 _LIBS = {}
@@ -98,6 +98,7 @@ def load_library(path=None):
     L.pppcsr_add_node.argtypes = [c_vp]
     L.pppcsr_apply_batch.argtypes = [c_vp, c_vp, c_u64]
     L.pppcsr_bucket_ops.argtypes = [c_u32, c_u64, c_vp, c_u64, c_vp, c_vp]
+    L.pppcsr_bucket_ops_device.argtypes = [c_u32, c_u64, c_vp, c_u64, c_vp, c_vp, c_vp]
     _LIBS[path] = L
     return L
 

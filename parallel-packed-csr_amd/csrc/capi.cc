@@ -262,6 +262,16 @@ int pppcsr_bucket_ops(uint32_t init_n, uint64_t n_parts, const ppcsr_op *ops, ui
   return 0;
 }
 
+int pppcsr_bucket_ops_device(uint32_t init_n, uint64_t n_parts, const ppcsr_op *d_ops, uint64_t n, ppcsr_op *d_bucketed,
+                             uint64_t *d_counts, void *stream) {
+  if (n_parts < 1 || n_parts > 64 || (!d_ops && n) || !d_bucketed || !d_counts) return bad("bad arguments");
+  std::string msg;
+  int rc = ppcsr::bucket_ops_device(init_n, (uint32_t)n_parts, reinterpret_cast<const ppcsr::Op *>(d_ops), n,
+                                    reinterpret_cast<ppcsr::Op *>(d_bucketed), reinterpret_cast<unsigned long long *>(d_counts), stream, &msg);
+  if (rc != 0) g_last_error = msg;
+  return rc;
+}
+
 int pppcsr_apply_batch(pppcsr_t h, const ppcsr_op *ops, uint64_t n) {
   PP_CHECK();
   const uint64_t P = h->parts.size();

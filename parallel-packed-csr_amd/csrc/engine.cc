@@ -1157,6 +1157,37 @@ int Engine::rebalance_bench(uint64_t wlen, int iters, double *ms_per_call) {
   return PPCSR_OK;
 }
 
+int bucket_ops_device(uint32_t init_n, uint32_t n_parts, const Op *d_ops, uint64_t n, Op *d_out, unsigned long long *d_counts,
+                      void *stream, std::string *errmsg) {
+  static thread_local uint32_t *d_hist = nullptr;  // per-thread scratch (one rank = one process = one device)
+  static thread_local uint64_t hist_cap = 0;
+  const uint64_t ntiles = (n + kBucketTile - 1) / kBucketTile;
+  const uint64_t need = std::max<uint64_t>(ntiles, 1) * n_parts;
+  gpu::stream_t st = gpu::stream_from_ptr(stream);
+  auto failm = [&](const char *what, int e) {
+    if (errmsg) *errmsg = std::string(what) + ": " + gpu::err_str(e);
+    return (int)PPCSR_EHIP;
+  };
+  if (hist_cap < need) {
+    if (d_hist) gpu::dfree(d_hist);
+    d_hist = nullptr;
+    hist_cap = 0;
+    int e = gpu::dmalloc((void **)&d_hist, need * sizeof(uint32_t));
+    if (e) return failm("hipMalloc", e);
+    hist_cap = need;
+  }
+  const uint32_t ps = init_n / n_parts;
+  if (n == 0) {
+    int e = gpu::dset(d_counts, 0, n_parts * sizeof(unsigned long long), st);
+    return e ? failm("hipMemsetAsync", e) : (int)PPCSR_OK;
+  }
+  GPU_LAUNCH(st, k_bucket_hist, ntiles, 256, d_ops, n, ps, n_parts, d_hist);
+  GPU_LAUNCH(st, k_bucket_scan, 1, 64, d_hist, ntiles, n_parts, d_counts);
+  GPU_LAUNCH(st, k_bucket_scatter, ntiles, 256, d_ops, n, ps, n_parts, (const uint32_t *)d_hist, d_out);
+  int e = gpu::last_error();
+  return e ? failm("bucket kernels", e) : (int)PPCSR_OK;
+}
+
 }  // namespace ppcsr
 
 int gpu_device_count_for_capi(int *n) { return gpu::device_count(n); }

@@ -83,6 +83,9 @@ class Engine {
 };
 
 const char *error_string(int code);
+// stable owner bucketing of a device-resident block of the stream (multi-GPU exchange); runs on `stream`
+int bucket_ops_device(uint32_t init_n, uint32_t n_parts, const Op *d_ops, uint64_t n, Op *d_out, unsigned long long *d_counts,
+                      void *stream, std::string *errmsg);
 }  // namespace ppcsr
 int gpu_device_count_for_capi(int *n);
 namespace ppcsr {

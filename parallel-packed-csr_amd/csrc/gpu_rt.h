@@ -17,6 +17,7 @@ inline const char *err_str(int) { return "sim error"; }
 inline int set_device(int) { return 0; }
 inline int device_count(int *n) { *n = 1; return 0; }
 inline int stream_create(stream_t *s) { *s = 0; return 0; }
+inline stream_t stream_from_ptr(void *) { return 0; }
 inline int stream_destroy(stream_t) { return 0; }
 inline int dmalloc(void **p, size_t b) { *p = ::malloc(b ? b : 1); return *p ? 0 : 2; }
 inline int dfree(void *p) { ::free(p); return 0; }
@@ -61,6 +62,7 @@ inline const char *err_str(int e) { return hipGetErrorString((hipError_t)e); }
 inline int set_device(int d) { return (int)hipSetDevice(d); }
 inline int device_count(int *n) { return (int)hipGetDeviceCount(n); }
 inline int stream_create(stream_t *s) { return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+inline stream_t stream_from_ptr(void *p) { return (stream_t)p; }
 inline int stream_destroy(stream_t s) { return dbg_report("hipStreamDestroy", (int)hipStreamDestroy(s)); }
 inline int dmalloc(void **p, size_t b) { return (int)hipMalloc(p, b ? b : 1); }
 inline int dfree(void *p) { return p ? dbg_report("hipFree", (int)hipFree(p)) : 0; }

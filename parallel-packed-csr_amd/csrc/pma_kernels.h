@@ -1130,4 +1130,113 @@ PMA_KERNEL void k_scan_onepass(View v, unsigned long long *tile_state, uint32_t 
   }
 }
 
+// ---- owner bucketing for the multi-GPU exchange (PPPCSR routing rule, PPPCSR.cpp:46-66) ----------------------------
+// Stable counting sort of a block of the update stream by owning partition, with `src` made partition-local.
+// Tile = 2048 updates per workgroup; (1) per-tile histogram, (2) one small scan (partition-major, tile-minor),
+// (3) scatter: rank inside the wave from ballots over the distinct owners present, inside the tile from an LDS
+// prefix over (row, wave), across tiles from the scan — so every bucket keeps stream order.
+constexpr uint32_t kBucketRows = 8;                          // rows of 256 updates per tile
+constexpr uint32_t kBucketTile = 256 * kBucketRows;
+constexpr uint32_t kMaxParts = 64;
+PMA_DEV uint32_t owner_of_src(uint32_t src, uint32_t part_size, uint32_t nparts) {
+  if (part_size == 0) return nparts - 1u;
+  const uint32_t o = src / part_size;
+  return o < nparts ? o : nparts - 1u;
+}
+// counts[w][p] for the 4 waves of one row; returns this lane's rank among same-owner lanes of its wave
+PMA_DEV uint32_t bucket_rank_in_wave(uint32_t owner, bool valid, uint32_t *wave_counts /* [kMaxParts] of this wave */) {
+  const int lane = wv::lane();
+  uint64_t remaining = wv::ballot(valid);
+  uint32_t myrank = 0;
+  while (remaining) {
+    const int l0 = wv::ctz64(remaining);
+    const uint32_t p0 = wv::shfl(owner, l0);
+    const uint64_t m = wv::ballot(valid && owner == p0);
+    if (valid && owner == p0) myrank = dev::lanemask_lt_count(m, lane);
+    if (lane == 0) wave_counts[p0] = (uint32_t)wv::popc64(m);
+    remaining &= ~m;
+  }
+  return myrank;
+}
+PMA_KERNEL void k_bucket_hist(const Op *ops, uint64_t n, uint32_t part_size, uint32_t nparts, uint32_t *hist /* [ntiles][nparts] */) {
+  PMA_SHARED uint32_t cnt[kBucketRows][4][kMaxParts];
+  const uint32_t tid = wv::thread_idx();
+  const int w = wv::wave_in_block();
+  const uint64_t tile = wv::block_idx();
+  for (uint32_t i = tid; i < kBucketRows * 4 * kMaxParts; i += 256) (&cnt[0][0][0])[i] = 0;
+  wv::block_sync();
+  for (uint32_t r = 0; r < kBucketRows; r++) {
+    const uint64_t i = tile * kBucketTile + (uint64_t)r * 256 + tid;
+    const bool valid = i < n;
+    const uint32_t owner = valid ? owner_of_src(ops[i].src, part_size, nparts) : 0u;
+    (void)bucket_rank_in_wave(owner, valid, cnt[r][w]);
+  }
+  wv::block_sync();
+  for (uint32_t p = tid; p < nparts; p += 256) {
+    uint32_t t = 0;
+    for (uint32_t r = 0; r < kBucketRows; r++)
+      for (uint32_t q = 0; q < 4; q++) t += cnt[r][q][p];
+    hist[tile * nparts + p] = t;
+  }
+}
+// exclusive offsets, partition-major: off[tile][p] = sum_{p'<p} total[p'] + sum_{tile'<tile} hist[tile'][p]; counts[p] = total[p]
+PMA_KERNEL void k_bucket_scan(uint32_t *hist, uint64_t ntiles, uint32_t nparts, unsigned long long *counts) {
+  PMA_SHARED unsigned long long tot[kMaxParts];
+  const uint32_t tid = wv::thread_idx();
+  if (tid < nparts) {  // one thread per partition walks the tiles (ntiles is a few hundred per million updates)
+    unsigned long long run = 0;
+    for (uint64_t t = 0; t < ntiles; t++) {
+      const uint32_t c = hist[t * nparts + tid];
+      hist[t * nparts + tid] = (uint32_t)run;
+      run += c;
+    }
+    tot[tid] = run;
+    counts[tid] = run;
+  }
+  wv::block_sync();
+  if (tid < nparts) {
+    unsigned long long base = 0;
+    for (uint32_t p = 0; p < tid; p++) base += tot[p];
+    for (uint64_t t = 0; t < ntiles; t++) hist[t * nparts + tid] += (uint32_t)base;
+  }
+}
+PMA_KERNEL void k_bucket_scatter(const Op *ops, uint64_t n, uint32_t part_size, uint32_t nparts, const uint32_t *off, Op *out) {
+  PMA_SHARED uint32_t cnt[kBucketRows][4][kMaxParts];
+  const uint32_t tid = wv::thread_idx();
+  const int w = wv::wave_in_block();
+  const uint64_t tile = wv::block_idx();
+  for (uint32_t i = tid; i < kBucketRows * 4 * kMaxParts; i += 256) (&cnt[0][0][0])[i] = 0;
+  wv::block_sync();
+  Op mine[kBucketRows];
+  uint32_t owner[kBucketRows], rank[kBucketRows];
+  for (uint32_t r = 0; r < kBucketRows; r++) {
+    const uint64_t i = tile * kBucketTile + (uint64_t)r * 256 + tid;
+    const bool valid = i < n;
+    mine[r] = valid ? ops[i] : Op{0u, 0u, 0u};
+    owner[r] = valid ? owner_of_src(mine[r].src, part_size, nparts) : 0u;
+    rank[r] = bucket_rank_in_wave(owner[r], valid, cnt[r][w]);
+  }
+  wv::block_sync();
+  // exclusive prefix over (row, wave) per partition, in place (one thread per partition)
+  for (uint32_t p = tid; p < nparts; p += 256) {
+    uint32_t run = 0;
+    for (uint32_t r = 0; r < kBucketRows; r++)
+      for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t c = cnt[r][q][p];
+        cnt[r][q][p] = run;
+        run += c;
+      }
+  }
+  wv::block_sync();
+  for (uint32_t r = 0; r < kBucketRows; r++) {
+    const uint64_t i = tile * kBucketTile + (uint64_t)r * 256 + tid;
+    if (i < n) {
+      const uint32_t p = owner[r];
+      Op o = mine[r];
+      o.src = o.src - p * part_size;  // partition-local source, global destination (PPPCSR.cpp:46-52)
+      out[(uint64_t)off[tile * nparts + p] + cnt[r][w][p] + rank[r]] = o;
+    }
+  }
+}
+
 }  // namespace ppcsr

@@ -43,9 +43,43 @@ def bucket_ops(ops, init_n, n_parts):
     return b.contiguous(), counts
 
 
+_HIP = {"lib": None, "tried": False}
+
+
+def _hip_lib():
+    """the engine library, for the device-side bucketing kernel (None when it is not built: CPU tests)"""
+    if not _HIP["tried"]:
+        _HIP["tried"] = True
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libppcsr_hip.so")
+        if os.path.exists(path):
+            L = ctypes.CDLL(path)
+            L.pppcsr_bucket_ops_device.argtypes = [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            _HIP["lib"] = L
+    return _HIP["lib"]
+
+
+def bucket_ops_device(ops, init_n, n_parts):
+    """same contract as bucket_ops for an (m,3) int32 CUDA tensor, done by the engine's HIP counting-sort kernels
+    (k_bucket_hist / k_bucket_scan / k_bucket_scatter) on torch's current stream"""
+    L = _hip_lib()
+    out = torch.empty_like(ops)
+    counts = torch.zeros(n_parts, dtype=torch.int64, device=ops.device)
+    rc = L.pppcsr_bucket_ops_device(init_n, n_parts, ops.data_ptr(), ops.shape[0], out.data_ptr(), counts.data_ptr(),
+                                    torch.cuda.current_stream(ops.device).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"pppcsr_bucket_ops_device failed with status {rc}")
+    return out, counts
+
+
 def exchange_ops(ops, init_n, n_parts, group=None):
     """all-to-all of owner buckets; returns this rank's partition subsequence (stream order, local src)"""
-    b, counts = bucket_ops(ops, init_n, n_parts)
+    if ops.is_cuda and n_parts <= 64 and _hip_lib() is not None:
+        b, counts = bucket_ops_device(ops.contiguous(), init_n, n_parts)
+    else:
+        b, counts = bucket_ops(ops, init_n, n_parts)
     recv_counts = torch.empty_like(counts)
     dist.all_to_all_single(recv_counts, counts, group=group)
     in_split = [int(x) for x in counts.tolist()]

@@ -217,3 +217,24 @@ def test_big_window_rebalance(pkg, streams):
     e.apply(more)
     o.apply(more)
     _same(e, o, "updates after the rebalances")
+
+
+def test_bucket_ops_device_matches_host_routing(pkg, streams):
+    """HIP counting-sort bucketing (the multi-GPU exchange's device side) == torch stable sort == host routine"""
+    import importlib.util
+    import os
+    import torch
+    from helpers import ROOT
+    spec = importlib.util.spec_from_file_location("ppcsr_exchange", os.path.join(ROOT, "parallel-packed-csr_amd", "exchange.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    for n_global, P, m in [(1 << 20, 8, 1_000_000), (1003, 8, 9000), (1 << 23, 2, 300_000), (77, 64, 5000)]:
+        ops = streams.random_stream(n_global, m, seed=P + 1, p_delete=0.3)
+        t = torch.from_numpy(ops.view(np.int32)).cuda()
+        out, counts = ex.bucket_ops_device(t, n_global, P)
+        ref, ref_counts = ex.bucket_ops(t, n_global, P)
+        torch.cuda.synchronize()
+        assert torch.equal(counts, ref_counts)
+        assert torch.equal(out, ref)
+        hb, hc = pkg.bucket_ops(n_global, P, ops)
+        np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), hb)

@@ -134,3 +134,20 @@ def test_sim_scan_all_and_queries(sim, streams):
         np.testing.assert_array_equal(dests[int(rows[v]):int(rows[v + 1])], ref)
     for s, d in [(0, 1), (5, 77), (119, 3)]:
         assert e.edge_exists(s, d) == o.edge_exists(s, d)
+
+
+def test_sim_bucket_kernels(streams):
+    """the HIP owner-bucketing kernels (multi-GPU exchange) under the emulator vs the host routing routine"""
+    import ctypes
+    build_sim()
+    pkg = load_pkg()
+    lib = pkg.load_library(SIM_SO)
+    for n_global, P, m in [(1000, 2, 5000), (1003, 8, 9000), (64, 64, 3000), (5, 8, 100)]:
+        ops = streams.random_stream(n_global, m, seed=3 + P, p_delete=0.3)
+        ref, ref_counts = pkg.bucket_ops(n_global, P, ops, lib=lib)
+        out = np.empty_like(ops)
+        counts = np.zeros(P, np.uint64)
+        rc = lib.pppcsr_bucket_ops_device(n_global, P, ops.ctypes.data, len(ops), out.ctypes.data, counts.ctypes.data, None)
+        assert rc == 0
+        np.testing.assert_array_equal(counts, ref_counts)
+        np.testing.assert_array_equal(out, ref)
