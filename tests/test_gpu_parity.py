@@ -238,3 +238,58 @@ def test_bucket_ops_device_matches_host_routing(pkg, streams):
         assert torch.equal(out, ref)
         hb, hc = pkg.bucket_ops(n_global, P, ops)
         np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), hb)
+
+
+def test_large_graph_properties(pkg, streams):
+    """BASELINE-sized shape (scale-19 RMAT, 4 M-edge core + 1 M mixed updates) checked through size-independent
+    properties of the reference's data structure instead of a slot-by-slot oracle comparison:
+    canonical nulls, sentinel <-> nodes[] consistency, sorted neighbourhoods, exact edge set, call-count semantics."""
+    scale, m = 19, 4_000_000
+    n = 1 << scale
+    s, d = streams.rmat_edges(scale, m, seed=1)
+    core = streams.adds(s, d)
+    s2, d2 = streams.rmat_edges(scale, 500_000, seed=2)
+    upd = streams.mixed_existing_stream(core, streams.adds(s2, d2), seed=3)
+    eng = pkg.PCSR(n)
+    eng.apply(core)
+    eng.apply(upd)
+    assert eng.check_invariants() == 0
+    items, nodes = eng.state()
+    N = len(items)
+    live = items[:, 2] != 0
+    # (1) every null slot is exactly {0xFFFFFFFF, 0, 0}
+    nul = items[~live]
+    assert (nul[:, 0] == 0xFFFFFFFF).all() and (nul[:, 1] == 0).all()
+    # (2) sentinels: slot nodes[v].beginning holds {v, MAX, v} (v = 0: value MAX); end = next beginning; last end = N-1
+    sent = live & (items[:, 1] == 0xFFFFFFFF)
+    pos = np.nonzero(sent)[0]
+    assert len(pos) == n
+    np.testing.assert_array_equal(items[pos, 0], np.arange(n, dtype=np.uint32))
+    np.testing.assert_array_equal(nodes[:, 0], pos.astype(np.uint32))
+    np.testing.assert_array_equal(nodes[:-1, 1], nodes[1:, 0])
+    assert nodes[-1, 1] == N - 1
+    # (3) edges between sentinel v and v+1 have src == v and strictly increasing dest
+    e = items[live & ~sent]
+    assert (np.diff(e[:, 0].astype(np.int64)) >= 0).all()
+    same = e[1:, 0] == e[:-1, 0]
+    assert (e[1:, 1][same] > e[:-1, 1][same]).all()
+    owner = np.searchsorted(pos, np.nonzero(live & ~sent)[0], side="right") - 1
+    np.testing.assert_array_equal(owner.astype(np.uint32), e[:, 0])
+    # (4) the edge SET equals the stream's net effect
+    key = lambda a: (a[:, 0].astype(np.uint64) << np.uint64(32)) | a[:, 1].astype(np.uint64)
+    expect = set(key(core).tolist())
+    for row_k, op in zip(key(upd).tolist(), upd[:, 2].tolist()):
+        if op:
+            expect.add(row_k)
+        else:
+            expect.discard(row_k)
+    got = key(e)
+    assert len(got) == len(expect) and set(got.tolist()) == expect
+    # (5) num_neighbors counts add calls minus delete calls per source (PCSR.cpp:1392, :747), mod 2^32
+    allops = np.concatenate([core, upd])
+    cnt = np.bincount(allops[allops[:, 2] != 0, 0], minlength=n).astype(np.int64) - \
+        np.bincount(allops[allops[:, 2] == 0, 0], minlength=n).astype(np.int64)
+    np.testing.assert_array_equal(nodes[:, 2], (cnt % (1 << 32)).astype(np.uint32))
+    # (6) the bulk scan agrees with the array
+    rows, dests = eng.scan_all()
+    assert rows[-1] == len(e) - (1 if (live[-1] and not sent[-1]) else 0)
