@@ -210,4 +210,28 @@ PMA_HD inline uint64_t chain_pos(const ChainTable *tb, uint64_t k, int *hint) {
   return M >> sg.shift;
 }
 
+
+// Linear form of a run of consecutive elements: if elements k0 .. k0+cnt (cnt >= 0, k0 >= 1, k0+cnt <= j-1) all fall
+// into ONE segment of the table, on its arithmetic-progression part, then pos_{k0+i} = (A + i*D) >> shift for
+// 0 <= i <= cnt.  Returns false when the run straddles segments (callers fall back to chain_pos per element).
+PMA_HD inline bool chain_linear_run(const ChainTable *tb, uint64_t k0, uint64_t cnt, int *hint, uint64_t *A, uint64_t *D, int *shift) {
+  if (k0 == 0 || tb->j < 2 || k0 + cnt > tb->j - 1) return false;
+  const uint64_t t_hi = tb->j - 1 - k0, t_lo = tb->j - 1 - (k0 + cnt);
+  int s = *hint;
+  if (s < 0 || s >= tb->nseg) s = 0;
+  while (s > 0 && tb->seg[s].t0 > t_lo) s--;
+  while (s + 1 < tb->nseg && tb->seg[s + 1].t0 <= t_lo) s++;
+  *hint = s;
+  const ChainSeg &sg = tb->seg[s];
+  if (t_hi > sg.t0 + sg.count) return false;  // the run continues in an earlier segment
+  const uint64_t d_lo = t_lo - sg.t0;         // smallest offset inside the segment (element k0+cnt)
+  if (d_lo == 0 && sg.Dfirst != sg.Drest) return false;
+  const uint64_t d_hi = t_hi - sg.t0;         // offset of element k0  (>= 1 here unless the progression is uniform)
+  // M(d) = M0 - Dfirst - (d-1)*Drest for d >= 1 (and for d = 0 when Dfirst == Drest)
+  *A = sg.M0 - sg.Dfirst - (d_hi - 1) * sg.Drest;
+  *D = sg.Drest;
+  *shift = sg.shift;
+  return true;
+}
+
 }  // namespace ppcsr

@@ -557,6 +557,69 @@ PMA_KERNEL void k_scatter_fill(View v, const Edge *src, uint64_t src_lo, uint64_
   }
 }
 
+// Leaner variant of the fused rebalance pass: ONE position-table look-up per wave (its <= 64 live elements are
+// consecutive ranks and almost always lie on one arithmetic progression of the table: pos_i = (A + i*D) >> shift),
+// and every lane stores its own run — the element followed by the null slots up to the next element's position —
+// straight from registers.  Consecutive lanes write consecutive runs, so a wave's stores cover one contiguous stretch.
+PMA_KERNEL void k_scatter_runs(View v, const Edge *src, uint64_t src_lo, uint64_t src_len, int src_sh, const uint32_t *rank,
+                               const ChainTable *tb, Edge *dst, uint64_t dst_bias, uint32_t *dst_leafcnt, int dst_sh,
+                               uint64_t dst_leaf_bias) {
+  PMA_SHARED ChainTable stb;
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
+    uint32_t *s = reinterpret_cast<uint32_t *>(&stb);
+    for (uint32_t i = wv::thread_idx(); i < sizeof(ChainTable) / 4; i += wv::block_dim()) s[i] = g[i];
+  }
+  wv::block_sync();
+  const int lane = wv::lane();
+  const uint64_t j = stb.j;
+  const uint64_t wend = stb.index + stb.len;
+  const uint64_t nchunks = (src_len + 63) / 64;
+  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
+  if (j == 0) {
+    const uint64_t tstride = (uint64_t)wv::grid_dim() * wv::block_dim();
+    for (uint64_t t = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); t < stb.len; t += tstride)
+      dst[stb.index + t - dst_bias] = null_edge();
+    return;
+  }
+  int hint = 0, hint2 = 0, hint3 = 0;
+  for (uint64_t ch = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); ch < nchunks; ch += wstride) {
+    const uint64_t off = ch * 64 + (uint64_t)lane;
+    Edge e = null_edge();
+    if (off < src_len) e = src[src_lo + off];
+    const uint64_t k0 = rank[(ch * 64) >> src_sh];  // live elements before this (leaf-aligned) chunk
+    const bool nn = e.value != 0;
+    const uint64_t m = wv::ballot(nn);
+    if (m == 0) continue;
+    const uint32_t cnt = (uint32_t)wv::popc64(m);
+    const uint32_t i = dev::lanemask_lt_count(m, lane);
+    uint64_t A, D;
+    int shift;
+    uint64_t pos = 0, nxt = 0;
+    if (chain_linear_run(&stb, k0, (k0 + cnt <= j - 1) ? cnt : cnt - 1, &hint3, &A, &D, &shift)) {
+      pos = (A + (uint64_t)i * D) >> shift;
+      nxt = (k0 + i + 1 < j) ? ((A + (uint64_t)(i + 1) * D) >> shift) : wend;
+    } else if (nn) {
+      pos = chain_pos(&stb, k0 + i, &hint);
+      nxt = (k0 + i + 1 < j) ? chain_pos(&stb, k0 + i + 1, &hint2) : wend;
+    }
+    if (nn) {
+      dst[pos - dst_bias] = e;
+      for (uint64_t s2 = pos + 1; s2 < nxt; s2++) dst[s2 - dst_bias] = null_edge();
+      dev::fix_sentinel(v, e, (uint32_t)pos);
+    }
+    // destination leaf counts: one atomic per leaf touched by this wave
+    const int lfirst = wv::ctz64(m), llast = 63 - __builtin_clzll(m);
+    const uint64_t l0 = (((uint64_t)wv::shfl((uint32_t)(pos >> 32), lfirst) << 32) | wv::shfl((uint32_t)pos, lfirst)) >> dst_sh;
+    const uint64_t l1 = (((uint64_t)wv::shfl((uint32_t)(pos >> 32), llast) << 32) | wv::shfl((uint32_t)pos, llast)) >> dst_sh;
+    const uint64_t mylf = pos >> dst_sh;
+    for (uint64_t L = l0; L <= l1; L++) {
+      const uint64_t mm = wv::ballot(nn && mylf == L);
+      if (mm && lane == 0) wv::atomic_add_u32(&dst_leafcnt[L - dst_leaf_bias], (uint32_t)wv::popc64(mm));
+    }
+  }
+}
+
 PMA_KERNEL void k_copy_slots(const Edge *src, Edge *dst, uint64_t len) {
   const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
   uint32_t *d = reinterpret_cast<uint32_t *>(dst);
