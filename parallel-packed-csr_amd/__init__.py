@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libppcsr_hip.so")
+LIB_PATH = os.environ.get("PPCSR_LIB", os.path.join(_HERE, "csrc", "libppcsr_hip.so"))  # env override: debugging builds only
 
 c_vp, c_u32, c_u64, c_int, c_i64, c_dbl = (ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int,
                                             ctypes.c_int64, ctypes.c_double)

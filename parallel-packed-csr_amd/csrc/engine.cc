@@ -83,6 +83,7 @@ struct Engine::Impl {
                                 // of rounds, so a wider horizon mostly re-plans more: 6144 measured best on config #2
   uint32_t start_horizon = 6144;
   uint32_t adaptive = 0;
+  uint32_t scatter_blocks = 8192;
   uint32_t scatter_variant = 1;  // 0: LDS-staged k_scatter_fill, 1: register-run k_scatter_runs
   bool carry_dumped = false;
   bool partial = false;
@@ -355,6 +356,10 @@ int Engine::set_option(const char *key, int64_t value) {
     p.opt_horizon = (uint32_t)value;
     p.start_horizon = std::min<uint32_t>(p.start_horizon, p.opt_horizon);
     if (!p.adaptive) p.start_horizon = p.opt_horizon;
+    return PPCSR_OK;
+  }
+  if (k == "scatter_blocks") {
+    p.scatter_blocks = (uint32_t)std::max<int64_t>(64, value);
     return PPCSR_OK;
   }
   if (k == "scatter_variant") {
@@ -795,7 +800,7 @@ int Engine::resize(uint64_t newN) {
   GCHK(gpu::dset(nv.leafcnt, 0, new_leaves * sizeof(uint32_t), p.stream));
   // one fused pass: read the old array once, write every slot of the new array exactly once (elements + nulls)
   if (p.scatter_variant == 1)
-    GPU_LAUNCH(p.stream, k_scatter_runs, grid_for((oldN + 63) / 64, 4), 256, nv, (const Edge *)old.items, (uint64_t)0, oldN,
+    GPU_LAUNCH(p.stream, k_scatter_runs, grid_for((oldN + 63) / 64, 4, p.scatter_blocks), 256, nv, (const Edge *)old.items, (uint64_t)0, oldN,
                old.g.sh, (const uint32_t *)p.d_rank, (const ChainTable *)p.d_table, nv.items, (uint64_t)0, nv.leafcnt, nv.g.sh,
                (uint64_t)0);
   else
@@ -837,7 +842,7 @@ int Engine::big_redistribute(uint64_t wstart, uint64_t wlen, bool sync) {
   }
   GCHK(gpu::dset(v.leafcnt + leaf_lo, 0, nleaves * sizeof(uint32_t), p.stream));
   if (p.scatter_variant == 1)
-    GPU_LAUNCH(p.stream, k_scatter_runs, grid_for((wlen + 63) / 64, 4), 256, v, (const Edge *)v.items, wstart, wlen, v.g.sh,
+    GPU_LAUNCH(p.stream, k_scatter_runs, grid_for((wlen + 63) / 64, 4, p.scatter_blocks), 256, v, (const Edge *)v.items, wstart, wlen, v.g.sh,
                (const uint32_t *)p.d_rank, (const ChainTable *)p.d_table, p.d_scratch, wstart, v.leafcnt, v.g.sh, (uint64_t)0);
   else
     GPU_LAUNCH(p.stream, k_scatter_fill, grid_for((wlen + 63) / 64, 4), 256, v, (const Edge *)v.items, wstart, wlen, v.g.sh,

@@ -565,10 +565,11 @@ PMA_KERNEL void k_scatter_runs(View v, const Edge *src, uint64_t src_lo, uint64_
                                const ChainTable *tb, Edge *dst, uint64_t dst_bias, uint32_t *dst_leafcnt, int dst_sh,
                                uint64_t dst_leaf_bias) {
   PMA_SHARED ChainTable stb;
-  {
+  {  // only the segments in use are copied (a table has <= ~30 of its 128 slots filled)
     const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
     uint32_t *s = reinterpret_cast<uint32_t *>(&stb);
-    for (uint32_t i = wv::thread_idx(); i < sizeof(ChainTable) / 4; i += wv::block_dim()) s[i] = g[i];
+    const uint32_t words = (uint32_t)((sizeof(ChainTable) - sizeof(ChainSeg) * (size_t)(kMaxSeg - tb->nseg)) / 4);
+    for (uint32_t i = wv::thread_idx(); i < words; i += wv::block_dim()) s[i] = g[i];
   }
   wv::block_sync();
   const int lane = wv::lane();
