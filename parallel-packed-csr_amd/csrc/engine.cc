@@ -959,8 +959,8 @@ int Engine::read_neighbourhood(int src) {
 
 // bulk neighbour scan: live-edge count per 64-slot chunk from the leaf counts and the sentinel positions (no pass over
 // the edge array), exclusive scan, then ONE streaming pass that writes dests (array order == CSR order) and row offsets.
-// (A single-kernel decoupled look-back variant, k_scan_onepass, is kept in pma_kernels.h: it measured slower on MI355X —
-//  110 us vs 85 us at N = 2^24 — because 1.5 K polling workgroups disturb the streaming loads.)
+// (A single-kernel decoupled look-back variant was tried and measured slower on MI355X — 110 us vs 85 us at N = 2^24,
+//  1.5 K polling workgroups disturb the streaming loads — and was removed; see the git history, "one-pass bulk neighbour scan".)
 int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap) {
   Impl &p = *p_;
   const uint64_t N = p.v.g.N, nchunks = (N + 63) / 64;

@@ -1094,106 +1094,6 @@ PMA_KERNEL void o_compact(OptArgs a) {
   }
 }
 
-// ---- one-pass bulk neighbour scan -------------------------------------------------------------------------------
-// Stream compaction of the live edges in array order (== CSR order) with a decoupled look-back prefix: every
-// workgroup takes the next 4096-slot tile (atomic ticket), counts its live edges while loading it ONCE, publishes
-// {flag, count} in one 64-bit word, sums the published words of the preceding tiles, and writes its dests / row
-// offsets.  A tile only ever waits for tiles with smaller tickets, which have already started: no deadlock.
-constexpr uint32_t kScanChunks = 16;               // 64-slot chunks per wave
-constexpr uint32_t kScanTileSlots = 4 * 64 * kScanChunks;  // 4096 slots per workgroup
-constexpr unsigned long long kFlagAgg = 1ull << 62, kFlagPre = 2ull << 62, kFlagMask = 3ull << 62;
-PMA_KERNEL void k_scan_onepass(View v, unsigned long long *tile_state, uint32_t *ticket, unsigned long long *row_offsets,
-                               int *dests, uint64_t cap, unsigned long long *total) {
-  PMA_SHARED uint32_t s_tile;
-  PMA_SHARED unsigned long long s_excl;
-  PMA_SHARED uint32_t s_wsum[4];
-  const int lane = wv::lane(), w = wv::wave_in_block();
-  const uint64_t N = v.g.N;
-  const uint64_t ntiles = (N + kScanTileSlots - 1) / kScanTileSlots;
-  for (;;) {
-    if (wv::thread_idx() == 0) s_tile = wv::atomic_add_u32(ticket, 1u);
-    wv::block_sync();
-    const uint64_t tile = s_tile;
-    if (tile >= ntiles) return;
-    const uint64_t wbase = tile * kScanTileSlots + (uint64_t)w * 64 * kScanChunks;
-    uint32_t dst[kScanChunks], val[kScanChunks];
-    uint64_t lm[kScanChunks];
-    uint32_t wcount = 0;
-#pragma unroll
-    for (uint32_t c = 0; c < kScanChunks; c++) {  // all loads of the tile are issued before any is consumed
-      const uint64_t s = wbase + (uint64_t)c * 64 + (uint64_t)lane;
-      dst[c] = 0;
-      val[c] = 0;
-      if (s < N) {
-        dst[c] = v.items[s].dest;
-        val[c] = v.items[s].value;
-      }
-    }
-#pragma unroll
-    for (uint32_t c = 0; c < kScanChunks; c++) {
-      const uint64_t s = wbase + (uint64_t)c * 64 + (uint64_t)lane;
-      const bool live = val[c] != 0 && dst[c] != kMax && val[c] != kMax && (s + 1 < N);
-      lm[c] = wv::ballot(live);
-      wcount += (uint32_t)wv::popc64(lm[c]);
-    }
-    if (lane == 0) s_wsum[w] = wcount;
-    wv::block_sync();
-    if (w == 0) {  // wave 0 resolves the tile's exclusive prefix: 64 predecessors per look-back step
-      const unsigned long long agg = (unsigned long long)s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-      unsigned long long excl = 0;
-      if (tile == 0) {
-        if (lane == 0) wv::agent_store_u64(&tile_state[0], kFlagPre | agg);
-      } else {
-        if (lane == 0) wv::agent_store_u64(&tile_state[tile], kFlagAgg | agg);
-        uint64_t hi = tile;  // predecessors [hi-64, hi) are inspected next
-        for (;;) {
-          const bool have = (uint64_t)lane < hi;
-          const uint64_t t = hi - 1 - (uint64_t)lane;  // lane 0 = nearest predecessor
-          unsigned long long st = 0;
-          uint64_t ready, pre;
-          for (;;) {
-            st = have ? wv::agent_load_u64(&tile_state[t]) : kFlagPre;  // beyond tile 0: a zero-valued "prefix"
-            ready = wv::ballot((st & kFlagMask) != 0);
-            pre = wv::ballot((st & kFlagMask) == kFlagPre);
-            // usable once every lane up to the nearest published prefix is ready
-            const int fp = pre ? wv::ctz64(pre) : 63;
-            const uint64_t need = (fp >= 63) ? ~0ull : ((2ull << fp) - 1ull);
-            if ((ready & need) == need) break;
-            wv::spin_pause();
-          }
-          const int fp = pre ? wv::ctz64(pre) : 63;
-          const unsigned long long mine = (lane <= fp) ? (st & ~kFlagMask) : 0ull;
-          const uint32_t lo = wv::reduce_add((uint32_t)mine), hi32 = wv::reduce_add((uint32_t)(mine >> 32));
-          excl += (unsigned long long)lo + ((unsigned long long)hi32 << 32);
-          if (pre) break;
-          hi -= 64;
-        }
-        if (lane == 0) wv::agent_store_u64(&tile_state[tile], kFlagPre | (excl + agg));
-      }
-      if (lane == 0) {
-        s_excl = excl;
-        if (tile == ntiles - 1) *total = excl + agg;
-      }
-    }
-    wv::block_sync();
-    unsigned long long run = s_excl;
-    for (int q = 0; q < w; q++) run += s_wsum[q];
-#pragma unroll
-    for (uint32_t c = 0; c < kScanChunks; c++) {
-      const uint64_t s = wbase + (uint64_t)c * 64 + (uint64_t)lane;
-      const bool live = (lm[c] >> lane) & 1ull;
-      const unsigned long long o = run + dev::lanemask_lt_count(lm[c], lane);
-      if (live && o < cap) dests[o] = (int)dst[c];
-      if (s < N && val[c] != 0 && (dst[c] == kMax || val[c] == kMax)) {  // sentinel: its live rank is the row offset
-        const uint32_t vid = (val[c] == kMax) ? 0u : val[c];
-        row_offsets[vid] = o;
-      }
-      run += (unsigned long long)wv::popc64(lm[c]);
-    }
-    wv::block_sync();  // s_tile / s_wsum are reused by the next tile
-  }
-}
-
 // ---- owner bucketing for the multi-GPU exchange (PPPCSR routing rule, PPPCSR.cpp:46-66) ----------------------------
 // Stable counting sort of a block of the update stream by owning partition, with `src` made partition-local.
 // Tile = 2048 updates per workgroup; (1) per-tile histogram, (2) one small scan (partition-major, tile-minor),

@@ -36,14 +36,6 @@ PMA_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v
 PMA_DEV unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 PMA_DEV uint32_t atomic_max_u32(uint32_t *p, uint32_t v) { return atomicMax(p, v); }
 PMA_DEV uint32_t atomic_exch_u32(uint32_t *p, uint32_t v) { return atomicExch(p, v); }
-// agent-scope relaxed 64-bit load / store (bypass the per-CU L1: cross-workgroup hand-off words, MI355X guide G16)
-PMA_DEV unsigned long long agent_load_u64(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-PMA_DEV void agent_store_u64(unsigned long long *p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-PMA_DEV void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 PMA_DEV int popc64(uint64_t m) { return __popcll((unsigned long long)m); }
 PMA_DEV int ctz64(uint64_t m) { return __ffsll((long long)m) - 1; }
 PMA_DEV uint32_t block_idx() { return blockIdx.x; }

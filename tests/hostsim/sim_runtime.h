@@ -46,9 +46,6 @@ inline uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = 
 inline unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline uint32_t atomic_max_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomic_exch_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
-inline unsigned long long agent_load_u64(const unsigned long long *p) { return *p; }
-inline void agent_store_u64(unsigned long long *p, unsigned long long v) { *p = v; }
-inline void spin_pause() {}
 inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 inline int ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
 inline uint32_t block_idx() { return (uint32_t)sim::cur_block(); }
