@@ -49,6 +49,29 @@ EXPORTED = [
 _LIBS = {}
 
 
+def _share_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64 (SONAME libamdhip64.so.7)
+    and look it up by its unversioned file name, so if the engine pulled /opt/rocm's copy in first, a later `import torch`
+    would load a second runtime that finds no GPU (and the reverse order would starve the engine).  Pre-loading torch's
+    copy — without importing torch — makes both resolve to the same object.  Without torch the engine uses /opt/rocm's."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library(path=None):
     """Load the engine library.  Default: the in-tree HIP build; raises if it has not been built."""
     path = path or LIB_PATH
@@ -57,6 +80,7 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise PpcsrError(f"{path} not found: build it with `python __graft_entry__.py` "
                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _share_hip_runtime()
     L = ctypes.CDLL(path)
     L.ppcsr_create.argtypes = [c_u32, c_u32, c_int, c_int, ctypes.POINTER(c_vp)]
     L.ppcsr_destroy.argtypes = [c_vp]

@@ -84,7 +84,7 @@ struct Engine::Impl {
   uint32_t start_horizon = 6144;
   uint32_t adaptive = 0;
   uint32_t scatter_blocks = 8192;
-  uint32_t scatter_variant = 1;  // 0: LDS-staged k_scatter_fill, 1: register-run k_scatter_runs
+  uint32_t scatter_variant = 2;  // 0: LDS-staged k_scatter_fill, 1: register-run k_scatter_runs, 2: runs + in-tile leaf scan (3 launches)
   bool carry_dumped = false;
   bool partial = false;
   bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
@@ -363,7 +363,7 @@ int Engine::set_option(const char *key, int64_t value) {
     return PPCSR_OK;
   }
   if (k == "scatter_variant") {
-    p.scatter_variant = value ? 1 : 0;
+    p.scatter_variant = value > 2 ? 2u : (uint32_t)value;
     return PPCSR_OK;
   }
   if (k == "adaptive") {
@@ -780,6 +780,26 @@ int Engine::rank_scan(const uint32_t *d_cnt, uint64_t nleaves, bool table, uint6
   return PPCSR_OK;
 }
 
+// three-launch rebalance pipeline (scatter_variant 2): tile sums (+ zeroing of the destination leaf counts), tile scan +
+// position table, scatter with the in-tile leaf scan done in LDS.  The source leaf counts must stay intact while the
+// scatter runs, so an in-place window (source counts == destination counts) is served from a copy of its counts.
+int Engine::rebalance_fused(const View &nv, const Edge *src_items, uint64_t src_lo, uint64_t src_len, int src_sh,
+                            uint32_t *src_cnt, bool inplace, uint64_t tb_index, uint64_t tb_len, Edge *dst, uint64_t dst_bias,
+                            uint32_t *dst_cnt, uint64_t dst_nleaves) {
+  Impl &p = *p_;
+  const uint64_t nleaves = src_len >> src_sh;
+  const uint64_t ntiles = (nleaves + kRbTile - 1) / kRbTile;
+  int rc = ensure_scratch(std::max<uint64_t>(nleaves, ntiles * kScanTile));  // d_tiles >= ntiles entries, d_rank >= nleaves
+  if (rc != PPCSR_OK) return rc;
+  GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, src_cnt, nleaves, p.d_tiles, inplace ? p.d_rank : (uint32_t *)nullptr,
+             inplace ? (uint32_t *)nullptr : dst_cnt, inplace ? (uint64_t)0 : dst_nleaves);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, 64, p.d_tiles, ntiles, p.d_total, p.d_table, tb_index, tb_len);
+  GPU_LAUNCH(p.stream, k_rb_scatter, ntiles, 256, nv, src_items, src_lo, src_len, src_sh,
+             inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, (const uint32_t *)p.d_tiles,
+             (const ChainTable *)p.d_table, dst, dst_bias, dst_cnt, nv.g.sh, (uint64_t)0);
+  return PPCSR_OK;
+}
+
 // double_list / half_list (PCSR.cpp:251-320): out-of-place whole-array rebalance into a fresh buffer
 int Engine::resize(uint64_t newN) {
   Impl &p = *p_;
@@ -795,11 +815,18 @@ int Engine::resize(uint64_t newN) {
   const uint64_t new_leaves = newN >> g.sh;
   GCHK(gpu::dmalloc((void **)&nv.items, newN * sizeof(Edge)));
   GCHK(gpu::dmalloc((void **)&nv.leafcnt, new_leaves * sizeof(uint32_t)));
-  int rc = rank_scan(old.leafcnt, old_leaves, true, 0, newN);
-  if (rc != PPCSR_OK) return rc;
-  GCHK(gpu::dset(nv.leafcnt, 0, new_leaves * sizeof(uint32_t), p.stream));
+  int rc = PPCSR_OK;
+  if (p.scatter_variant == 2 && old.g.logN <= 32) {
+    rc = rebalance_fused(nv, old.items, 0, oldN, old.g.sh, old.leafcnt, false, 0, newN, nv.items, 0, nv.leafcnt, new_leaves);
+    if (rc != PPCSR_OK) return rc;
+  } else {
+    rc = rank_scan(old.leafcnt, old_leaves, true, 0, newN);
+    if (rc != PPCSR_OK) return rc;
+    GCHK(gpu::dset(nv.leafcnt, 0, new_leaves * sizeof(uint32_t), p.stream));
+  }
   // one fused pass: read the old array once, write every slot of the new array exactly once (elements + nulls)
-  if (p.scatter_variant == 1)
+  if (p.scatter_variant == 2 && old.g.logN <= 32) {
+  } else if (p.scatter_variant == 1)
     GPU_LAUNCH(p.stream, k_scatter_runs, grid_for((oldN + 63) / 64, 4, p.scatter_blocks), 256, nv, (const Edge *)old.items, (uint64_t)0, oldN,
                old.g.sh, (const uint32_t *)p.d_rank, (const ChainTable *)p.d_table, nv.items, (uint64_t)0, nv.leafcnt, nv.g.sh,
                (uint64_t)0);
@@ -829,7 +856,8 @@ int Engine::big_redistribute(uint64_t wstart, uint64_t wlen, bool sync) {
   Impl &p = *p_;
   const View v = p.v;
   const uint64_t leaf_lo = wstart >> v.g.sh, nleaves = wlen >> v.g.sh;
-  int rc = rank_scan(v.leafcnt + leaf_lo, nleaves, true, wstart, wlen);
+  const bool fused = p.scatter_variant == 2 && v.g.logN <= 32;
+  int rc = fused ? ensure_scratch(nleaves) : rank_scan(v.leafcnt + leaf_lo, nleaves, true, wstart, wlen);
   if (rc != PPCSR_OK) return rc;
   const bool whole = (wstart == 0 && wlen == v.g.N);
   const uint64_t need = whole ? v.g.N : wlen;
@@ -840,8 +868,13 @@ int Engine::big_redistribute(uint64_t wstart, uint64_t wlen, bool sync) {
     GCHK(gpu::dmalloc((void **)&p.d_scratch, need * sizeof(Edge)));
     p.scratch_cap = need;
   }
-  GCHK(gpu::dset(v.leafcnt + leaf_lo, 0, nleaves * sizeof(uint32_t), p.stream));
-  if (p.scatter_variant == 1)
+  if (fused) {
+    rc = rebalance_fused(v, v.items, wstart, wlen, v.g.sh, v.leafcnt + leaf_lo, true, wstart, wlen, p.d_scratch, wstart, v.leafcnt, 0);
+    if (rc != PPCSR_OK) return rc;
+  } else
+    GCHK(gpu::dset(v.leafcnt + leaf_lo, 0, nleaves * sizeof(uint32_t), p.stream));
+  if (fused) {
+  } else if (p.scatter_variant == 1)
     GPU_LAUNCH(p.stream, k_scatter_runs, grid_for((wlen + 63) / 64, 4, p.scatter_blocks), 256, v, (const Edge *)v.items, wstart, wlen, v.g.sh,
                (const uint32_t *)p.d_rank, (const ChainTable *)p.d_table, p.d_scratch, wstart, v.leafcnt, v.g.sh, (uint64_t)0);
   else

@@ -11,6 +11,7 @@
 namespace ppcsr {
 
 struct View;  // pma_device.h
+struct Edge;
 
 struct EngineStats {
   uint64_t N, n;
@@ -71,6 +72,8 @@ class Engine {
   int pull_stats();
 
   int run_speculative(const Op *d_ops, uint64_t n);
+  int rebalance_fused(const View &nv, const Edge *src_items, uint64_t src_lo, uint64_t src_len, int src_sh, uint32_t *src_cnt,
+                      bool inplace, uint64_t tb_index, uint64_t tb_len, Edge *dst, uint64_t dst_bias, uint32_t *dst_cnt, uint64_t dst_nleaves);
   int scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap);
 
  public:

@@ -621,6 +621,110 @@ PMA_KERNEL void k_scatter_runs(View v, const Edge *src, uint64_t src_lo, uint64_
   }
 }
 
+// ---- rebalance with the leaf-rank scan folded in --------------------------------------------------------------------
+// Tile = kRbTile source leaves per workgroup.  k_rb_tilesums: per-tile live counts (+ zeroing of the destination leaf
+// counts as a side job); k_scan_tilesums: exclusive scan of the tile sums + the exact position table; k_rb_scatter: each
+// workgroup scans its own tile's leaf counts in LDS (so no per-leaf rank array is ever written or read) and runs the
+// register-run scatter of k_scatter_runs over the tile's chunks.  Three launches for a whole-array rebalance.
+constexpr uint32_t kRbTile = 256;
+PMA_KERNEL void k_rb_tilesums(uint32_t *cnt, uint64_t nleaves, uint32_t *tilesum, uint32_t *copy_out, uint32_t *zero_ptr,
+                              uint64_t zero_n) {
+  PMA_SHARED uint32_t red[4];
+  const uint64_t b = wv::block_idx();
+  const uint64_t l = b * kRbTile + wv::thread_idx();
+  uint32_t s = (l < nleaves) ? cnt[l] : 0u;
+  if (copy_out != nullptr && l < nleaves) {  // in-place window: park the source counts, clear them for the rebuild
+    copy_out[l] = s;
+    cnt[l] = 0u;
+  }
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t i = b * wv::block_dim() + wv::thread_idx(); i < zero_n; i += stride) zero_ptr[i] = 0u;
+  s = wv::reduce_add(s);
+  if (wv::lane() == 0) red[wv::wave_in_block()] = s;
+  wv::block_sync();
+  if (wv::thread_idx() == 0) tilesum[b] = red[0] + red[1] + red[2] + red[3];
+}
+PMA_KERNEL void k_rb_scatter(View v, const Edge *src, uint64_t src_lo, uint64_t src_len, int src_sh, const uint32_t *cnt,
+                             const uint32_t *tile_excl, const ChainTable *tb, Edge *dst, uint64_t dst_bias, uint32_t *dst_leafcnt,
+                             int dst_sh, uint64_t dst_leaf_bias) {
+  PMA_SHARED ChainTable stb;
+  PMA_SHARED uint32_t pre[kRbTile];
+  PMA_SHARED uint32_t wsum[4];
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
+    uint32_t *s = reinterpret_cast<uint32_t *>(&stb);
+    const uint32_t words = (uint32_t)((sizeof(ChainTable) - sizeof(ChainSeg) * (size_t)(kMaxSeg - tb->nseg)) / 4);
+    for (uint32_t i = wv::thread_idx(); i < words; i += wv::block_dim()) s[i] = g[i];
+  }
+  const int lane = wv::lane(), w = wv::wave_in_block();
+  const uint64_t tile = wv::block_idx();
+  const uint64_t nleaves = src_len >> src_sh;
+  {  // exclusive prefix of this tile's leaf counts (256 leaves = one per thread)
+    const uint64_t l = tile * kRbTile + wv::thread_idx();
+    const uint32_t x = (l < nleaves) ? cnt[l] : 0u;
+    uint32_t incl = x;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[w] = incl;
+    wv::block_sync();
+    uint32_t woff = 0;
+    for (int q = 0; q < w; q++) woff += wsum[q];
+    pre[wv::thread_idx()] = woff + incl - x;
+  }
+  wv::block_sync();
+  const uint64_t j = stb.j;
+  const uint64_t wend = stb.index + stb.len;
+  if (j == 0) {
+    const uint64_t tstride = (uint64_t)wv::grid_dim() * wv::block_dim();
+    for (uint64_t t = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); t < stb.len; t += tstride)
+      dst[stb.index + t - dst_bias] = null_edge();
+    return;
+  }
+  const uint64_t base_rank = tile_excl[tile];
+  const uint32_t lpc = 64u >> src_sh;               // leaves per 64-slot chunk (logN <= 32)
+  const uint32_t chunks = kRbTile / lpc;            // chunks in this tile
+  const uint64_t tile_slot0 = (tile * kRbTile) << src_sh;
+  int hint = 0, hint2 = 0, hint3 = 0;
+  for (uint32_t c = (uint32_t)w; c < chunks; c += 4) {
+    const uint64_t off0 = tile_slot0 + (uint64_t)c * 64;
+    if (off0 >= src_len) break;
+    const uint64_t off = off0 + (uint64_t)lane;
+    Edge e = null_edge();
+    if (off < src_len) e = src[src_lo + off];
+    const uint64_t k0 = base_rank + pre[c * lpc];
+    const bool nn = e.value != 0;
+    const uint64_t m = wv::ballot(nn);
+    if (m == 0) continue;
+    const uint32_t cn = (uint32_t)wv::popc64(m);
+    const uint32_t i = dev::lanemask_lt_count(m, lane);
+    uint64_t A, D;
+    int shift;
+    uint64_t pos = 0, nxt = 0;
+    if (chain_linear_run(&stb, k0, (k0 + cn <= j - 1) ? cn : cn - 1, &hint3, &A, &D, &shift)) {
+      pos = (A + (uint64_t)i * D) >> shift;
+      nxt = (k0 + i + 1 < j) ? ((A + (uint64_t)(i + 1) * D) >> shift) : wend;
+    } else if (nn) {
+      pos = chain_pos(&stb, k0 + i, &hint);
+      nxt = (k0 + i + 1 < j) ? chain_pos(&stb, k0 + i + 1, &hint2) : wend;
+    }
+    if (nn) {
+      dst[pos - dst_bias] = e;
+      for (uint64_t s2 = pos + 1; s2 < nxt; s2++) dst[s2 - dst_bias] = null_edge();
+      dev::fix_sentinel(v, e, (uint32_t)pos);
+    }
+    const int lfirst = wv::ctz64(m), llast = 63 - __builtin_clzll(m);
+    const uint64_t l0 = (((uint64_t)wv::shfl((uint32_t)(pos >> 32), lfirst) << 32) | wv::shfl((uint32_t)pos, lfirst)) >> dst_sh;
+    const uint64_t l1 = (((uint64_t)wv::shfl((uint32_t)(pos >> 32), llast) << 32) | wv::shfl((uint32_t)pos, llast)) >> dst_sh;
+    const uint64_t mylf = pos >> dst_sh;
+    for (uint64_t L = l0; L <= l1; L++) {
+      const uint64_t mm = wv::ballot(nn && mylf == L);
+      if (mm && lane == 0) wv::atomic_add_u32(&dst_leafcnt[L - dst_leaf_bias], (uint32_t)wv::popc64(mm));
+    }
+  }
+}
+
 PMA_KERNEL void k_copy_slots(const Edge *src, Edge *dst, uint64_t len) {
   const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
   uint32_t *d = reinterpret_cast<uint32_t *>(dst);
