@@ -84,6 +84,9 @@ struct Engine::Impl {
   uint32_t start_horizon = 6144;
   uint32_t adaptive = 0;
   uint32_t scatter_blocks = 8192;
+  uint32_t rb_tile = 0;          // leaves per rebalance tile (power of two <= 256); 0 = pick per window
+  uint32_t rb_min_tiles = 4096;  // auto tile: shrink the tile until the window has at least this many
+  uint32_t rb_prefetch = 1;  // 1: four chunks in flight per wave, 0: one
   uint32_t scatter_variant = 2;  // 0: LDS-staged k_scatter_fill, 1: register-run k_scatter_runs, 2: runs + in-tile leaf scan (3 launches)
   bool carry_dumped = false;
   bool partial = false;
@@ -360,6 +363,20 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "scatter_blocks") {
     p.scatter_blocks = (uint32_t)std::max<int64_t>(64, value);
+    return PPCSR_OK;
+  }
+  if (k == "rb_tile") {
+    uint32_t t = 0;
+    if (value > 0) for (t = 8; t < (uint32_t)value && t < kRbTile; t <<= 1) {}
+    p.rb_tile = t;
+    return PPCSR_OK;
+  }
+  if (k == "rb_min_tiles") {
+    p.rb_min_tiles = value < 1 ? 1u : (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "rb_prefetch") {
+    p.rb_prefetch = value ? 1u : 0u;
     return PPCSR_OK;
   }
   if (k == "scatter_variant") {
@@ -775,7 +792,7 @@ int Engine::rank_scan(const uint32_t *d_cnt, uint64_t nleaves, bool table, uint6
   if (rc != PPCSR_OK) return rc;
   const uint64_t ntiles = (nleaves + kScanTile - 1) / kScanTile;
   GPU_LAUNCH(p.stream, k_scan_tiles, ntiles, 256, d_cnt, nleaves, p.d_tiles);
-  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, 64, p.d_tiles, ntiles, p.d_total, table ? p.d_table : (ChainTable *)nullptr, tb_index, tb_len);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, 128, p.d_tiles, ntiles, p.d_total, table ? p.d_table : (ChainTable *)nullptr, tb_index, tb_len);
   GPU_LAUNCH(p.stream, k_scan_apply, ntiles, 256, d_cnt, nleaves, (const uint32_t *)p.d_tiles, p.d_rank);
   return PPCSR_OK;
 }
@@ -788,14 +805,23 @@ int Engine::rebalance_fused(const View &nv, const Edge *src_items, uint64_t src_
                             uint32_t *dst_cnt, uint64_t dst_nleaves) {
   Impl &p = *p_;
   const uint64_t nleaves = src_len >> src_sh;
-  const uint64_t ntiles = (nleaves + kRbTile - 1) / kRbTile;
+  // tile size: as large as the workgroup when that still gives every CU several tiles, smaller for smaller windows
+  uint32_t tile = p.rb_tile;
+  if (tile == 0) {
+    tile = kRbTile;
+    while (tile > 32 && nleaves / tile < p.rb_min_tiles) tile >>= 1;
+  }
+  const uint32_t lpc = 64u >> src_sh;
+  if (tile < lpc) tile = lpc;
+  if (tile > kRbTile) tile = kRbTile;
+  const uint64_t ntiles = (nleaves + tile - 1) / tile;
   int rc = ensure_scratch(std::max<uint64_t>(nleaves, ntiles * kScanTile));  // d_tiles >= ntiles entries, d_rank >= nleaves
   if (rc != PPCSR_OK) return rc;
-  GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, src_cnt, nleaves, p.d_tiles, inplace ? p.d_rank : (uint32_t *)nullptr,
+  GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, src_cnt, nleaves, tile, p.d_tiles, inplace ? p.d_rank : (uint32_t *)nullptr,
              inplace ? (uint32_t *)nullptr : dst_cnt, inplace ? (uint64_t)0 : dst_nleaves);
-  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, 64, p.d_tiles, ntiles, p.d_total, p.d_table, tb_index, tb_len);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, 128, p.d_tiles, ntiles, p.d_total, p.d_table, tb_index, tb_len);
   GPU_LAUNCH(p.stream, k_rb_scatter, ntiles, 256, nv, src_items, src_lo, src_len, src_sh,
-             inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, (const uint32_t *)p.d_tiles,
+             inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, tile, p.rb_prefetch ? 4u : 1u, (const uint32_t *)p.d_tiles,
              (const ChainTable *)p.d_table, dst, dst_bias, dst_cnt, nv.g.sh, (uint64_t)0);
   return PPCSR_OK;
 }

@@ -130,6 +130,7 @@ PMA_HD inline void build_chain_table(uint64_t index, uint64_t len, uint64_t j, C
   tb->nseg = 0;
   tb->overflow = 0;
   if (j < 2) return;
+  int nseg = 0;  // kept in a register: the table usually lives in device memory and is only written, never read back
   const double step = chain_step(len, j);
   double x = chain_top(index, j, step);
   const uint64_t sb = dbl_bits(step);
@@ -138,7 +139,8 @@ PMA_HD inline void build_chain_table(uint64_t index, uint64_t len, uint64_t j, C
   const uint64_t T = j - 2;  // last chain step needed (k = 1)
   uint64_t t = 0;
   for (;;) {
-    if (tb->nseg >= kMaxSeg) {
+    if (nseg >= kMaxSeg) {
+      tb->nseg = nseg;
       tb->overflow = 1;
       return;
     }
@@ -184,9 +186,12 @@ PMA_HD inline void build_chain_table(uint64_t index, uint64_t len, uint64_t j, C
     }
     if (c > T - t) c = T - t;
     sg.count = c;
-    tb->seg[tb->nseg++] = sg;
+    tb->seg[nseg++] = sg;
     t += c;
-    if (t >= T) return;
+    if (t >= T) {
+      tb->nseg = nseg;
+      return;
+    }
     // one true fp64 subtraction across the binade boundary
     uint64_t Mc = (c == 0) ? M0 : (M0 - sg.Dfirst - (c - 1) * sg.Drest);
     double xc = bits_dbl(((uint64_t)(e + 1023) << 52) | (Mc & 0xFFFFFFFFFFFFFull));

@@ -416,24 +416,32 @@ PMA_KERNEL void k_scan_tiles(const uint32_t *cnt, uint64_t nleaves, uint32_t *ti
 }
 PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned long long *total, ChainTable *tb,
                                 uint64_t tb_index, uint64_t tb_len) {
-  // single wave, serial over chunks of 64 (ntiles <= 2^31/ (8*1024) — tiny)
-  const int lane = wv::lane();
-  unsigned long long run = 0;
-  for (uint64_t base = 0; base < ntiles; base += 64) {
-    const uint64_t i = base + (uint64_t)lane;
-    uint32_t x = (i < ntiles) ? tilesum[i] : 0u;
-    // inclusive scan across lanes via shuffles
-    uint32_t incl = x;
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
-      if (lane >= o) incl += y;
-    }
-    if (i < ntiles) tilesum[i] = (uint32_t)(run + incl - x);
-    run += wv::shfl(incl, 63);
+  // one workgroup of two waves.  Each lane owns a contiguous run of tile sums, so all of its loads are independent and in
+  // flight together; wave 0 writes the exclusive prefix back while wave 1 builds the rebalance's exact position table
+  // from the grand total (saves a launch).
+  const int lane = wv::lane(), w = wv::wave_in_block();
+  const uint64_t per = (ntiles + 63) / 64;
+  const uint64_t lo = (uint64_t)lane * per;
+  const uint64_t hi = (lo + per < ntiles) ? lo + per : ntiles;
+  uint32_t mine = 0;
+  for (uint64_t i = lo; i < hi; i++) mine += tilesum[i];
+  uint32_t incl = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
+    if (lane >= o) incl += y;
   }
-  if (lane == 0) {
-    *total = run;
-    if (tb) build_chain_table(tb_index, tb_len, (uint64_t)run, tb);  // the rebalance's exact position table (saves a launch)
+  const uint32_t grand = wv::shfl(incl, 63);
+  wv::block_sync();  // every read of the un-scanned sums is done before wave 0 overwrites them
+  if (w == 0) {
+    uint32_t run = incl - mine;
+    for (uint64_t i = lo; i < hi; i++) {
+      const uint32_t x = tilesum[i];
+      tilesum[i] = run;
+      run += x;
+    }
+    if (lane == 0) *total = grand;
+  } else if (lane == 0 && tb) {
+    build_chain_table(tb_index, tb_len, (uint64_t)grand, tb);
   }
 }
 PMA_KERNEL void k_scan_apply(const uint32_t *cnt, uint64_t nleaves, const uint32_t *tilesum, uint32_t *rank) {
@@ -626,14 +634,15 @@ PMA_KERNEL void k_scatter_runs(View v, const Edge *src, uint64_t src_lo, uint64_
 // counts as a side job); k_scan_tilesums: exclusive scan of the tile sums + the exact position table; k_rb_scatter: each
 // workgroup scans its own tile's leaf counts in LDS (so no per-leaf rank array is ever written or read) and runs the
 // register-run scatter of k_scatter_runs over the tile's chunks.  Three launches for a whole-array rebalance.
-constexpr uint32_t kRbTile = 256;
-PMA_KERNEL void k_rb_tilesums(uint32_t *cnt, uint64_t nleaves, uint32_t *tilesum, uint32_t *copy_out, uint32_t *zero_ptr,
-                              uint64_t zero_n) {
+constexpr uint32_t kRbTile = 256;  // maximum tile (= workgroup size); the engine picks a power of two <= this per window
+PMA_KERNEL void k_rb_tilesums(uint32_t *cnt, uint64_t nleaves, uint32_t tile_leaves, uint32_t *tilesum, uint32_t *copy_out,
+                              uint32_t *zero_ptr, uint64_t zero_n) {
   PMA_SHARED uint32_t red[4];
   const uint64_t b = wv::block_idx();
-  const uint64_t l = b * kRbTile + wv::thread_idx();
-  uint32_t s = (l < nleaves) ? cnt[l] : 0u;
-  if (copy_out != nullptr && l < nleaves) {  // in-place window: park the source counts, clear them for the rebuild
+  const uint64_t l = b * tile_leaves + wv::thread_idx();
+  const bool mine = wv::thread_idx() < tile_leaves && l < nleaves;
+  uint32_t s = mine ? cnt[l] : 0u;
+  if (copy_out != nullptr && mine) {  // in-place window: park the source counts, clear them for the rebuild
     copy_out[l] = s;
     cnt[l] = 0u;
   }
@@ -644,24 +653,68 @@ PMA_KERNEL void k_rb_tilesums(uint32_t *cnt, uint64_t nleaves, uint32_t *tilesum
   wv::block_sync();
   if (wv::thread_idx() == 0) tilesum[b] = red[0] + red[1] + red[2] + red[3];
 }
-PMA_KERNEL void k_rb_scatter(View v, const Edge *src, uint64_t src_lo, uint64_t src_len, int src_sh, const uint32_t *cnt,
-                             const uint32_t *tile_excl, const ChainTable *tb, Edge *dst, uint64_t dst_bias, uint32_t *dst_leafcnt,
-                             int dst_sh, uint64_t dst_leaf_bias) {
+// One chunk (64 source slots, already in registers) of the rebalance scatter: rank the live slots, look their exact
+// positions up, store element + trailing nulls, fix sentinels, add the destination leaf counts.
+PMA_DEV void rb_scatter_chunk(const View &v, const Edge &e, uint64_t k0, const ChainTable *stb, uint64_t j, uint64_t wend,
+                              Edge *__restrict__ dst, uint64_t dst_bias, uint32_t *dst_leafcnt, int dst_sh, uint64_t dst_leaf_bias,
+                              int lane, uint64_t lt_mask, int *hint, int *hint2, int *hint3) {
+  const bool nn = e.value != 0;
+  const uint64_t m = wv::ballot(nn);
+  if (m == 0) return;
+  const uint32_t cn = (uint32_t)wv::popc64(m);
+  const uint64_t below = m & lt_mask;
+  const uint32_t i = (uint32_t)wv::popc64(below);
+  uint64_t A, D;
+  int shift;
+  uint64_t pos = 0, nxt = 0;
+  if (chain_linear_run(stb, k0, (k0 + cn <= j - 1) ? cn : cn - 1, hint3, &A, &D, &shift)) {
+    const uint64_t M = A + (uint64_t)i * D;
+    pos = M >> shift;
+    nxt = (k0 + i + 1 < j) ? ((M + D) >> shift) : wend;
+  } else if (nn) {
+    pos = chain_pos(stb, k0 + i, hint);
+    nxt = (k0 + i + 1 < j) ? chain_pos(stb, k0 + i + 1, hint2) : wend;
+  }
+  if (nn) {
+    dst[pos - dst_bias] = e;
+    for (uint64_t s2 = pos + 1; s2 < nxt; s2++) dst[s2 - dst_bias] = null_edge();
+    dev::fix_sentinel(v, e, (uint32_t)pos);
+  }
+  // destination leaf counts: the first live lane of every destination leaf adds that leaf's share of this chunk
+  const uint32_t mylf = (uint32_t)(pos >> dst_sh);
+  const int prevlane = below ? 63 - __builtin_clzll(below) : lane;
+  const uint32_t prevlf = wv::shfl(mylf, prevlane);
+  const bool head = nn && (below == 0 || prevlf != mylf);
+  const uint64_t hm = wv::ballot(head);
+  if (head) {
+    const uint64_t later_heads = hm & ~lt_mask & ~(1ull << lane);
+    const uint64_t upto = later_heads ? ((1ull << wv::ctz64(later_heads)) - 1ull) : ~0ull;
+    wv::atomic_add_u32(&dst_leafcnt[(uint64_t)mylf - dst_leaf_bias], (uint32_t)wv::popc64(m & upto & ~lt_mask));
+  }
+}
+
+// kRbBatch chunks are requested back to back before the first one is processed: the kernel is bound by memory latency
+// per wave (load -> rank -> store -> store acknowledgement), so bytes in flight per wave are what buys bandwidth.
+constexpr int kRbBatch = 4;
+PMA_KERNEL void k_rb_scatter(View v, const Edge *__restrict__ src, uint64_t src_lo, uint64_t src_len, int src_sh,
+                             const uint32_t *__restrict__ cnt, uint32_t tile_leaves, uint32_t batch,
+                             const uint32_t *__restrict__ tile_excl, const ChainTable *tb, Edge *__restrict__ dst, uint64_t dst_bias,
+                             uint32_t *dst_leafcnt, int dst_sh, uint64_t dst_leaf_bias) {
   PMA_SHARED ChainTable stb;
   PMA_SHARED uint32_t pre[kRbTile];
   PMA_SHARED uint32_t wsum[4];
   {
     const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
-    uint32_t *s = reinterpret_cast<uint32_t *>(&stb);
+    uint32_t *sp = reinterpret_cast<uint32_t *>(&stb);
     const uint32_t words = (uint32_t)((sizeof(ChainTable) - sizeof(ChainSeg) * (size_t)(kMaxSeg - tb->nseg)) / 4);
-    for (uint32_t i = wv::thread_idx(); i < words; i += wv::block_dim()) s[i] = g[i];
+    for (uint32_t i = wv::thread_idx(); i < words; i += wv::block_dim()) sp[i] = g[i];
   }
   const int lane = wv::lane(), w = wv::wave_in_block();
   const uint64_t tile = wv::block_idx();
   const uint64_t nleaves = src_len >> src_sh;
-  {  // exclusive prefix of this tile's leaf counts (256 leaves = one per thread)
-    const uint64_t l = tile * kRbTile + wv::thread_idx();
-    const uint32_t x = (l < nleaves) ? cnt[l] : 0u;
+  {  // exclusive prefix of this tile's leaf counts (one leaf per thread)
+    const uint64_t l = tile * tile_leaves + wv::thread_idx();
+    const uint32_t x = (wv::thread_idx() < tile_leaves && l < nleaves) ? cnt[l] : 0u;
     uint32_t incl = x;
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
@@ -684,43 +737,34 @@ PMA_KERNEL void k_rb_scatter(View v, const Edge *src, uint64_t src_lo, uint64_t 
   }
   const uint64_t base_rank = tile_excl[tile];
   const uint32_t lpc = 64u >> src_sh;               // leaves per 64-slot chunk (logN <= 32)
-  const uint32_t chunks = kRbTile / lpc;            // chunks in this tile
-  const uint64_t tile_slot0 = (tile * kRbTile) << src_sh;
+  const uint32_t chunks = tile_leaves / lpc;        // chunks in this tile
+  const uint64_t tile_slot0 = (tile * tile_leaves) << src_sh;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;   // lanes below this one
   int hint = 0, hint2 = 0, hint3 = 0;
-  for (uint32_t c = (uint32_t)w; c < chunks; c += 4) {
-    const uint64_t off0 = tile_slot0 + (uint64_t)c * 64;
-    if (off0 >= src_len) break;
-    const uint64_t off = off0 + (uint64_t)lane;
-    Edge e = null_edge();
-    if (off < src_len) e = src[src_lo + off];
-    const uint64_t k0 = base_rank + pre[c * lpc];
-    const bool nn = e.value != 0;
-    const uint64_t m = wv::ballot(nn);
-    if (m == 0) continue;
-    const uint32_t cn = (uint32_t)wv::popc64(m);
-    const uint32_t i = dev::lanemask_lt_count(m, lane);
-    uint64_t A, D;
-    int shift;
-    uint64_t pos = 0, nxt = 0;
-    if (chain_linear_run(&stb, k0, (k0 + cn <= j - 1) ? cn : cn - 1, &hint3, &A, &D, &shift)) {
-      pos = (A + (uint64_t)i * D) >> shift;
-      nxt = (k0 + i + 1 < j) ? ((A + (uint64_t)(i + 1) * D) >> shift) : wend;
-    } else if (nn) {
-      pos = chain_pos(&stb, k0 + i, &hint);
-      nxt = (k0 + i + 1 < j) ? chain_pos(&stb, k0 + i + 1, &hint2) : wend;
+  if (batch >= (uint32_t)kRbBatch) {
+    for (uint32_t c0 = (uint32_t)w * kRbBatch; c0 < chunks; c0 += 4 * kRbBatch) {
+      Edge e[kRbBatch];
+#pragma unroll
+      for (int q = 0; q < kRbBatch; q++) {
+        const uint64_t off = tile_slot0 + (uint64_t)(c0 + q) * 64 + (uint64_t)lane;
+        e[q] = null_edge();
+        if (c0 + q < chunks && off < src_len) e[q] = src[src_lo + off];
+      }
+#pragma unroll
+      for (int q = 0; q < kRbBatch; q++) {
+        if (c0 + q < chunks)
+          rb_scatter_chunk(v, e[q], base_rank + pre[(c0 + q) * lpc], &stb, j, wend, dst, dst_bias, dst_leafcnt, dst_sh, dst_leaf_bias,
+                           lane, lt_mask, &hint, &hint2, &hint3);
+      }
     }
-    if (nn) {
-      dst[pos - dst_bias] = e;
-      for (uint64_t s2 = pos + 1; s2 < nxt; s2++) dst[s2 - dst_bias] = null_edge();
-      dev::fix_sentinel(v, e, (uint32_t)pos);
-    }
-    const int lfirst = wv::ctz64(m), llast = 63 - __builtin_clzll(m);
-    const uint64_t l0 = (((uint64_t)wv::shfl((uint32_t)(pos >> 32), lfirst) << 32) | wv::shfl((uint32_t)pos, lfirst)) >> dst_sh;
-    const uint64_t l1 = (((uint64_t)wv::shfl((uint32_t)(pos >> 32), llast) << 32) | wv::shfl((uint32_t)pos, llast)) >> dst_sh;
-    const uint64_t mylf = pos >> dst_sh;
-    for (uint64_t L = l0; L <= l1; L++) {
-      const uint64_t mm = wv::ballot(nn && mylf == L);
-      if (mm && lane == 0) wv::atomic_add_u32(&dst_leafcnt[L - dst_leaf_bias], (uint32_t)wv::popc64(mm));
+  } else {
+    for (uint32_t c = (uint32_t)w; c < chunks; c += 4) {
+      const uint64_t off = tile_slot0 + (uint64_t)c * 64 + (uint64_t)lane;
+      if (off - lane >= src_len) break;
+      Edge e = null_edge();
+      if (off < src_len) e = src[src_lo + off];
+      rb_scatter_chunk(v, e, base_rank + pre[c * lpc], &stb, j, wend, dst, dst_bias, dst_leafcnt, dst_sh, dst_leaf_bias, lane, lt_mask,
+                       &hint, &hint2, &hint3);
     }
   }
 }

@@ -20,6 +20,15 @@ N = e.geometry()[0]
 for w in (N, N // 2, N // 16):
     ms = e.bench_rebalance(w, 10)
     print(f"rebalance window {w}: {ms*1e3:.1f} us  -> {24.0*w/ms/1e6:.0f} GB/s algorithmic ({24.0*w/ms/1e6/80:.1f} % of 8 TB/s)")
+if os.environ.get("PPCSR_SWEEP"):
+    for pf in (0, 1):
+        for tile in (32, 64, 128, 256):
+            e.set_option("rb_prefetch", pf)
+            e.set_option("rb_tile", tile)
+            r = [e.bench_rebalance(w, 10) * 1e3 for w in (N, N // 2, N // 16, N // 128)]
+            print(f"prefetch={pf} tile={tile}: " + "  ".join(f"{x:.1f}us" for x in r))
+    e.set_option("rb_tile", 0)
+    e.set_option("rb_prefetch", 1)
 for _ in range(3):
     ms, tot = e.bench_scan_all()
 stt = e.stats()
