@@ -51,7 +51,7 @@ struct Engine::Impl {
   unsigned long long *d_total = nullptr, *h_total = nullptr;
   ChainTable *d_table = nullptr;
   unsigned long long *d_scan_state = nullptr;
-  uint64_t scan_state_cap = 0;
+  uint64_t scan_state_cap = 0, scan_nchunks = 0;
   Edge *d_scratch = nullptr;  // persistent destination of big in-place rebalances
   uint64_t scratch_cap = 0;
   int *d_nbr = nullptr;
@@ -774,7 +774,11 @@ int Engine::ensure_scratch(uint64_t nleaves) {
     GCHK(gpu::dmalloc((void **)&p.d_rank, nleaves * sizeof(uint32_t)));
     p.rank_cap = nleaves;
   }
-  const uint64_t ntiles = (nleaves + kScanTile - 1) / kScanTile;
+  return ensure_tiles((nleaves + kScanTile - 1) / kScanTile);
+}
+
+int Engine::ensure_tiles(uint64_t ntiles) {
+  Impl &p = *p_;
   if (ntiles > p.tiles_cap) {
     if (p.d_tiles) GPU_DFREE(p.d_tiles);
     p.d_tiles = nullptr;
@@ -792,7 +796,7 @@ int Engine::rank_scan(const uint32_t *d_cnt, uint64_t nleaves, bool table, uint6
   if (rc != PPCSR_OK) return rc;
   const uint64_t ntiles = (nleaves + kScanTile - 1) / kScanTile;
   GPU_LAUNCH(p.stream, k_scan_tiles, ntiles, 256, d_cnt, nleaves, p.d_tiles);
-  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, 128, p.d_tiles, ntiles, p.d_total, table ? p.d_table : (ChainTable *)nullptr, tb_index, tb_len);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, table ? p.d_table : (ChainTable *)nullptr, tb_index, tb_len);
   GPU_LAUNCH(p.stream, k_scan_apply, ntiles, 256, d_cnt, nleaves, (const uint32_t *)p.d_tiles, p.d_rank);
   return PPCSR_OK;
 }
@@ -815,11 +819,12 @@ int Engine::rebalance_fused(const View &nv, const Edge *src_items, uint64_t src_
   if (tile < lpc) tile = lpc;
   if (tile > kRbTile) tile = kRbTile;
   const uint64_t ntiles = (nleaves + tile - 1) / tile;
-  int rc = ensure_scratch(std::max<uint64_t>(nleaves, ntiles * kScanTile));  // d_tiles >= ntiles entries, d_rank >= nleaves
+  int rc = ensure_scratch(nleaves);  // d_rank parks the source counts of an in-place window
+  if (rc == PPCSR_OK) rc = ensure_tiles(ntiles);
   if (rc != PPCSR_OK) return rc;
   GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, src_cnt, nleaves, tile, p.d_tiles, inplace ? p.d_rank : (uint32_t *)nullptr,
              inplace ? (uint32_t *)nullptr : dst_cnt, inplace ? (uint64_t)0 : dst_nleaves);
-  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, 128, p.d_tiles, ntiles, p.d_total, p.d_table, tb_index, tb_len);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, tb_index, tb_len);
   GPU_LAUNCH(p.stream, k_rb_scatter, ntiles, 256, nv, src_items, src_lo, src_len, src_sh,
              inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, tile, p.rb_prefetch ? 4u : 1u, (const uint32_t *)p.d_tiles,
              (const ChainTable *)p.d_table, dst, dst_bias, dst_cnt, nv.g.sh, (uint64_t)0);
@@ -1023,6 +1028,8 @@ int Engine::read_neighbourhood(int src) {
 int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap) {
   Impl &p = *p_;
   const uint64_t N = p.v.g.N, nchunks = (N + 63) / 64;
+  bool fresh_state = (p.scan_nchunks != nchunks);  // the sentinel counts are laid out (and left zeroed) per array size
+  p.scan_nchunks = nchunks;
   if (p.scan_state_cap < 2 * nchunks) {
     if (p.d_scan_state) GPU_DFREE(p.d_scan_state);
     p.d_scan_state = nullptr;
@@ -1031,14 +1038,17 @@ int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap) {
     p.scan_state_cap = 2 * nchunks;
   }
   uint32_t *d_cs = reinterpret_cast<uint32_t *>(p.d_scan_state), *d_cc = d_cs + nchunks;
-  int rc = ensure_scratch(nchunks);
+  // tile of chunks per workgroup: as large as the workgroup while the array still yields thousands of tiles
+  uint32_t tile = 256;
+  while (tile > 16 && nchunks / tile < p.rb_min_tiles) tile >>= 1;
+  const uint64_t ntiles = (nchunks + tile - 1) / tile;
+  int rc = ensure_tiles(ntiles);
   if (rc != PPCSR_OK) return rc;
-  GCHK(gpu::dset(d_cs, 0, nchunks * sizeof(uint32_t), p.stream));
+  if (fresh_state) GCHK(gpu::dset(d_cs, 0, nchunks * sizeof(uint32_t), p.stream));  // later scans find it zeroed (k_chunk_counts)
   GPU_LAUNCH(p.stream, k_chunk_sentinels, grid_for(n(), 256), 256, p.v, d_cs);
-  GPU_LAUNCH(p.stream, k_chunk_counts, grid_for(nchunks, 256), 256, p.v, (const uint32_t *)d_cs, d_cc);
-  rc = rank_scan(d_cc, nchunks);
-  if (rc != PPCSR_OK) return rc;
-  GPU_LAUNCH(p.stream, k_scan_write, grid_for(nchunks, 4), 256, p.v, (const uint32_t *)p.d_rank, d_rows, d_dst, cap);
+  GPU_LAUNCH(p.stream, k_chunk_counts, ntiles, 256, p.v, d_cs, d_cc, tile, p.d_tiles);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, (ChainTable *)nullptr, (uint64_t)0, (uint64_t)0);
+  GPU_LAUNCH(p.stream, k_scan_write, ntiles, 256, p.v, (const uint32_t *)d_cc, tile, (const uint32_t *)p.d_tiles, d_rows, d_dst, cap);
   return PPCSR_OK;
 }
 

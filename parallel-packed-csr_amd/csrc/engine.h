@@ -68,6 +68,7 @@ class Engine {
   int big_redistribute(uint64_t wstart, uint64_t wlen, bool sync = true);
   int rank_scan(const uint32_t *d_cnt, uint64_t nleaves, bool table = false, uint64_t tb_index = 0, uint64_t tb_len = 0);
   int ensure_scratch(uint64_t nleaves);
+  int ensure_tiles(uint64_t ntiles);
   int fail(int code, const std::string &msg);
   int pull_stats();
 

@@ -123,6 +123,22 @@ PMA_HD inline double chain_sub(double x, double step) {
   return x - step;
 }
 
+// floor(a / b) for a, b < 2^53, b > 0: one fp64 division plus an exact integer fix-up (a 64-bit integer division is a
+// ~100-instruction software routine on the GPU and this sits on the table build's serial path)
+PMA_HD inline uint64_t div_floor_u53(uint64_t a, uint64_t b) {
+  uint64_t q = (uint64_t)((double)a / (double)b);
+  int64_t r = (int64_t)(a - q * b);
+  while (r < 0) {
+    q--;
+    r += (int64_t)b;
+  }
+  while (r >= (int64_t)b) {
+    q++;
+    r -= (int64_t)b;
+  }
+  return q;
+}
+
 PMA_HD inline void build_chain_table(uint64_t index, uint64_t len, uint64_t j, ChainTable *tb) {
   tb->index = index;
   tb->len = len;
@@ -179,7 +195,7 @@ PMA_HD inline void build_chain_table(uint64_t index, uint64_t len, uint64_t j, C
       if (M0 >= Th && Dr > 0) {
         const uint64_t M1 = M0 - Df;
         c = 1;
-        if (M1 >= Th) c += (M1 - Th) / Dr + 1;
+        if (M1 >= Th) c += div_floor_u53(M1 - Th, Dr) + 1;
       }
       sg.Dfirst = Df;
       sg.Drest = Dr;

@@ -414,14 +414,16 @@ PMA_KERNEL void k_scan_tiles(const uint32_t *cnt, uint64_t nleaves, uint32_t *ti
   wv::block_sync();
   if (wv::thread_idx() == 0) tilesum[b] = red[0] + red[1] + red[2] + red[3];
 }
+constexpr uint32_t kTileSumThreads = 1024;
 PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned long long *total, ChainTable *tb,
                                 uint64_t tb_index, uint64_t tb_len) {
-  // one workgroup of two waves.  Each lane owns a contiguous run of tile sums, so all of its loads are independent and in
-  // flight together; wave 0 writes the exclusive prefix back while wave 1 builds the rebalance's exact position table
-  // from the grand total (saves a launch).
+  // ONE workgroup of kTileSumThreads.  Each thread owns a contiguous run of tile sums (independent loads, all in
+  // flight together); waves combine through LDS; the prefix is written back while one lane builds the rebalance's exact
+  // position table from the grand total (saves a launch).
+  PMA_SHARED uint32_t wtot[kTileSumThreads / 64];
   const int lane = wv::lane(), w = wv::wave_in_block();
-  const uint64_t per = (ntiles + 63) / 64;
-  const uint64_t lo = (uint64_t)lane * per;
+  const uint64_t per = (ntiles + kTileSumThreads - 1) / kTileSumThreads;
+  const uint64_t lo = (uint64_t)wv::thread_idx() * per;
   const uint64_t hi = (lo + per < ntiles) ? lo + per : ntiles;
   uint32_t mine = 0;
   for (uint64_t i = lo; i < hi; i++) mine += tilesum[i];
@@ -430,18 +432,23 @@ PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned lon
     const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
     if (lane >= o) incl += y;
   }
-  const uint32_t grand = wv::shfl(incl, 63);
-  wv::block_sync();  // every read of the un-scanned sums is done before wave 0 overwrites them
-  if (w == 0) {
-    uint32_t run = incl - mine;
-    for (uint64_t i = lo; i < hi; i++) {
-      const uint32_t x = tilesum[i];
-      tilesum[i] = run;
-      run += x;
-    }
-    if (lane == 0) *total = grand;
-  } else if (lane == 0 && tb) {
-    build_chain_table(tb_index, tb_len, (uint64_t)grand, tb);
+  if (lane == 63) wtot[w] = incl;
+  wv::block_sync();  // also: every read of the un-scanned sums is done before anyone overwrites them
+  uint32_t woff = 0, grand = 0;
+  for (int q = 0; q < (int)(kTileSumThreads / 64); q++) {
+    const uint32_t x = wtot[q];
+    if (q < w) woff += x;
+    grand += x;
+  }
+  if (wv::thread_idx() == kTileSumThreads - 1) {  // (this thread's own run is the shortest or empty)
+    *total = grand;
+    if (tb) build_chain_table(tb_index, tb_len, (uint64_t)grand, tb);
+  }
+  uint32_t run = woff + incl - mine;
+  for (uint64_t i = lo; i < hi; i++) {
+    const uint32_t x = tilesum[i];
+    tilesum[i] = run;
+    run += x;
   }
 }
 PMA_KERNEL void k_scan_apply(const uint32_t *cnt, uint64_t nleaves, const uint32_t *tilesum, uint32_t *rank) {
@@ -821,23 +828,47 @@ PMA_KERNEL void k_neighbourhood(View v, uint32_t src, int *outbuf, uint64_t cap,
 // (one atomic per vertex on a 4 B/chunk histogram), minus slot N-1 which is never part of a neighbourhood
 PMA_KERNEL void k_chunk_sentinels(View v, uint32_t *chunk_sent) {
   // sentinel positions increase with the vertex id, so the sentinels of one chunk are a run of consecutive vertices:
-  // the first vertex of each run counts the run and stores it (no atomics; chunks without sentinels stay 0)
+  // the first vertex of each run counts the run and stores it (no atomics; chunks without sentinels stay 0).  Runs are
+  // measured inside the wave with one ballot; the wave's last run may continue into the next 64 vertices (isolated
+  // vertices sit shoulder to shoulder, up to 64 per chunk) and is finished with one more 64-wide probe.
   const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
   const uint64_t n = v.g.n;
-  for (uint64_t k = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); k < n; k += stride) {
-    const uint32_t ch = v.nodes[k].beginning >> 6;
-    if (k > 0 && (v.nodes[k - 1].beginning >> 6) == ch) continue;
-    uint32_t run = 1;
-    while (k + run < n && (v.nodes[k + run].beginning >> 6) == ch) run++;
-    chunk_sent[ch] = run;
+  const int lane = wv::lane();
+  for (uint64_t base = (uint64_t)wv::block_idx() * wv::block_dim() + (wv::thread_idx() & ~63u); base < n; base += stride) {
+    const uint64_t k = base + (uint64_t)lane;
+    const bool valid = k < n;
+    const uint32_t ch = valid ? (v.nodes[k].beginning >> 6) : kMax;
+    uint32_t prev = wv::shfl(ch, lane == 0 ? 0 : lane - 1);
+    if (lane == 0) prev = (k > 0) ? (v.nodes[k - 1].beginning >> 6) : kMax;
+    const bool head = valid && (k == 0 || prev != ch);
+    const uint64_t hm = wv::ballot(head);
+    const int nvalid = wv::popc64(wv::ballot(valid));
+    if (hm == 0) continue;  // the whole wave lies inside a run that an earlier wave counts
+    const int lh = 63 - __builtin_clzll(hm);  // the wave's last run starts here
+    if (head && lane != lh) {
+      const uint64_t later = (hm >> (lane + 1)) << (lane + 1);
+      chunk_sent[ch] = (uint32_t)(wv::ctz64(later) - lane);
+    }
+    const uint32_t chl = wv::shfl(ch, lh);
+    uint32_t run = (uint32_t)(nvalid - lh);
+    if (nvalid == 64) {  // a chunk holds at most 64 sentinels, so one probe of the next 64 vertices finishes the run
+      const uint64_t k2 = base + 64 + (uint64_t)lane;
+      const bool same = k2 < n && (v.nodes[k2].beginning >> 6) == chl;
+      const uint64_t diff = wv::ballot(!same);
+      run += diff ? (uint32_t)wv::ctz64(diff) : 64u;
+    }
+    if (lane == lh) chunk_sent[chl] = run;
   }
 }
-PMA_KERNEL void k_chunk_counts(View v, const uint32_t *chunk_sent, uint32_t *chunkcnt) {
+// live-edge count of every 64-slot chunk (leaf counts minus sentinels; slot N-1 is never part of a neighbourhood) and
+// the sum over each tile of `tile_chunks` chunks; chunk_sent is left zeroed for the next scan
+PMA_KERNEL void k_chunk_counts(View v, uint32_t *chunk_sent, uint32_t *chunkcnt, uint32_t tile_chunks, uint32_t *tilesum) {
+  PMA_SHARED uint32_t red[4];
   const uint64_t N = v.g.N, nchunks = (N + 63) / 64;
   const uint32_t lpc = (v.g.logN >= 64) ? 1u : (64u >> v.g.sh);  // leaves per chunk
-  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
-  for (uint64_t ch = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); ch < nchunks; ch += stride) {
-    uint32_t c = 0;
+  const uint64_t ch = (uint64_t)wv::block_idx() * tile_chunks + wv::thread_idx();
+  uint32_t c = 0;
+  if (wv::thread_idx() < tile_chunks && ch < nchunks) {
     if (v.g.logN >= 64) {
       c = v.leafcnt[(ch * 64) >> v.g.sh];  // (logN = 64 only for N >= 2^32: not reachable, kept for completeness)
     } else {
@@ -847,34 +878,69 @@ PMA_KERNEL void k_chunk_counts(View v, const uint32_t *chunk_sent, uint32_t *chu
       }
     }
     c -= chunk_sent[ch];
+    chunk_sent[ch] = 0u;
     if (ch == nchunks - 1) {
       const Edge e = v.items[N - 1];
       if (e.value != 0 && !is_sentinel(e)) c -= 1u;
     }
     chunkcnt[ch] = c;
   }
+  const uint32_t s = wv::reduce_add(c);
+  if (wv::lane() == 0) red[wv::wave_in_block()] = s;
+  wv::block_sync();
+  if (wv::thread_idx() == 0) tilesum[wv::block_idx()] = red[0] + red[1] + red[2] + red[3];
 }
-// bulk neighbour scan (CSR export), final streaming pass: after the exclusive scan of the per-chunk live-edge counts
-// (k_chunk_sentinels / k_chunk_counts below + the rank scan) write dests in array order == CSR order and the row
-// offsets at the sentinels.  Slot N-1 is never part of a neighbourhood (the last vertex's end is N-1, exclusive).
-PMA_KERNEL void k_scan_write(View v, const uint32_t *chunkoff, unsigned long long *row_offsets, int *dests, uint64_t cap) {
-  const int lane = wv::lane();
+// bulk neighbour scan (CSR export), final streaming pass: one workgroup per tile of chunks.  The tile's chunk counts are
+// scanned in LDS (offset = scanned tile sum + in-tile prefix), then every wave streams its chunks — four in flight —
+// writing dests in array order == CSR order and the row offsets at the sentinels.
+PMA_KERNEL void k_scan_write(View v, const uint32_t *__restrict__ chunkcnt, uint32_t tile_chunks, const uint32_t *__restrict__ tile_excl,
+                             unsigned long long *__restrict__ row_offsets, int *__restrict__ dests, uint64_t cap) {
+  PMA_SHARED uint32_t pre[256];
+  PMA_SHARED uint32_t wsum[4];
+  const int lane = wv::lane(), w = wv::wave_in_block();
   const uint64_t N = v.g.N;
   const uint64_t nchunks = (N + 63) / 64;
-  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
-  for (uint64_t ch = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); ch < nchunks; ch += wstride) {
-    const uint64_t s = ch * 64 + (uint64_t)lane;
-    Edge e = null_edge();
-    if (s < N) e = v.items[s];
-    const bool nn = e.value != 0;
-    const bool sent = nn && is_sentinel(e);
-    const bool live = nn && !sent && (s + 1 < N);
-    const uint64_t m = wv::ballot(live);
-    const unsigned long long o = (unsigned long long)chunkoff[ch] + dev::lanemask_lt_count(m, lane);
-    if (live && o < cap) dests[o] = (int)e.dest;
-    if (sent) {
-      const uint32_t vid = (e.value == kMax) ? 0u : e.value;
-      row_offsets[vid] = o;
+  const uint64_t tile = wv::block_idx();
+  {
+    const uint64_t ch = tile * tile_chunks + wv::thread_idx();
+    const uint32_t x = (wv::thread_idx() < tile_chunks && ch < nchunks) ? chunkcnt[ch] : 0u;
+    uint32_t incl = x;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[w] = incl;
+    wv::block_sync();
+    uint32_t woff = 0;
+    for (int q = 0; q < w; q++) woff += wsum[q];
+    pre[wv::thread_idx()] = woff + incl - x;
+  }
+  wv::block_sync();
+  const unsigned long long base = tile_excl[tile];
+  const Edge *__restrict__ items = v.items;
+  constexpr int K = 4;
+  for (uint32_t c0 = (uint32_t)w * K; c0 < tile_chunks; c0 += 4 * K) {
+    Edge e[K];
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+      const uint64_t s = (tile * tile_chunks + c0 + q) * 64 + (uint64_t)lane;
+      e[q] = null_edge();
+      if (c0 + q < tile_chunks && s < N) e[q] = items[s];
+    }
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+      if (c0 + q >= tile_chunks) break;
+      const uint64_t s = (tile * tile_chunks + c0 + q) * 64 + (uint64_t)lane;
+      const bool nn = e[q].value != 0;
+      const bool sent = nn && is_sentinel(e[q]);
+      const bool live = nn && !sent && (s + 1 < N);
+      const uint64_t m = wv::ballot(live);
+      const unsigned long long o = base + pre[c0 + q] + dev::lanemask_lt_count(m, lane);
+      if (live && o < cap) dests[o] = (int)e[q].dest;
+      if (sent) {
+        const uint32_t vid = (e[q].value == kMax) ? 0u : e[q].value;
+        row_offsets[vid] = o;
+      }
     }
   }
 }

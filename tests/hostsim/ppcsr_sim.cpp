@@ -5,3 +5,26 @@
 #define PPCSR_SIM 1
 #include "engine.cc"
 #include "capi.cc"
+
+// test hook (emulator build only): the exact position table evaluated for every element of a window, so the table
+// construction and its look-ups can be checked against the oracle's serial fp64 chain without running an engine
+extern "C" int ppcsr_sim_chain_positions(uint64_t index, uint64_t len, uint64_t j, uint64_t *out, int *nseg, int *linear_ok) {
+  static ppcsr::ChainTable tb;
+  ppcsr::build_chain_table(index, len, j, &tb);
+  if (nseg) *nseg = tb.nseg;
+  if (tb.overflow) return 1;
+  int hint = 0;
+  for (uint64_t k = 0; k < j; k++) out[k] = ppcsr::chain_pos(&tb, k, &hint);
+  // every run of up to 64 consecutive elements that chain_linear_run accepts must reproduce the same positions
+  int ok = 1, h3 = 0;
+  for (uint64_t k0 = 1; k0 + 1 < j; k0 += 37) {
+    const uint64_t cnt = (k0 + 64 <= j - 1) ? 64 : (j - 1 - k0);
+    uint64_t A, D;
+    int shift;
+    if (ppcsr::chain_linear_run(&tb, k0, cnt, &h3, &A, &D, &shift))
+      for (uint64_t i = 0; i <= cnt; i++)
+        if (((A + i * D) >> shift) != out[k0 + i]) ok = 0;
+  }
+  if (linear_ok) *linear_ok = ok;
+  return 0;
+}

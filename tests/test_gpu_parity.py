@@ -240,6 +240,37 @@ def test_bucket_ops_device_matches_host_routing(pkg, streams):
         np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), hb)
 
 
+def test_scan_all_repeated_across_resizes(pkg, streams):
+    """bulk scan called repeatedly while the array doubles and halves (its scratch state is per array size); long runs
+    of isolated vertices (adjacent sentinels spanning several waves) included"""
+    n = 5000
+    eng, o = pkg.PCSR(n), Oracle(n)
+
+    def check():
+        rows, dests = eng.scan_all()
+        items, nodes = o.state()
+        live = (items[:, 2] != 0) & (items[:, 1] != 0xFFFFFFFF)
+        live[-1] = False
+        np.testing.assert_array_equal(dests, items[live, 1].astype(np.int32))
+        deg = np.add.reduceat(live.astype(np.int64), nodes[:, 0]) if len(dests) else np.zeros(n, np.int64)
+        np.testing.assert_array_equal(np.diff(rows.astype(np.int64)), deg)
+
+    check()
+    s, d = streams.rmat_edges(12, 60_000, seed=9)
+    adds = streams.adds(s + 700, d)  # vertices 0..699 and 4796.. stay isolated
+    for part in (adds[:3000], adds[3000:30000], adds[30000:]):
+        eng.apply(part)
+        o.apply(part)
+        check()
+        check()
+    dels = adds.copy()
+    dels[:, 2] = 0
+    eng.apply(dels[:55000])
+    o.apply(dels[:55000])
+    check()
+    assert eng.geometry() == o.geometry()
+
+
 def test_large_graph_properties(pkg, streams):
     """BASELINE-sized shape (scale-19 RMAT, 4 M-edge core + 1 M mixed updates) checked through size-independent
     properties of the reference's data structure instead of a slot-by-slot oracle comparison:

@@ -136,6 +136,66 @@ def test_sim_scan_all_and_queries(sim, streams):
         assert e.edge_exists(s, d) == o.edge_exists(s, d)
 
 
+def test_sim_scan_all_repeated_across_resizes(sim, streams):
+    """the bulk scan keeps per-array-size scratch state between calls: scan, grow (double_list), scan, shrink, scan;
+    isolated vertices (runs of adjacent sentinels longer than a wave) included"""
+    n = 300
+    e, o = sim(n), Oracle(n)
+
+    def check():
+        rows, dests = e.scan_all()
+        for v in range(n):
+            np.testing.assert_array_equal(dests[int(rows[v]):int(rows[v + 1])], o.get_neighbourhood(v))
+        assert int(rows[n]) == len(dests)
+
+    check()  # empty graph: nothing but sentinels
+    src = np.repeat(np.arange(100, 140, dtype=np.uint32), 60)
+    dst = np.tile(np.arange(60, dtype=np.uint32), 40)
+    adds = np.stack([src, dst, np.ones_like(src)], 1).astype(np.uint32)
+    for part in (adds[:700], adds[700:]):
+        e.apply(part)
+        o.apply(part)
+        check()
+        check()
+    dels = adds.copy()
+    dels[:, 2] = 0
+    e.apply(dels[:2300])
+    o.apply(dels[:2300])
+    check()
+    assert e.geometry() == o.geometry()
+
+
+def test_chain_table_matches_serial_fp64_chain():
+    """the piecewise-linear position table (built with the fp64-reciprocal division) == the oracle's serial `x -= step`
+    chain (PCSR.cpp:237-247), for windows up to 2^31 slots and densities across the PMA's range"""
+    import ctypes
+    from oracle_lib import oracle_lib
+    build_sim()
+    lib = ctypes.CDLL(SIM_SO)
+    c_u64 = ctypes.c_uint64
+    lib.ppcsr_sim_chain_positions.argtypes = [c_u64, c_u64, c_u64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int),
+                                              ctypes.POINTER(ctypes.c_int)]
+    L = oracle_lib()
+    rng = np.random.default_rng(5)
+    cases = [(0, 1 << 24, 10_000_000), (0, 1 << 24, 4_194_305), (1 << 30, 1 << 30, 3_000_001), (0, 1 << 31, 2_500_000),
+             (4096, 4096, 4095), (0, 8, 1), (0, 8, 2), (64, 64, 64), (12288, 8192, 3)]
+    for _ in range(60):
+        lg = int(rng.integers(3, 25))
+        ln = 1 << lg
+        idx = int(rng.integers(0, 1 << (30 - lg))) * ln
+        j = int(rng.integers(1, ln + 1))
+        cases.append((idx, ln, j))
+    for idx, ln, j in cases:
+        ref = np.zeros(j, np.uint64)
+        got = np.zeros(j, np.uint64)
+        L.po_redistribute_positions(idx, ln, j, ref.ctypes.data)
+        nseg, lin = ctypes.c_int(0), ctypes.c_int(0)
+        rc = lib.ppcsr_sim_chain_positions(idx, ln, j, got.ctypes.data, ctypes.byref(nseg), ctypes.byref(lin))
+        assert rc == 0, (idx, ln, j, nseg.value)
+        np.testing.assert_array_equal(got, ref, err_msg=f"window ({idx},{ln}) j={j}")
+        assert lin.value == 1, (idx, ln, j)
+
+
 def test_sim_bucket_kernels(streams):
     """the HIP owner-bucketing kernels (multi-GPU exchange) under the emulator vs the host routing routine"""
     import ctypes
