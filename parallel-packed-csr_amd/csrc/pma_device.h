@@ -100,7 +100,21 @@ PMA_DEV void rec_range(RangeRec &rr, const View &v, uint32_t slot_lo, uint32_t s
 PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32_t end, RangeRec &rr) {
   const int lane = wv::lane();
   const Edge *items = v.items;
+  // Once the interval fits one wave (<= 64 slots) it is loaded ONCE, lane l holding slot cbase + l, and the remaining
+  // levels probe that register copy through shuffles: same probes, same decisions, no further memory round trips.
+  bool cached = false;
+  uint32_t cbase = 0, cend = 0, cval = 0, cdst = 0;
   while (start + 1 < end) {
+    if (!cached && end - start <= 64) {
+      cbase = start;
+      cend = end;
+      const uint32_t s = start + (uint32_t)lane;
+      if (s < end) {
+        cval = items[s].value;
+        cdst = items[s].dest;
+      }
+      cached = true;
+    }
     const uint32_t mid = (start + end) / 2;
     bool found = false;
     uint32_t check = mid, idest = 0, dist = 0;
@@ -117,7 +131,14 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
         valid = (d <= mid - start);  // mid - d >= start
       }
       uint32_t val = 0, dst = 0;
-      if (valid) {
+      if (cached) {
+        const int from = valid ? (int)(slot - cbase) : 0;
+        const uint32_t tv = wv::shfl(cval, from), td = wv::shfl(cdst, from);
+        if (valid) {
+          val = tv;
+          dst = td;
+        }
+      } else if (valid) {
         val = items[slot].value;
         dst = items[slot].dest;
       }
@@ -147,9 +168,16 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
     if (dest < idest) end = check; else start = check;
   }
   if (end < start) start = end;
-  const Edge e = items[start];
+  uint32_t ev, ed;
+  if (cached && start >= cbase && start < cend) {
+    ev = wv::shfl(cval, (int)(start - cbase));
+    ed = wv::shfl(cdst, (int)(start - cbase));
+  } else {
+    ev = items[start].value;
+    ed = items[start].dest;
+  }
   rec_range(rr, v, start, start);
-  if (!is_null(e) && dest <= e.dest) return start;
+  if (ev != 0 && dest <= ed) return start;
   return end;
 }
 
@@ -333,11 +361,16 @@ PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, ui
     const uint32_t k = lanemask_lt_count(m, lane);
     uint64_t mypos = wstart;
     if (j >= 2) {
-      const double step = chain_step(wlen, j);
-      double x = chain_top(wstart, j, step);
-      for (uint32_t t = 0; t + 1 < j; t++) {
-        if (nn && k == j - 1 - t) mypos = (uint64_t)x;
-        x = chain_sub(x, step);
+      ChainSeg sg;
+      if (chain_single(wstart, wlen, j, &sg)) {  // closed form (every window that does not start at slot 0)
+        if (nn) mypos = chain_single_pos(sg, wstart, j, k);
+      } else {
+        const double step = chain_step(wlen, j);
+        double x = chain_top(wstart, j, step);
+        for (uint32_t t = 0; t + 1 < j; t++) {
+          if (nn && k == j - 1 - t) mypos = (uint64_t)x;
+          x = chain_sub(x, step);
+        }
       }
     }
     // LDS tile (SoA, stride-1): clear, scatter, gather
@@ -405,14 +438,20 @@ PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, ui
     if (j >= 2) {
       const double step = chain_step(wlen, j);
       double x = chain_top(wstart, j, step);
+      ChainSeg sg;
+      const bool single = chain_single(wstart, wlen, j, &sg);
       uint32_t khi = j - 1;
       while (khi >= 1) {
         const uint32_t klo = (khi >= 64) ? khi - 63 : 1;
         const uint32_t cntc = khi - klo + 1;
         uint64_t mypos = 0;
-        for (uint32_t i = 0; i < cntc; i++) {
-          if ((uint32_t)lane == i) mypos = (uint64_t)x;
-          x = chain_sub(x, step);
+        if (single) {
+          if ((uint32_t)lane < cntc) mypos = chain_single_pos(sg, wstart, j, khi - (uint32_t)lane);
+        } else {
+          for (uint32_t i = 0; i < cntc; i++) {
+            if ((uint32_t)lane == i) mypos = (uint64_t)x;
+            x = chain_sub(x, step);
+          }
         }
         const bool act = (uint32_t)lane < cntc;
         const uint32_t so = khi - (uint32_t)lane;  // source offset in the compacted tile
@@ -478,14 +517,20 @@ PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, ui
   if (j >= 2) {  // phase 2: spread right-to-left, 64 elements per step
     const double step = chain_step(wlen, j);
     double x = chain_top(wstart, j, step);
+    ChainSeg sg;
+    const bool single = chain_single(wstart, wlen, j, &sg);
     uint64_t khi = j - 1;
     while (khi >= 1) {
       const uint64_t klo = (khi >= 64) ? khi - 63 : 1;
       const uint32_t cntc = (uint32_t)(khi - klo + 1);
       uint64_t mypos = 0;
-      for (uint32_t i = 0; i < cntc; i++) {
-        if ((uint32_t)lane == i) mypos = (uint64_t)x;
-        x = chain_sub(x, step);
+      if (single) {
+        if ((uint32_t)lane < cntc) mypos = chain_single_pos(sg, wstart, j, khi - (uint64_t)lane);
+      } else {
+        for (uint32_t i = 0; i < cntc; i++) {
+          if ((uint32_t)lane == i) mypos = (uint64_t)x;
+          x = chain_sub(x, step);
+        }
       }
       const bool act = (uint32_t)lane < cntc;
       const uint64_t srcslot = wstart + (khi - (uint64_t)lane);

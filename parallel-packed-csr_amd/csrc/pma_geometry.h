@@ -139,6 +139,51 @@ PMA_HD inline uint64_t div_floor_u53(uint64_t a, uint64_t b) {
   return q;
 }
 
+// One segment of the chain starting at value x (a chain value, i.e. positive and finite): fills M0 / shift / Dfirst /
+// Drest and returns how many further steps (beyond the first value) stay on the segment's arithmetic progression.
+// S / es: mantissa (with the hidden bit) and unbiased exponent of `step`.
+PMA_HD inline uint64_t chain_segment(double x, uint64_t S, int es, ChainSeg *sg) {
+  const uint64_t xb = dbl_bits(x);
+  const int e = (int)((xb >> 52) & 0x7FF) - 1023;
+  const uint64_t M0 = (xb & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+  sg->M0 = M0;
+  sg->shift = 52 - e;
+  sg->pad = 0;
+  sg->Dfirst = sg->Drest = 0;
+  uint64_t c = 0;
+  const int r = e - es;
+  if (sg->shift >= 0 && r >= 0 && r <= 52) {
+    uint64_t q, rem, half;
+    if (r == 0) {
+      q = S;
+      rem = 0;
+      half = 1;
+    } else {
+      q = S >> r;
+      rem = S & ((1ull << r) - 1);
+      half = 1ull << (r - 1);
+    }
+    uint64_t Df, Dr;
+    if (rem < half) {
+      Df = Dr = q;
+    } else if (rem > half) {
+      Df = Dr = q + 1;
+    } else {  // exact tie: round to even mantissa
+      Df = (((M0 - q) & 1ull) == 0) ? q : q + 1;
+      Dr = ((q & 1ull) == 0) ? q : q + 1;
+    }
+    const uint64_t Th = (1ull << 52) + q + (rem ? 1 : 0);
+    if (M0 >= Th && Dr > 0) {
+      const uint64_t M1 = M0 - Df;
+      c = 1;
+      if (M1 >= Th) c += div_floor_u53(M1 - Th, Dr) + 1;
+    }
+    sg->Dfirst = Df;
+    sg->Drest = Dr;
+  }
+  return c;
+}
+
 PMA_HD inline void build_chain_table(uint64_t index, uint64_t len, uint64_t j, ChainTable *tb) {
   tb->index = index;
   tb->len = len;
@@ -160,46 +205,9 @@ PMA_HD inline void build_chain_table(uint64_t index, uint64_t len, uint64_t j, C
       tb->overflow = 1;
       return;
     }
-    const uint64_t xb = dbl_bits(x);
-    const int e = (int)((xb >> 52) & 0x7FF) - 1023;
-    const uint64_t M0 = (xb & 0xFFFFFFFFFFFFFull) | (1ull << 52);
     ChainSeg sg;
     sg.t0 = t;
-    sg.M0 = M0;
-    sg.shift = 52 - e;
-    sg.pad = 0;
-    sg.Dfirst = sg.Drest = 0;
-    uint64_t c = 0;
-    const int r = e - es;
-    if (sg.shift >= 0 && r >= 0 && r <= 52) {
-      uint64_t q, rem, half;
-      if (r == 0) {
-        q = S;
-        rem = 0;
-        half = 1;
-      } else {
-        q = S >> r;
-        rem = S & ((1ull << r) - 1);
-        half = 1ull << (r - 1);
-      }
-      uint64_t Df, Dr;
-      if (rem < half) {
-        Df = Dr = q;
-      } else if (rem > half) {
-        Df = Dr = q + 1;
-      } else {  // exact tie: round to even mantissa
-        Df = (((M0 - q) & 1ull) == 0) ? q : q + 1;
-        Dr = ((q & 1ull) == 0) ? q : q + 1;
-      }
-      const uint64_t Th = (1ull << 52) + q + (rem ? 1 : 0);
-      if (M0 >= Th && Dr > 0) {
-        const uint64_t M1 = M0 - Df;
-        c = 1;
-        if (M1 >= Th) c += div_floor_u53(M1 - Th, Dr) + 1;
-      }
-      sg.Dfirst = Df;
-      sg.Drest = Dr;
-    }
+    uint64_t c = chain_segment(x, S, es, &sg);
     if (c > T - t) c = T - t;
     sg.count = c;
     tb->seg[nseg++] = sg;
@@ -209,11 +217,34 @@ PMA_HD inline void build_chain_table(uint64_t index, uint64_t len, uint64_t j, C
       return;
     }
     // one true fp64 subtraction across the binade boundary
-    uint64_t Mc = (c == 0) ? M0 : (M0 - sg.Dfirst - (c - 1) * sg.Drest);
+    const uint64_t Mc = (c == 0) ? sg.M0 : (sg.M0 - sg.Dfirst - (c - 1) * sg.Drest);
+    const int e = 52 - sg.shift;
     double xc = bits_dbl(((uint64_t)(e + 1023) << 52) | (Mc & 0xFFFFFFFFFFFFFull));
     x = chain_sub(xc, step);
     t += 1;
   }
+}
+
+// Whole chain in ONE segment?  True for every window that does not straddle a power of two — i.e. all aligned PMA
+// windows except those starting at slot 0 — because every chain value then lies in [index, index+len) inside one
+// binade.  On success pos_k = chain_single_pos(sg, index, j, k) for 0 <= k < j, with no serial dependency.
+PMA_HD inline bool chain_single(uint64_t index, uint64_t len, uint64_t j, ChainSeg *sg) {
+  if (j < 2) return false;
+  const double step = chain_step(len, j);
+  const double x = chain_top(index, j, step);
+  const uint64_t sb = dbl_bits(step);
+  const int es = (int)((sb >> 52) & 0x7FF) - 1023;
+  const uint64_t S = (sb & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+  sg->t0 = 0;
+  const uint64_t c = chain_segment(x, S, es, sg);
+  sg->count = c;
+  return c >= j - 2;
+}
+PMA_HD inline uint64_t chain_single_pos(const ChainSeg &sg, uint64_t index, uint64_t j, uint64_t k) {
+  if (k == 0) return index;
+  const uint64_t d = j - 1 - k;
+  const uint64_t M = (d == 0) ? sg.M0 : (sg.M0 - sg.Dfirst - (d - 1) * sg.Drest);
+  return M >> sg.shift;
 }
 
 // position of element k (0 <= k < j) from the table; *hint is a segment cursor (monotone callers)

@@ -1144,8 +1144,7 @@ PMA_KERNEL void o_check(OptArgs a) {
   if (lane == 0) a.status[wid] = (anyfail ? 0u : OS_PASS) | (anybad ? OS_STAMP_BAD : 0u);
 }
 
-PMA_KERNEL void o_apply(OptArgs a) {
-  PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
+PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
   if (c->done || c->violation || c->excl || c->error) return;
@@ -1202,7 +1201,7 @@ PMA_KERNEL void o_apply(OptArgs a) {
     fprintf(stderr, "R%u commit idx=%u op=(%u,%u,%u) kind=%u index=%u gap=%u win=(%u,%u) wleaf=[%u,%u] nr=%u\n", a.round, idx, op.src,
             op.dst, op.op, kind, pl->index, pl->gap, pl->wstart, pl->wlen, pl->wleaf_lo, pl->wleaf_hi, pl->nr);
 #endif
-  dev::apply_op(a.v, op, pl, lds[wv::wave_in_block()], &a.stats[wv::block_idx() & (kStatShards - 1)]);
+  dev::apply_op(a.v, op, pl, lds_wave, &a.stats[wv::block_idx() & (kStatShards - 1)]);
   const uint32_t me1 = idx + 1u;
   if (kind_strong(kind)) {  // (a duplicate's value overwrite commutes with everything it can be reordered with: no stamp)
     const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
@@ -1220,14 +1219,20 @@ PMA_KERNEL void o_apply(OptArgs a) {
                                                 // per-update atomicMax on one word would serialise the whole round)
 }
 
-// one workgroup: stable compaction of the deferred updates into the next carry list + next round's bookkeeping
-PMA_KERNEL void o_compact(OptArgs a) {
-  PMA_SHARED uint32_t wsum[16];
-  PMA_SHARED uint32_t s_count;
+// stable compaction of the deferred updates into the next carry list + next round's bookkeeping
+// ONE workgroup; everything it needs is requested in one batch of independent loads (control block, then each thread's
+// run of statuses and indices), because at ~6 K entries this step is nothing but load latency.
+// kPer: slots per thread held in registers (covers a horizon of kPer * blockDim).  wsum: 16 words of LDS, s_first_p: 1.
+template <uint32_t kPer>
+PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
-  if (c->done || c->violation || c->excl || c->error) return;
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
   const uint32_t hor = c->hor[par], cn = c->carry_n[par], nf = c->next_fresh[par];
+  const uint32_t cur_h = c->cur_horizon, max_h = c->max_horizon, adaptive = c->adaptive, e1 = c->e1;
+  const unsigned long long gb = c->gbar[par];
+  const unsigned long long n_rounds = c->rounds, n_committed = c->committed, n_planned = c->planned;
+  if (f_done || f_viol || f_excl || f_err) return;
   const uint32_t used = cn < hor ? cn : hor;
   const uint32_t *cin = par ? a.carry1 : a.carry0;
   uint32_t *cout = par ? a.carry0 : a.carry1;
@@ -1238,11 +1243,29 @@ PMA_KERNEL void o_compact(OptArgs a) {
   const uint32_t per = (hor + bd - 1) / bd;
   const uint32_t s0 = tid * per;
   uint32_t mykeep = 0, mymaxc = 0;
-  for (uint32_t q = 0; q < per; q++) {
-    const uint32_t sl = s0 + q;
-    if (sl < hor) {
-      if (a.status[sl] != OS_COMMITTED) mykeep++;
-      else if (a.opidx[sl] + 1u > mymaxc) mymaxc = a.opidx[sl] + 1u;
+  uint32_t st[kPer], oi[kPer];
+  const bool regs = per <= kPer;
+  if (regs) {
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; q++) {
+      const uint32_t sl = s0 + q;
+      const bool in = q < per && sl < hor;
+      st[q] = in ? a.status[sl] : OS_COMMITTED;
+      oi[q] = in ? a.opidx[sl] : 0u;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; q++) {
+      const bool in = q < per && s0 + q < hor;
+      if (in && st[q] != OS_COMMITTED) mykeep++;
+      else if (in && oi[q] + 1u > mymaxc) mymaxc = oi[q] + 1u;
+    }
+  } else {
+    for (uint32_t q = 0; q < per; q++) {
+      const uint32_t sl = s0 + q;
+      if (sl < hor) {
+        if (a.status[sl] != OS_COMMITTED) mykeep++;
+        else if (a.opidx[sl] + 1u > mymaxc) mymaxc = a.opidx[sl] + 1u;
+      }
     }
   }
   // wave-level inclusive scan of the per-thread counts, then wave totals through LDS
@@ -1252,6 +1275,7 @@ PMA_KERNEL void o_compact(OptArgs a) {
     if (lane >= o) incl += y;
   }
   if (lane == 63) wsum[w] = incl;
+  if (tid == 0) *s_first_p = kMax;
   wv::block_sync();
   uint32_t woff = 0, tot = 0;
   for (uint32_t q = 0; q < nw; q++) {
@@ -1259,53 +1283,82 @@ PMA_KERNEL void o_compact(OptArgs a) {
     tot += wsum[q];
   }
   uint32_t o = woff + incl - mykeep;
-  for (uint32_t q = 0; q < per; q++) {
-    const uint32_t sl = s0 + q;
-    if (sl < hor && a.status[sl] != OS_COMMITTED) cout[o++] = a.opidx[sl];
+  if (regs) {
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; q++) {
+      if (q < per && s0 + q < hor && st[q] != OS_COMMITTED) {
+        if (o == 0) *s_first_p = oi[q];
+        cout[o++] = oi[q];
+      }
+    }
+  } else {
+    for (uint32_t q = 0; q < per; q++) {
+      const uint32_t sl = s0 + q;
+      if (sl < hor && a.status[sl] != OS_COMMITTED) {
+        const uint32_t x = a.opidx[sl];
+        if (o == 0) *s_first_p = x;
+        cout[o++] = x;
+      }
+    }
   }
   const uint32_t ncommitted = hor - tot;
-  if (tid == 0) s_count = tot;
-  wv::block_sync();
-  const uint32_t kept = s_count;
+  const uint32_t kept = tot;
   if (mymaxc) wv::atomic_max_u32(&c->maxc, mymaxc);  // <= 1024 atomics per round, only by threads that saw a commit
-  for (uint32_t i = used + tid; i < cn; i += bd) cout[kept + (i - used)] = cin[i];  // carry entries beyond the horizon
+  for (uint32_t i = used + tid; i < cn; i += bd) {  // carry entries beyond the horizon
+    const uint32_t x = cin[i];
+    if (kept + (i - used) == 0) *s_first_p = x;
+    cout[kept + (i - used)] = x;
+  }
   wv::block_sync();
   if (tid == 0) {
     const uint32_t new_cn = kept + (cn - used);
     const uint32_t new_nf = nf + (hor - used);
     // adaptive width: dependency chains bound the number of rounds, so planning far more updates than can commit only
     // makes every round slower; widen by 1/8 when > 85 % of the round committed, narrow by 1/8 when < 65 % did
-    uint32_t ch = c->cur_horizon ? c->cur_horizon : c->max_horizon;
-    if (c->adaptive && hor >= ch) {  // only full-width rounds carry information about the width
+    uint32_t ch = cur_h ? cur_h : max_h;
+    if (adaptive && hor >= ch) {  // only full-width rounds carry information about the width
       if (ncommitted * 100u > hor * 92u) ch += ch / 16u;
       else if (ncommitted * 100u < hor * 80u) ch -= ch / 16u;
     }
     if (ch < 1024u) ch = 1024u;
-    if (ch > c->max_horizon) ch = c->max_horizon;
+    if (ch > max_h) ch = max_h;
     c->cur_horizon = ch;
-    uint32_t nh = new_cn + (c->e1 - new_nf);
+    uint32_t nh = new_cn + (e1 - new_nf);
     if (nh > ch) nh = ch;
     c->carry_n[par ^ 1u] = new_cn;
     c->next_fresh[par ^ 1u] = new_nf;
     c->hor[par ^ 1u] = nh;
-    const unsigned long long gb = c->gbar[par];
     c->gbar[par ^ 1u] = ~0ull;
     c->gbar[par] = ~0ull;
-    if (new_cn == 0 && new_nf == c->e1) c->done = 1;
-    const uint32_t lowest = new_cn ? cout[0] : new_nf;
+    const bool done = (new_cn == 0 && new_nf == e1);
+    if (done) c->done = 1;
+    const uint32_t lowest = new_cn ? *s_first_p : new_nf;
     const uint32_t tag = (uint32_t)(make_key(a.round, 0) >> 32);
-    if (!c->done && (uint32_t)(gb >> 32) == tag && (uint32_t)gb == lowest) {
+    if (!done && (uint32_t)(gb >> 32) == tag && (uint32_t)gb == lowest) {
       c->excl = 1;
       c->excl_idx = lowest;
     }
-    if (c->rounds < 96) {
-      c->hist[2 * c->rounds] = hor;
-      c->hist[2 * c->rounds + 1] = ncommitted;
+    if (n_rounds < 96) {
+      c->hist[2 * n_rounds] = hor;
+      c->hist[2 * n_rounds + 1] = ncommitted;
     }
-    c->rounds += 1ull;
-    c->committed += (unsigned long long)ncommitted;
-    c->planned += (unsigned long long)hor;
+    c->rounds = n_rounds + 1ull;
+    c->committed = n_committed + (unsigned long long)ncommitted;
+    c->planned = n_planned + (unsigned long long)hor;
   }
+}
+
+PMA_KERNEL void o_apply(OptArgs a) {
+  PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
+  o_apply_wave(a, lds[wv::wave_in_block()]);
+}
+
+// (Folding the compaction into o_apply's last-finishing workgroup was measured and dropped: the device-scope fences the
+// ticket needs make every workgroup write back its XCD's L2, and the round got 3x slower than with a separate launch.)
+PMA_KERNEL void o_compact(OptArgs a) {
+  PMA_SHARED uint32_t wsum[16];
+  PMA_SHARED uint32_t s_first;
+  compact_block<8>(a, wsum, &s_first);
 }
 
 // ---- owner bucketing for the multi-GPU exchange (PPPCSR routing rule, PPPCSR.cpp:46-66) ----------------------------

@@ -25,6 +25,13 @@ extern "C" int ppcsr_sim_chain_positions(uint64_t index, uint64_t len, uint64_t 
       for (uint64_t i = 0; i <= cnt; i++)
         if (((A + i * D) >> shift) != out[k0 + i]) ok = 0;
   }
+  // closed form used by the in-wave rebalance: when the chain is a single segment it must give the same positions
+  ppcsr::ChainSeg sg;
+  if (j >= 2 && ppcsr::chain_single(index, len, j, &sg)) {
+    for (uint64_t k = 0; k < j; k++)
+      if (ppcsr::chain_single_pos(sg, index, j, k) != out[k]) ok = 0;
+    ok |= 2;  // bit 1: the window took the closed form
+  }
   if (linear_ok) *linear_ok = ok;
   return 0;
 }
