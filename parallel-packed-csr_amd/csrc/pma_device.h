@@ -72,6 +72,8 @@ struct RangeRec {  // read-leaf ranges collected by lane 0 into the plan record
   Plan *plan;
   uint32_t nr;
   uint32_t nlong = 0;
+  // register copy, lane r holding range r (r < 64): the planning kernel reserves from it without reading the record back
+  uint32_t my_lo = 1, my_hi = 0;
 };
 PMA_DEV void rec_range(RangeRec &rr, const View &v, uint32_t slot_lo, uint32_t slot_hi) {
   if (!rr.plan) return;
@@ -80,6 +82,10 @@ PMA_DEV void rec_range(RangeRec &rr, const View &v, uint32_t slot_lo, uint32_t s
     if (wv::lane() == 0) {
       rr.plan->rlo[rr.nr] = lo;
       rr.plan->rhi[rr.nr] = hi;
+    }
+    if ((uint32_t)wv::lane() == rr.nr) {
+      rr.my_lo = lo;
+      rr.my_hi = hi;
     }
     if (hi - lo >= kLongRange) rr.nlong++;
     rr.nr++;
@@ -97,7 +103,15 @@ PMA_DEV void rec_range(RangeRec &rr, const View &v, uint32_t slot_lo, uint32_t s
 // Gap-aware lower bound of `dest` in slots [start,end) (PCSR.cpp:427-502), one wave.
 // Lane p probes the p-th slot of the reference's probe sequence mid, mid+1, mid-1, mid+2, ... so the
 // first set bit of the ballot is exactly the slot the reference's scalar walk would stop at.
-PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32_t end, RangeRec &rr) {
+// *hit: what the search already knows about the slot it returns (saves the caller a dependent load): known = 1 with
+// value/dest of that slot, or known = 0.
+struct SearchHit {
+  uint32_t known, value, dest;
+};
+PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32_t end, RangeRec &rr, SearchHit *hit) {
+  hit->known = 0;
+  hit->value = 0;
+  hit->dest = 0;
   const int lane = wv::lane();
   const Edge *items = v.items;
   // Once the interval fits one wave (<= 64 slots) it is loaded ONCE, lane l holding slot cbase + l, and the remaining
@@ -117,7 +131,7 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
     }
     const uint32_t mid = (start + end) / 2;
     bool found = false;
-    uint32_t check = mid, idest = 0, dist = 0;
+    uint32_t check = mid, idest = 0, ival = 0, dist = 0;
     for (uint32_t pbase = 0;; pbase += 64) {
       const uint32_t p = pbase + (uint32_t)lane;
       const uint32_t d = (p + 1) >> 1;
@@ -147,6 +161,7 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
         const int pl = wv::ctz64(m);
         check = wv::shfl(slot, pl);
         idest = wv::shfl(dst, pl);
+        ival = wv::shfl(val, pl);
         dist = (pbase + (uint32_t)pl + 1) >> 1;
         found = true;
         break;
@@ -161,10 +176,26 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
       rec_range(rr, v, start, end - 1);
     }
     if (!found || check == start) {
-      if (found && dest <= idest) return check;
+      if (found && dest <= idest) {
+        hit->known = 1;
+        hit->value = ival;
+        hit->dest = idest;
+        return check;
+      }
+      // mid itself: the nearest live slot to it is `check` (or there is none), so unless mid == check it is null
+      hit->known = 1;
+      if (found && check == mid) {
+        hit->value = ival;
+        hit->dest = idest;
+      }
       return mid;
     }
-    if (dest == idest) return check;
+    if (dest == idest) {
+      hit->known = 1;
+      hit->value = ival;
+      hit->dest = idest;
+      return check;
+    }
     if (dest < idest) end = check; else start = check;
   }
   if (end < start) start = end;
@@ -177,19 +208,31 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
     ed = items[start].dest;
   }
   rec_range(rr, v, start, start);
-  if (ev != 0 && dest <= ed) return start;
+  if (ev != 0 && dest <= ed) {
+    hit->known = 1;
+    hit->value = ev;
+    hit->dest = ed;
+    return start;
+  }
+  if (cached && end >= cbase && end < cend) {
+    hit->known = 1;
+    hit->value = wv::shfl(cval, (int)(end - cbase));
+    hit->dest = wv::shfl(cdst, (int)(end - cbase));
+  }
   return end;
 }
 
 // first null slot in [from, N); returns N if none.  Stops (returns kMax) after `limit` slots.
-PMA_DEV uint32_t find_gap_right(const View &v, uint32_t from, uint32_t limit) {
+// pre / pre_nul: the caller has already loaded the first 64 slots (lane l: slot from + l is null)
+PMA_DEV uint32_t find_gap_right(const View &v, uint32_t from, uint32_t limit, bool pre = false, bool pre_nul = false) {
   const int lane = wv::lane();
   const uint64_t N = v.g.N;
   for (uint64_t base = from; base < N; base += 64) {
     if (base - from > limit) return kMax;
     const uint64_t s = base + (uint64_t)lane;
     bool nul = false;
-    if (s < N) nul = (v.items[s].value == 0);
+    if (pre && base == from) nul = pre_nul;
+    else if (s < N) nul = (v.items[s].value == 0);
     const uint64_t m = wv::ballot(nul);
     if (m) return (uint32_t)(base + (uint64_t)wv::ctz64(m));
   }
@@ -206,7 +249,9 @@ struct InsertPlan {
 
 // Emulation of acquire_insert_locks (PCSR.cpp:949-1134) for a single sequential caller.  The lock
 // range [min_node,max_node] is tracked only as far as it steers `tries`.
-PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, RangeRec &rr) {
+// c_leaf: leafcnt of index's leaf, gap_right: find_gap_right(index + 1) when occupied — both loaded by the caller in one
+// batch so that they do not sit one behind the other on the dependent-load chain.
+PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, uint32_t c_leaf, uint32_t gap_right, RangeRec &rr) {
   const Geometry &g = v.g;
   const int sh = g.sh;
   const uint64_t logN = (uint64_t)g.logN;
@@ -239,7 +284,7 @@ PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, Ran
     bool restart = false;
     // every leaf count consulted below is a READ of that leaf: record it, so that an earlier update of the same
     // round writing there is seen as a conflict even when the leaf ends up outside this update's own window
-    uint32_t c = v.leafcnt[node_index >> sh];
+    uint32_t c = c_leaf;
     rec_range(rr, v, (uint32_t)node_index, (uint32_t)node_index);
     if ((uint64_t)c + 1 == len) {  // leaf would become full (PCSR.cpp:1012-1023)
       const uint64_t new_idx = node_index & ~(2 * len - 1);
@@ -284,7 +329,7 @@ PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, Ran
     out.node_index_final = node_index;
     // leaves the slide will cross (PCSR.cpp:1085-1132)
     if (occupied) {
-      const uint32_t gap = find_gap_right(v, index + 1, kMaxSlide);
+      const uint32_t gap = gap_right;
       if (gap == kMax) {
         out.status = PS_SLIDE_LONG;
         return out;
@@ -585,7 +630,12 @@ PMA_DEV void slide_right_wave(const View &v, uint32_t index, uint32_t gap) {
 }
 
 // ---- full per-op planning (search + window plan) -------------------------------------------------------
-PMA_DEV void plan_op(const View &v, const Op op, Plan *plan) {
+// What the planning kernels need from the plan right away (the full record goes to memory for the later kernels)
+struct PlanRegs {
+  uint32_t kind, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, nr, nlong;
+  uint32_t my_lo, my_hi;  // lane r: read range r (r < 64)
+};
+PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
   const int lane = wv::lane();
   const Geometry &g = v.g;
   RangeRec rr;
@@ -599,23 +649,40 @@ PMA_DEV void plan_op(const View &v, const Op op, Plan *plan) {
     // (Plan::mv_lo/mv_hi of the writers, View::vw/vr), not through the leaves that hold them
     sleaf_b = nd.beginning >> g.sh;
     sleaf_e = nd.end >> g.sh;
-    index = pma_search(v, op.dst, nd.beginning + 1, nd.end, rr);
-    const Edge at = v.items[index];
-    const bool occupied = !is_null(at);
+    SearchHit hit;
+    index = pma_search(v, op.dst, nd.beginning + 1, nd.end, rr, &hit);
     const uint32_t leaf = index >> g.sh;
+    // one batch of independent loads: the slot the search returned (unless the search already knows it), its leaf's
+    // count, and — for an occupied slot — the first 64 slots of the gap search to the right
+    Edge at;
+    at.src = 0;
+    at.value = hit.value;
+    at.dest = hit.dest;
+    if (!hit.known) {
+      at.value = v.items[index].value;
+      at.dest = v.items[index].dest;
+    }
+    const uint32_t c_leaf = v.leafcnt[leaf];
+    bool nul0 = false;
+    if (op.op != 0) {
+      const uint64_t g0 = (uint64_t)index + 1ull + (uint64_t)lane;
+      if (g0 < g.N) nul0 = (v.items[g0].value == 0);
+    }
+    const bool occupied = !is_null(at);
     if (op.op != 0) {
       const Edge elem{op.src, op.dst, op.op};
       if (occupied && !is_sentinel(elem) && at.dest == op.dst) {
         kind = K_DUP;
         wl = wh = leaf;
       } else {
-        const InsertPlan ip = plan_insert(v, index, occupied, rr);
+        const uint32_t gap_right = occupied ? find_gap_right(v, index + 1, kMaxSlide, true, nul0) : index;
+        const InsertPlan ip = plan_insert(v, index, occupied, c_leaf, gap_right, rr);
         if (ip.status != PS_OK) {
           kind = K_EXCL;
         } else {
           gap = ip.gap;
           const uint32_t gleaf = gap >> g.sh;
-          const uint32_t cpost = v.leafcnt[leaf] + ((gleaf == leaf) ? 1u : 0u);
+          const uint32_t cpost = c_leaf + ((gleaf == leaf) ? 1u : 0u);
           uint64_t ws, wn;
           if (cpost == (uint32_t)g.logN) {  // PCSR.cpp:555-557
             wn = 2ull * (uint64_t)g.logN;
@@ -673,18 +740,37 @@ PMA_DEV void plan_op(const View &v, const Op op, Plan *plan) {
     const uint32_t whi = wstart + wlen - 1u;
     const uint32_t hi = (kind == K_INSERT && gap > whi) ? gap : whi;
     uint32_t down = 0, up = 0;
+    // both directions' first 64 vertices are requested together (one round trip for almost every update)
+    uint32_t bdn = 0, bup = 0;
+    const bool vdn = (uint32_t)lane <= op.src;
+    const uint64_t u0 = (uint64_t)op.src + 1ull + (uint64_t)lane;
+    const bool vup = u0 < g.n;
+    if (vdn) bdn = v.nodes[op.src - (uint32_t)lane].beginning;
+    if (vup) bup = v.nodes[u0].beginning;
+    uint32_t beg_lowest = 0;  // beginning of the lowest vertex found inside the range (vertex mv_lo)
     for (uint32_t base = 0;; base += 64) {  // downwards: src, src-1, ...
       const uint32_t k = base + (uint32_t)lane;
+      uint32_t bg = bdn;
       bool in = false;
-      if (k <= op.src) in = v.nodes[op.src - k].beginning >= lo;
+      if (base == 0) {
+        in = vdn && bg >= lo;
+      } else if (k <= op.src) {
+        bg = v.nodes[op.src - k].beginning;
+        in = bg >= lo;
+      }
       const uint64_t m = wv::ballot(in);
+      if (m) beg_lowest = wv::shfl(bg, 63 - __builtin_clzll(m));  // (the in-range vertices are a prefix of the lanes)
       down += (uint32_t)wv::popc64(m);
       if (m != ~0ull) break;
     }
     for (uint32_t base = 0;; base += 64) {  // upwards: src+1, src+2, ...
       const uint64_t u = (uint64_t)op.src + 1ull + base + (uint64_t)lane;
       bool in = false;
-      if (u < g.n) in = v.nodes[u].beginning <= hi;
+      if (base == 0) {
+        in = vup && bup <= hi;
+      } else if (u < g.n) {
+        in = v.nodes[u].beginning <= hi;
+      }
       const uint64_t m = wv::ballot(in);
       up += (uint32_t)wv::popc64(m);
       if (m != ~0ull) break;
@@ -693,7 +779,10 @@ PMA_DEV void plan_op(const View &v, const Op op, Plan *plan) {
     mv_hi = op.src + up;
     // the element at the first slot of the rebalance window keeps its slot (PCSR.cpp:240: "already in the correct
     // position"); a sentinel sitting there does not move unless the insert/slide displaces it
-    if (mv_lo <= mv_hi && v.nodes[mv_lo].beginning == wstart && (kind == K_REMOVE || index > wstart)) mv_lo++;
+    if (mv_lo <= mv_hi) {
+      const uint32_t b_lo = (down > 0) ? beg_lowest : v.nodes[mv_lo].beginning;
+      if (b_lo == wstart && (kind == K_REMOVE || index > wstart)) mv_lo++;
+    }
   }
   if (lane == 0) {
     plan->mv_lo = mv_lo;
@@ -712,6 +801,18 @@ PMA_DEV void plan_op(const View &v, const Op op, Plan *plan) {
     plan->nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
     plan->nlong = rr.nlong;
   }
+  PlanRegs pr;
+  pr.kind = kind;
+  pr.wlen = wlen;
+  pr.wleaf_lo = wl;
+  pr.wleaf_hi = wh;
+  pr.mv_lo = mv_lo;
+  pr.mv_hi = mv_hi;
+  pr.nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
+  pr.nlong = rr.nlong;
+  pr.my_lo = rr.my_lo;
+  pr.my_hi = rr.my_hi;
+  return pr;
 }
 
 // apply a planned op whose reservations were validated

@@ -63,16 +63,15 @@ PMA_KERNEL void k_plan(RoundArgs a) {
   const uint32_t idx = base + wid;
   const Op op = a.ops[idx];
   Plan *pl = &a.plans[wid];
-  dev::plan_op(a.v, op, pl);
-  wv::fence();
-  const uint32_t kind = pl->kind;
+  const dev::PlanRegs pr = dev::plan_op(a.v, op, pl);
+  const uint32_t kind = pr.kind;
   if (kind == K_DUP) {
-    if (wv::lane() == 0) wv::atomic_min_u64(&a.v.dres[pl->wleaf_lo], make_key(a.round, idx));
+    if (wv::lane() == 0) wv::atomic_min_u64(&a.v.dres[pr.wleaf_lo], make_key(a.round, idx));
   } else if (kind_strong(kind)) {
     const unsigned long long key = make_key(a.round, idx);
-    const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
+    const uint32_t wl = pr.wleaf_lo, wh = pr.wleaf_hi;
     for (uint32_t leaf = wl + (uint32_t)wv::lane(); leaf <= wh; leaf += 64) wv::atomic_min_u64(&a.v.wres[leaf], key);
-    const uint32_t ml = pl->mv_lo, mh = pl->mv_hi;  // sentinels this update may move
+    const uint32_t ml = pr.mv_lo, mh = pr.mv_hi;  // sentinels this update may move
     for (uint64_t u = (uint64_t)ml + (uint64_t)wv::lane(); u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_min_u64(&a.v.vw[u], key);
   }
 }
@@ -190,13 +189,15 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
       elem.dest = kMax;
       if (flags & XF_RESEARCH) {
         const Node nd = v.nodes[op.src];
-        index = dev::pma_search(v, kMax, nd.beginning + 1, nd.end, rr);
+        dev::SearchHit hit_;
+        index = dev::pma_search(v, kMax, nd.beginning + 1, nd.end, rr, &hit_);
       } else {
         index = op.dst;
       }
     } else {
       const Node nd = v.nodes[op.src];
-      index = dev::pma_search(v, op.dst, nd.beginning + 1, nd.end, rr);
+      dev::SearchHit hit_;
+      index = dev::pma_search(v, op.dst, nd.beginning + 1, nd.end, rr, &hit_);
       if (!(flags & XF_SKIP_COUNT) && lane == 0) wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 1u);
     }
     const Edge at = v.items[index];
@@ -216,7 +217,8 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
       ip.max_len = logN;
       ip.node_index_final = 0;
       if (!(flags & XF_FORCE_NOINFO) && !add_node) {
-        ip = dev::plan_insert(v, index, occupied, rr);
+        ip = dev::plan_insert(v, index, occupied, v.leafcnt[index >> g.sh],
+                              occupied ? dev::find_gap_right(v, index + 1, kMaxSlide) : index, rr);
         status = ip.status;
       }
       uint32_t gap = index;
@@ -307,7 +309,8 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
   } else {  // delete
     if (op.src < g.n) {
       const Node nd = v.nodes[op.src];
-      const uint32_t index = dev::pma_search(v, op.dst, nd.beginning + 1, nd.end, rr);
+      dev::SearchHit hit_;
+      const uint32_t index = dev::pma_search(v, op.dst, nd.beginning + 1, nd.end, rr, &hit_);
       if (!(flags & XF_SKIP_COUNT) && lane == 0) wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
       const Edge at = v.items[index];
       wv::fence();
@@ -792,7 +795,8 @@ PMA_KERNEL void k_edge_exists(View v, uint32_t src, uint32_t dst, ExclOut *out) 
   uint32_t found = 0;
   if (src < v.g.n) {
     const Node nd = v.nodes[src];
-    const uint32_t loc = dev::pma_search(v, dst, nd.beginning + 1, nd.end, rr);
+    dev::SearchHit hit_;
+    const uint32_t loc = dev::pma_search(v, dst, nd.beginning + 1, nd.end, rr, &hit_);
     const Edge e = v.items[loc];
     found = (!is_null(e) && !is_sentinel(e) && e.dest == dst) ? 1u : 0u;
   }
@@ -1002,8 +1006,9 @@ PMA_DEV bool key_earlier(unsigned long long k, uint32_t tag, uint32_t idx) { ret
 PMA_KERNEL void o_plan(OptArgs a) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
-  if (c->done || c->violation || c->excl || c->error) return;
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
   const uint32_t hor = c->hor[par], cn = c->carry_n[par], nf = c->next_fresh[par];
+  if (f_done || f_viol || f_excl || f_err) return;
   const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
   if (wid >= hor) return;
   const uint32_t used = cn < hor ? cn : hor;
@@ -1011,28 +1016,34 @@ PMA_KERNEL void o_plan(OptArgs a) {
   const uint32_t idx = (wid < used) ? carry[wid] : nf + (wid - used);
   const Op op = a.ops[idx];
   Plan *pl = &a.plans[wid];
-  dev::plan_op(a.v, op, pl);
-  wv::fence();
+  // the plan record goes to memory for o_check / o_apply; this kernel reserves straight from the registers
+  const dev::PlanRegs pr = dev::plan_op(a.v, op, pl);
   const int lane = wv::lane();
   if (lane == 0) a.opidx[wid] = idx;
   const unsigned long long key = make_key(a.round, idx);
-  const uint32_t kind = pl->kind;
+  const uint32_t kind = pr.kind;
   if (kind == K_EXCL) {
     if (lane == 0) wv::atomic_min_u64(&c->gbar[par], key);
     return;
   }
   if (kind == K_DUP) {
-    if (lane == 0) wv::atomic_min_u64(&a.v.dres[pl->wleaf_lo], key);
+    if (lane == 0) wv::atomic_min_u64(&a.v.dres[pr.wleaf_lo], key);
   } else if (kind_strong(kind)) {
-    const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
+    const uint32_t wl = pr.wleaf_lo, wh = pr.wleaf_hi;
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_min_u64(&a.v.wres[leaf], key);
     // an update whose window is already within two levels of the exclusive threshold is likely to turn exclusive
     // once the earlier updates have landed: nothing later may overtake it (soft barrier)
-    if (pl->wlen >= kBigWindow / 4 && lane == 0) wv::atomic_min_u64(&c->gbar[par], key + 1ull);
-    const uint32_t ml = pl->mv_lo, mh = pl->mv_hi;
+    if (pr.wlen >= kBigWindow / 4 && lane == 0) wv::atomic_min_u64(&c->gbar[par], key + 1ull);
+    const uint32_t ml = pr.mv_lo, mh = pr.mv_hi;
     for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_min_u64(&a.v.vw[u], key);
   }
-  PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, wv::atomic_min_u64(&a.v.rres[leaf], key));
+  if (pr.nr <= 64u && pr.nlong == 0u) {  // lane r holds read range r
+    if ((uint32_t)lane < pr.nr)
+      for (uint32_t leaf = pr.my_lo; leaf <= pr.my_hi; leaf++) wv::atomic_min_u64(&a.v.rres[leaf], key);
+  } else {
+    wv::fence();  // (rare) more ranges than lanes, or long ranges: walk the record this wave has just written
+    PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, wv::atomic_min_u64(&a.v.rres[leaf], key));
+  }
   if (kind != K_NOOP && op.src < a.v.g.n) {  // readers of the positions of sentinels src and src+1
     if (lane == 0) wv::atomic_min_u64(&a.v.vr[op.src], key);
     if (lane == 1 && op.src + 1u < a.v.g.n) wv::atomic_min_u64(&a.v.vr[op.src + 1u], key);
