@@ -68,6 +68,16 @@ PMA_DEV void fix_sentinel(const View &v, const Edge &e, uint32_t in) {
 }
 
 constexpr uint32_t kLongRange = 8;  // read ranges spanning more leaves are walked by the whole wave
+// Phase clock of one wave (profiling builds only, -DPPCSR_PHASE_TIMING: tools/phase_timing.py); a no-op otherwise.
+struct PhaseClock {
+#if defined(PPCSR_PHASE_TIMING) && !defined(PPCSR_SIM)
+  unsigned long long t[12];
+  PMA_DEV void mark(int i) { t[i] = wall_clock64(); }
+#else
+  PMA_DEV void mark(int) {}
+#endif
+};
+
 struct RangeRec {  // read-leaf ranges collected by lane 0 into the plan record
   Plan *plan;
   uint32_t nr;
@@ -118,6 +128,46 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
   // levels probe that register copy through shuffles: same probes, same decisions, no further memory round trips.
   bool cached = false;
   uint32_t cbase = 0, cend = 0, cval = 0, cdst = 0;
+  // 64-ary narrowing.  The value the reference's walk returns does not depend on the walk: any bracket (start, end)
+  // with "start is the range's first slot or a live slot whose dest < key" and "end is the range's end or a live slot
+  // whose dest > key" leads to the same answer (the walk only ever tightens such a bracket, and every exit fires on
+  // the tight one; tests/test_search_model.py checks this against the scalar walk).  So the bracket is first tightened
+  // 64 samples at a time — one round trip per factor of ~64 instead of one per factor of 2 — and the reference's walk
+  // then finishes it from registers.  Only the two samples that become the new bracket are recorded as reads: with a
+  // sorted neighbourhood the others cannot change the outcome.
+  while (end - start > 64) {
+    const uint32_t len = end - start;
+    const uint32_t stride = (len + 63u) / 64u;
+    const uint32_t sl = start + (uint32_t)lane * stride;
+    uint32_t sv = 0, sd = 0;
+    if (sl < end) {
+      sv = items[sl].value;
+      sd = items[sl].dest;
+    }
+    const bool live = sl < end && sv != 0;
+    const uint64_t mlt = wv::ballot(live && sd < dest);
+    const uint64_t mge = wv::ballot(live && sd >= dest);
+    uint32_t nstart = start, nend = end;
+    if (mge) {
+      const int lb = wv::ctz64(mge);
+      const uint32_t bslot = wv::shfl(sl, lb), bdst = wv::shfl(sd, lb);
+      if (bdst == dest) {  // the key itself: the walk returns its slot whenever it meets it
+        rec_range(rr, v, bslot, bslot);
+        hit->known = 1;
+        hit->value = wv::shfl(sv, lb);
+        hit->dest = bdst;
+        return bslot;
+      }
+      nend = bslot;
+    }
+    if (mlt) nstart = wv::shfl(sl, 63 - __builtin_clzll(mlt));
+    if (nstart != start) rec_range(rr, v, nstart, nstart);
+    if (nend != end) rec_range(rr, v, nend, nend);
+    const bool progress = (nend - nstart) <= len / 2u;
+    start = nstart;
+    end = nend;
+    if (!progress) break;  // sparse samples: let the reference's walk take over from here
+  }
   while (start + 1 < end) {
     if (!cached && end - start <= 64) {
       cbase = start;
@@ -635,7 +685,7 @@ struct PlanRegs {
   uint32_t kind, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, nr, nlong;
   uint32_t my_lo, my_hi;  // lane r: read range r (r < 64)
 };
-PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
+PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, PhaseClock &pc) {
   const int lane = wv::lane();
   const Geometry &g = v.g;
   RangeRec rr;
@@ -650,7 +700,9 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
     sleaf_b = nd.beginning >> g.sh;
     sleaf_e = nd.end >> g.sh;
     SearchHit hit;
+    pc.mark(3);
     index = pma_search(v, op.dst, nd.beginning + 1, nd.end, rr, &hit);
+    pc.mark(4);
     const uint32_t leaf = index >> g.sh;
     // one batch of independent loads: the slot the search returned (unless the search already knows it), its leaf's
     // count, and — for an occupied slot — the first 64 slots of the gap search to the right
@@ -669,6 +721,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
       if (g0 < g.N) nul0 = (v.items[g0].value == 0);
     }
     const bool occupied = !is_null(at);
+    pc.mark(5);
     if (op.op != 0) {
       const Edge elem{op.src, op.dst, op.op};
       if (occupied && !is_sentinel(elem) && at.dest == op.dst) {
@@ -733,6 +786,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
   } else if (op.op == 0) {
     kind = K_NOOP;  // reference: unchecked out-of-range delete is UB; we ignore it
   }
+  pc.mark(6);
   if (kind == K_INSERT || kind == K_REMOVE) {
     // sentinels inside [lo, hi] = slide range U window.  Sentinel positions increase with the vertex id and
     // beg(src) < index <= beg(src+1), so they are the vertices src, src-1, ... and src+1, src+2, ... around `src`.
@@ -784,6 +838,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
       if (b_lo == wstart && (kind == K_REMOVE || index > wstart)) mv_lo++;
     }
   }
+  pc.mark(7);
   if (lane == 0) {
     plan->mv_lo = mv_lo;
     plan->mv_hi = mv_hi;
