@@ -27,16 +27,6 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in os.listdir(CSRC) if f.endswith((".h", ".cc", ".hip")))
 
 
-TIMING_LIB = os.path.join(CSRC, "libppcsr_hip_timing.so")
-
-
-def build_timing():
-    """profiling build (tools/phase_timing.py): same source with per-phase wave clocks in o_plan; never the product"""
-    cmd = [hipcc()] + HIPCC_FLAGS + ["-DPPCSR_PHASE_TIMING", os.path.join(CSRC, "ppcsr_hip.hip"), "-o", TIMING_LIB]
-    subprocess.run(cmd, check=True, cwd=CSRC)
-    return TIMING_LIB
-
-
 def build_engine(force=False, verbose=False):
     if not force and not needs_build():
         return LIB

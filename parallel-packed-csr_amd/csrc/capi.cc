@@ -289,21 +289,3 @@ int pppcsr_apply_batch(pppcsr_t h, const ppcsr_op *ops, uint64_t n) {
 }
 
 }  // extern "C"
-
-#if defined(PPCSR_PHASE_TIMING) && !defined(PPCSR_SIM)
-// profiling build only (tools/phase_timing.py): out[0..11] sums, [12..23] cumulative maxima, [24] count, [25..88] histogram
-extern "C" int ppcsr_debug_phase_read(unsigned long long *out, int reset) {
-  unsigned long long z[64] = {0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ppcsr::g_phase_sum), 12 * 8) != hipSuccess) return 3;
-  if (hipMemcpyFromSymbol(out + 12, HIP_SYMBOL(ppcsr::g_phase_max), 12 * 8) != hipSuccess) return 3;
-  if (hipMemcpyFromSymbol(out + 24, HIP_SYMBOL(ppcsr::g_phase_cnt), 8) != hipSuccess) return 3;
-  if (hipMemcpyFromSymbol(out + 25, HIP_SYMBOL(ppcsr::g_phase_hist), 64 * 8) != hipSuccess) return 3;
-  if (reset) {
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(ppcsr::g_phase_sum), z, 12 * 8);
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(ppcsr::g_phase_max), z, 12 * 8);
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(ppcsr::g_phase_cnt), z, 8);
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(ppcsr::g_phase_hist), z, 64 * 8);
-  }
-  return 0;
-}
-#endif

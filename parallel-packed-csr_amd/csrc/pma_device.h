@@ -68,16 +68,6 @@ PMA_DEV void fix_sentinel(const View &v, const Edge &e, uint32_t in) {
 }
 
 constexpr uint32_t kLongRange = 8;  // read ranges spanning more leaves are walked by the whole wave
-// Phase clock of one wave (profiling builds only, -DPPCSR_PHASE_TIMING: tools/phase_timing.py); a no-op otherwise.
-struct PhaseClock {
-#if defined(PPCSR_PHASE_TIMING) && !defined(PPCSR_SIM)
-  unsigned long long t[12];
-  PMA_DEV void mark(int i) { t[i] = wall_clock64(); }
-#else
-  PMA_DEV void mark(int) {}
-#endif
-};
-
 struct RangeRec {  // read-leaf ranges collected by lane 0 into the plan record
   Plan *plan;
   uint32_t nr;
@@ -685,7 +675,7 @@ struct PlanRegs {
   uint32_t kind, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, nr, nlong;
   uint32_t my_lo, my_hi;  // lane r: read range r (r < 64)
 };
-PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, PhaseClock &pc) {
+PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
   const int lane = wv::lane();
   const Geometry &g = v.g;
   RangeRec rr;
@@ -700,9 +690,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, PhaseClock &pc)
     sleaf_b = nd.beginning >> g.sh;
     sleaf_e = nd.end >> g.sh;
     SearchHit hit;
-    pc.mark(3);
     index = pma_search(v, op.dst, nd.beginning + 1, nd.end, rr, &hit);
-    pc.mark(4);
     const uint32_t leaf = index >> g.sh;
     // one batch of independent loads: the slot the search returned (unless the search already knows it), its leaf's
     // count, and — for an occupied slot — the first 64 slots of the gap search to the right
@@ -721,7 +709,6 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, PhaseClock &pc)
       if (g0 < g.N) nul0 = (v.items[g0].value == 0);
     }
     const bool occupied = !is_null(at);
-    pc.mark(5);
     if (op.op != 0) {
       const Edge elem{op.src, op.dst, op.op};
       if (occupied && !is_sentinel(elem) && at.dest == op.dst) {
@@ -786,7 +773,6 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, PhaseClock &pc)
   } else if (op.op == 0) {
     kind = K_NOOP;  // reference: unchecked out-of-range delete is UB; we ignore it
   }
-  pc.mark(6);
   if (kind == K_INSERT || kind == K_REMOVE) {
     // sentinels inside [lo, hi] = slide range U window.  Sentinel positions increase with the vertex id and
     // beg(src) < index <= beg(src+1), so they are the vertices src, src-1, ... and src+1, src+2, ... around `src`.
@@ -838,7 +824,6 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, PhaseClock &pc)
       if (b_lo == wstart && (kind == K_REMOVE || index > wstart)) mv_lo++;
     }
   }
-  pc.mark(7);
   if (lane == 0) {
     plan->mv_lo = mv_lo;
     plan->mv_hi = mv_hi;

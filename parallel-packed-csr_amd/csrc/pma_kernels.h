@@ -63,8 +63,7 @@ PMA_KERNEL void k_plan(RoundArgs a) {
   const uint32_t idx = base + wid;
   const Op op = a.ops[idx];
   Plan *pl = &a.plans[wid];
-  dev::PhaseClock pc_;
-  const dev::PlanRegs pr = dev::plan_op(a.v, op, pl, pc_);
+  const dev::PlanRegs pr = dev::plan_op(a.v, op, pl);
   const uint32_t kind = pr.kind;
   if (kind == K_DUP) {
     if (wv::lane() == 0) wv::atomic_min_u64(&a.v.dres[pr.wleaf_lo], make_key(a.round, idx));
@@ -1004,13 +1003,7 @@ constexpr uint32_t OS_PASS = 1u, OS_STAMP_BAD = 2u, OS_COMMITTED = 4u;
 
 PMA_DEV bool key_earlier(unsigned long long k, uint32_t tag, uint32_t idx) { return (uint32_t)(k >> 32) == tag && (uint32_t)k < idx; }
 
-#if defined(PPCSR_PHASE_TIMING) && !defined(PPCSR_SIM)
-// profiling build: per-phase time of o_plan's waves, summed / maxed over all waves and launches (units of 10 ns)
-__device__ unsigned long long g_phase_sum[12], g_phase_max[12], g_phase_cnt, g_phase_hist[64];
-#endif
 PMA_KERNEL void o_plan(OptArgs a) {
-  dev::PhaseClock pc;
-  pc.mark(0);
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
   const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
@@ -1021,13 +1014,10 @@ PMA_KERNEL void o_plan(OptArgs a) {
   const uint32_t used = cn < hor ? cn : hor;
   const uint32_t *carry = par ? a.carry1 : a.carry0;
   const uint32_t idx = (wid < used) ? carry[wid] : nf + (wid - used);
-  pc.mark(1);
   const Op op = a.ops[idx];
   Plan *pl = &a.plans[wid];
-  pc.mark(2);
   // the plan record goes to memory for o_check / o_apply; this kernel reserves straight from the registers
-  const dev::PlanRegs pr = dev::plan_op(a.v, op, pl, pc);
-  pc.mark(8);
+  const dev::PlanRegs pr = dev::plan_op(a.v, op, pl);
   const int lane = wv::lane();
   if (lane == 0) a.opidx[wid] = idx;
   const unsigned long long key = make_key(a.round, idx);
@@ -1058,18 +1048,6 @@ PMA_KERNEL void o_plan(OptArgs a) {
     if (lane == 0) wv::atomic_min_u64(&a.v.vr[op.src], key);
     if (lane == 1 && op.src + 1u < a.v.g.n) wv::atomic_min_u64(&a.v.vr[op.src + 1u], key);
   }
-#if defined(PPCSR_PHASE_TIMING) && !defined(PPCSR_SIM)
-  pc.mark(9);
-  if (lane == 0 && op.src < a.v.g.n) {
-    for (int i = 1; i <= 9; i++) {
-      atomicAdd(&g_phase_sum[i], pc.t[i] - pc.t[i - 1]);
-      atomicMax(&g_phase_max[i], pc.t[i] - pc.t[0]);
-    }
-    atomicAdd(&g_phase_cnt, 1ull);
-    unsigned long long b = (pc.t[9] - pc.t[0]) / 50ull;  // 0.5 us buckets
-    atomicAdd(&g_phase_hist[b < 63 ? b : 63], 1ull);
-  }
-#endif
 }
 
 PMA_KERNEL void o_check(OptArgs a) {
