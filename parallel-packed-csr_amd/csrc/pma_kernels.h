@@ -1314,7 +1314,14 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
   }
   const uint32_t ncommitted = hor - tot;
   const uint32_t kept = tot;
-  if (mymaxc) wv::atomic_max_u32(&c->maxc, mymaxc);  // <= 1024 atomics per round, only by threads that saw a commit
+  {  // one atomic per wave: a thousand same-address atomics would serialise in L2 for longer than the rest of this kernel
+    uint32_t wmax = mymaxc;
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+      const uint32_t y = wv::shfl(wmax, lane ^ o2);
+      wmax = y > wmax ? y : wmax;
+    }
+    if (lane == 0 && wmax) wv::atomic_max_u32(&c->maxc, wmax);
+  }
   for (uint32_t i = used + tid; i < cn; i += bd) {  // carry entries beyond the horizon
     const uint32_t x = cin[i];
     if (kept + (i - used) == 0) *s_first_p = x;
