@@ -237,7 +237,7 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   GCHK(gpu::dmalloc((void **)&p.d_total, sizeof(unsigned long long)));
   GCHK(gpu::hmalloc((void **)&p.h_total, sizeof(unsigned long long)));
   GCHK(gpu::dmalloc((void **)&p.d_table, sizeof(ChainTable)));
-  GCHK(gpu::dmalloc((void **)&p.d_plans, (uint64_t)p.max_horizon * sizeof(Plan)));
+  GCHK(gpu::dmalloc((void **)&p.d_plans, ((uint64_t)p.max_horizon + 8) * sizeof(Plan)));
   memset(p.h_ctl, 0, sizeof(Control));
 
   // constructor layout (PCSR.cpp:796-837): sentinel positions come from an fp64 accumulator, O(n) on the host
@@ -538,13 +538,13 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     if (p.d_status) GPU_DFREE(p.d_status);
     p.d_opidx = p.d_status = nullptr;
     p.hslot_cap = 0;
-    GCHK(gpu::dmalloc((void **)&p.d_opidx, (uint64_t)p.opt_horizon * sizeof(uint32_t)));
-    GCHK(gpu::dmalloc((void **)&p.d_status, (uint64_t)p.opt_horizon * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_opidx, ((uint64_t)p.opt_horizon + 8) * sizeof(uint32_t)));  // (+8: padded to the launch grid)
+    GCHK(gpu::dmalloc((void **)&p.d_status, ((uint64_t)p.opt_horizon + 8) * sizeof(uint32_t)));
     if (p.d_vdbg) GPU_DFREE(p.d_vdbg);
-    GCHK(gpu::dmalloc((void **)&p.d_vdbg, (uint64_t)p.opt_horizon * 4 * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_vdbg, ((uint64_t)p.opt_horizon + 8) * 4 * sizeof(uint32_t)));
     GPU_DFREE(p.d_plans);
     p.d_plans = nullptr;
-    GCHK(gpu::dmalloc((void **)&p.d_plans, (uint64_t)std::max(p.opt_horizon, p.max_horizon) * sizeof(Plan)));
+    GCHK(gpu::dmalloc((void **)&p.d_plans, ((uint64_t)std::max(p.opt_horizon, p.max_horizon) + 8) * sizeof(Plan)));
     p.hslot_cap = p.opt_horizon;
   }
   if (p.carry_cap < p.epoch_ops) {

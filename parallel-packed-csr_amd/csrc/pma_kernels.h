@@ -1003,6 +1003,41 @@ constexpr uint32_t OS_PASS = 1u, OS_STAMP_BAD = 2u, OS_COMMITTED = 4u;
 
 PMA_DEV bool key_earlier(unsigned long long k, uint32_t tag, uint32_t idx) { return (uint32_t)(k >> 32) == tag && (uint32_t)k < idx; }
 
+// The plan record's header and this lane's read range, requested in ONE batch (and before the kernel's early-exit tests:
+// the per-wave arrays are padded to the launch grid, so the loads are always in bounds).  The round kernels are chains
+// of dependent loads; what can be asked for together is asked for together.
+struct PlanHead {
+  uint32_t kind, index, wstart, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, sleaf_b, sleaf_e, nr, nlong;
+  uint32_t my_lo, my_hi;  // lane r: read range r (r < 64)
+};
+PMA_DEV PlanHead load_plan_head(const Plan *pl, int lane) {
+  PlanHead h;
+  h.kind = pl->kind;
+  h.index = pl->index;
+  h.wstart = pl->wstart;
+  h.wlen = pl->wlen;
+  h.wleaf_lo = pl->wleaf_lo;
+  h.wleaf_hi = pl->wleaf_hi;
+  h.mv_lo = pl->mv_lo;
+  h.mv_hi = pl->mv_hi;
+  h.sleaf_b = pl->sleaf_b;
+  h.sleaf_e = pl->sleaf_e;
+  h.nr = pl->nr;
+  h.nlong = pl->nlong;
+  h.my_lo = pl->rlo[lane];
+  h.my_hi = pl->rhi[lane];
+  return h;
+}
+#define PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, LEAFVAR, BODY)                                  \
+  do {                                                                                        \
+    if ((h).nr <= 64u && (h).nlong == 0u) {                                                   \
+      if ((uint32_t)(lane) < (h).nr)                                                          \
+        for (uint32_t LEAFVAR = (h).my_lo; LEAFVAR <= (h).my_hi; LEAFVAR++) { BODY; }         \
+    } else {                                                                                  \
+      PMA_FOR_EACH_READ_LEAF(pl, lane, LEAFVAR, BODY);                                        \
+    }                                                                                         \
+  } while (0)
+
 PMA_KERNEL void o_plan(OptArgs a) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
@@ -1053,28 +1088,31 @@ PMA_KERNEL void o_plan(OptArgs a) {
 PMA_KERNEL void o_check(OptArgs a) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
-  if (c->done || c->violation || c->excl || c->error) return;
-  const uint32_t hor = c->hor[par];
   const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
-  if (wid >= hor) return;
   const int lane = wv::lane();
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  const uint32_t hor = c->hor[par];
+  const unsigned long long gbar = c->gbar[par];
   const uint32_t idx = a.opidx[wid];
   const Plan *pl = &a.plans[wid];
-  const uint32_t kind = pl->kind;
+  const PlanHead h = load_plan_head(pl, lane);
+  if (f_done || f_viol || f_excl || f_err) return;
+  if (wid >= hor) return;
+  const uint32_t kind = h.kind;
   const unsigned long long key = make_key(a.round, idx);
   const uint32_t tag = (uint32_t)(key >> 32);
-  bool fail = (kind == K_EXCL) || key_earlier(c->gbar[par], tag, idx);
+  bool fail = (kind == K_EXCL) || key_earlier(gbar, tag, idx);
   bool stamp_bad = false;
   const uint32_t me1 = idx + 1u;  // stamps hold (index + 1) of the latest committed toucher
   const bool writes = kind_writes(kind);
   const bool strong = kind_strong(kind);
   if (kind == K_DUP) {
-    const uint32_t leaf = pl->wleaf_lo;
+    const uint32_t leaf = h.wleaf_lo;
     if (key_earlier(a.v.wres[leaf], tag, idx)) fail = true;  // an earlier pending update moves slots of this leaf
     if (a.v.dres[leaf] != key) fail = true;                   // an earlier pending duplicate on this leaf
   }
   if (strong) {
-    const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
+    const uint32_t wl = h.wleaf_lo, wh = h.wleaf_hi;
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) {
       if (a.v.wres[leaf] != key) fail = true;                   // an earlier pending update writes it
       if (key_earlier(a.v.dres[leaf], tag, idx)) fail = true;   // an earlier pending duplicate overwrites a slot here
@@ -1087,7 +1125,7 @@ PMA_KERNEL void o_check(OptArgs a) {
       }
     }
   }
-  PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, {
+  PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, {
     if (key_earlier(a.v.wres[leaf], tag, idx)) fail = true;  // an earlier pending update writes what we read
     if (a.wstamp[leaf] > me1) {                               // a LATER update already wrote what we read
       stamp_bad = true;
@@ -1109,7 +1147,7 @@ PMA_KERNEL void o_check(OptArgs a) {
       }
     }
     if (strong) {
-      const uint32_t ml = pl->mv_lo, mh = pl->mv_hi;
+      const uint32_t ml = h.mv_lo, mh = h.mv_hi;
       for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) {
         if (key_earlier(a.v.vr[u], tag, idx)) fail = true;  // an earlier pending update still needs the old position
         if (a.vrs[u] > me1 || a.vws[u] > me1) {              // a LATER update already used / moved it
@@ -1125,27 +1163,27 @@ PMA_KERNEL void o_check(OptArgs a) {
   const bool anybad = wv::ballot(stamp_bad) != 0;
   uint32_t glo, ghi;
   if (writes) {
-    glo = pl->wleaf_lo >> a.regshift;
-    ghi = pl->wleaf_hi >> a.regshift;
+    glo = h.wleaf_lo >> a.regshift;
+    ghi = h.wleaf_hi >> a.regshift;
   } else {
-    glo = ghi = (pl->index >> a.v.g.sh) >> a.regshift;
+    glo = ghi = (h.index >> a.v.g.sh) >> a.regshift;
   }
   if (anyfail && kind != K_NOOP) {
     // a deferred update keeps later updates out of its region(s); its footprint may still creep over a region edge
     // by a slide, so the mark is padded by kRegionPadLeaves leaves on both sides
     const uint32_t nleaves = (uint32_t)(a.v.g.N >> a.v.g.sh);
-    uint32_t ll = writes ? pl->wleaf_lo : (pl->index >> a.v.g.sh), lh = writes ? pl->wleaf_hi : ll;
+    uint32_t ll = writes ? h.wleaf_lo : (h.index >> a.v.g.sh), lh = writes ? h.wleaf_hi : ll;
     ll = (ll > kRegionPadLeaves) ? ll - kRegionPadLeaves : 0u;
     lh = (lh + kRegionPadLeaves < nleaves) ? lh + kRegionPadLeaves : nleaves - 1u;
     const uint32_t pglo = ll >> a.regshift, pghi = lh >> a.regshift;
     for (uint32_t g = pglo + (uint32_t)lane; g <= pghi; g += 64) wv::atomic_min_u64(&a.regfail[g], key);
     // leaf-level mark for later READERS: the deferred update's window can still grow to an ancestor block; cover
     // the aligned block of 4x its tentative window (at least kGrowLeaves leaves) plus the slide pad
-    uint32_t wleaves = writes && pl->wlen ? (pl->wlen >> a.v.g.sh) : 1u;
+    uint32_t wleaves = writes && h.wlen ? (h.wlen >> a.v.g.sh) : 1u;
     if (wleaves < 1u) wleaves = 1u;
     uint32_t blk = wleaves * 4u;
     if (blk < kGrowLeaves) blk = kGrowLeaves;
-    const uint32_t anchor = writes && pl->wlen ? (pl->wstart >> a.v.g.sh) : (pl->index >> a.v.g.sh);
+    const uint32_t anchor = writes && h.wlen ? (h.wstart >> a.v.g.sh) : (h.index >> a.v.g.sh);
     uint32_t bl = anchor & ~(blk - 1u), bh = bl + blk - 1u;
     if (ll < bl) bl = ll;
     if (lh > bh) bh = lh;
@@ -1158,35 +1196,37 @@ PMA_KERNEL void o_check(OptArgs a) {
 PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
-  if (c->done || c->violation || c->excl || c->error) return;
-  const uint32_t hor = c->hor[par];
   const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
-  if (wid >= hor) return;
   const int lane = wv::lane();
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  const uint32_t hor = c->hor[par];
   const uint32_t st = a.status[wid];
-  if (!(st & OS_PASS)) return;
   const uint32_t idx = a.opidx[wid];
   const Plan *pl = &a.plans[wid];
-  const uint32_t kind = pl->kind;
+  const PlanHead h = load_plan_head(pl, lane);
+  if (f_done || f_viol || f_excl || f_err) return;
+  if (wid >= hor) return;
+  if (!(st & OS_PASS)) return;
+  const uint32_t kind = h.kind;
   const unsigned long long key = make_key(a.round, idx);
   const uint32_t tag = (uint32_t)(key >> 32);
   const bool writes = kind_writes(kind);
   if (kind != K_NOOP) {
     uint32_t glo, ghi;
     if (writes) {
-      glo = pl->wleaf_lo >> a.regshift;
-      ghi = pl->wleaf_hi >> a.regshift;
+      glo = h.wleaf_lo >> a.regshift;
+      ghi = h.wleaf_hi >> a.regshift;
     } else {
-      glo = ghi = (pl->index >> a.v.g.sh) >> a.regshift;
+      glo = ghi = (h.index >> a.v.g.sh) >> a.regshift;
     }
     bool blocked = false;
     for (uint32_t g = glo + (uint32_t)lane; g <= ghi; g += 64)
       if (key_earlier(a.regfail[g], tag, idx)) blocked = true;
     // ... nor may we have READ a leaf an earlier deferred update may still grow over
-    PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, { if (key_earlier(a.pfail[leaf], tag, idx)) blocked = true; });
+    PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, { if (key_earlier(a.pfail[leaf], tag, idx)) blocked = true; });
     // ... nor located our range by a sentinel inside the block a deferred earlier update may still grow over
-    if (lane == 0 && key_earlier(a.pfail[pl->sleaf_b], tag, idx)) blocked = true;
-    if (lane == 1 && key_earlier(a.pfail[pl->sleaf_e], tag, idx)) blocked = true;
+    if (lane == 0 && key_earlier(a.pfail[h.sleaf_b], tag, idx)) blocked = true;
+    if (lane == 1 && key_earlier(a.pfail[h.sleaf_e], tag, idx)) blocked = true;
     if (wv::ballot(blocked) != 0) return;  // an earlier update of this region was deferred: keep stream order inside it
   }
   if (st & OS_STAMP_BAD) {
@@ -1198,10 +1238,10 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
         c->viol_info[1] = a.vdbg[4 * wid + 0];
         c->viol_info[2] = a.vdbg[4 * wid + 1];
         c->viol_info[3] = a.vdbg[4 * wid + 2];
-        c->viol_info[4] = pl->wleaf_lo;
-        c->viol_info[5] = pl->wleaf_hi;
-        c->viol_info[6] = pl->index;
-        c->viol_info[7] = pl->nr;
+        c->viol_info[4] = h.wleaf_lo;
+        c->viol_info[5] = h.wleaf_hi;
+        c->viol_info[6] = h.index;
+        c->viol_info[7] = h.nr;
       }
     }
     return;
@@ -1210,19 +1250,19 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
 #if defined(PPCSR_SIM)
   if (lane == 0 && getenv("PPCSR_TRACE"))
     fprintf(stderr, "R%u commit idx=%u op=(%u,%u,%u) kind=%u index=%u gap=%u win=(%u,%u) wleaf=[%u,%u] nr=%u\n", a.round, idx, op.src,
-            op.dst, op.op, kind, pl->index, pl->gap, pl->wstart, pl->wlen, pl->wleaf_lo, pl->wleaf_hi, pl->nr);
+            op.dst, op.op, kind, h.index, pl->gap, h.wstart, h.wlen, h.wleaf_lo, h.wleaf_hi, h.nr);
 #endif
   dev::apply_op(a.v, op, pl, lds_wave, &a.stats[wv::block_idx() & (kStatShards - 1)]);
   const uint32_t me1 = idx + 1u;
   if (kind_strong(kind)) {  // (a duplicate's value overwrite commutes with everything it can be reordered with: no stamp)
-    const uint32_t wl = pl->wleaf_lo, wh = pl->wleaf_hi;
+    const uint32_t wl = h.wleaf_lo, wh = h.wleaf_hi;
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_max_u32(&a.wstamp[leaf], me1);
   }
-  PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, wv::atomic_max_u32(&a.rstamp[leaf], me1));
+  PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, wv::atomic_max_u32(&a.rstamp[leaf], me1));
   if (kind != K_NOOP && op.src < a.v.g.n) {
     if (lane < 2 && op.src + (uint32_t)lane < a.v.g.n) wv::atomic_max_u32(&a.vrs[op.src + (uint32_t)lane], me1);
     if (kind_strong(kind)) {
-      const uint32_t ml = pl->mv_lo, mh = pl->mv_hi;
+      const uint32_t ml = h.mv_lo, mh = h.mv_hi;
       for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_max_u32(&a.vws[u], me1);
     }
   }
