@@ -547,14 +547,15 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     GCHK(gpu::dmalloc((void **)&p.d_plans, ((uint64_t)std::max(p.opt_horizon, p.max_horizon) + 8) * sizeof(Plan)));
     p.hslot_cap = p.opt_horizon;
   }
-  if (p.carry_cap < p.epoch_ops) {
+  const uint64_t carry_need = (uint64_t)std::max<uint64_t>(p.epoch_ops, p.opt_horizon) + 8;  // (padded to the launch grid)
+  if (p.carry_cap < carry_need) {
     if (p.d_carry0) GPU_DFREE(p.d_carry0);
     if (p.d_carry1) GPU_DFREE(p.d_carry1);
     p.d_carry0 = p.d_carry1 = nullptr;
     p.carry_cap = 0;
-    GCHK(gpu::dmalloc((void **)&p.d_carry0, (uint64_t)p.epoch_ops * sizeof(uint32_t)));
-    GCHK(gpu::dmalloc((void **)&p.d_carry1, (uint64_t)p.epoch_ops * sizeof(uint32_t)));
-    p.carry_cap = p.epoch_ops;
+    GCHK(gpu::dmalloc((void **)&p.d_carry0, carry_need * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_carry1, carry_need * sizeof(uint32_t)));
+    p.carry_cap = carry_need;
   }
   uint64_t e0 = 0;
   uint64_t forced_e1 = 0;  // after a rollback: end the retried epoch right after the update that failed validation

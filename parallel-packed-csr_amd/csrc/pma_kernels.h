@@ -1041,14 +1041,15 @@ PMA_DEV PlanHead load_plan_head(const Plan *pl, int lane) {
 PMA_KERNEL void o_plan(OptArgs a) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
+  const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
+  const uint32_t *carry = par ? a.carry1 : a.carry0;
   const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
   const uint32_t hor = c->hor[par], cn = c->carry_n[par], nf = c->next_fresh[par];
+  const uint32_t cw = carry[wid];  // (requested with the control block; the carry lists are padded to the launch grid)
   if (f_done || f_viol || f_excl || f_err) return;
-  const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
   if (wid >= hor) return;
   const uint32_t used = cn < hor ? cn : hor;
-  const uint32_t *carry = par ? a.carry1 : a.carry0;
-  const uint32_t idx = (wid < used) ? carry[wid] : nf + (wid - used);
+  const uint32_t idx = (wid < used) ? cw : nf + (wid - used);
   const Op op = a.ops[idx];
   Plan *pl = &a.plans[wid];
   // the plan record goes to memory for o_check / o_apply; this kernel reserves straight from the registers
