@@ -127,8 +127,13 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
   // sorted neighbourhood the others cannot change the outcome.
   while (end - start > 64) {
     const uint32_t len = end - start;
-    const uint32_t stride = (len + 63u) / 64u;
-    const uint32_t sl = start + (uint32_t)lane * stride;
+    // samples sit on an ABSOLUTE power-of-two grid (multiples of 2^sshift), not at offsets from `start`: a deferred
+    // update that is planned again after its vertex's range has shifted by a slot or two then reads the same sample
+    // leaves as before, which is what the per-round reservations of the other updates were checked against
+    uint32_t sshift = 0;
+    while ((len >> sshift) >= 64u) sshift++;
+    const uint32_t first = ((start + (1u << sshift) - 1u) >> sshift) << sshift;
+    const uint32_t sl = first + ((uint32_t)lane << sshift);
     uint32_t sv = 0, sd = 0;
     if (sl < end) {
       sv = items[sl].value;
