@@ -1,15 +1,24 @@
 #!/usr/bin/env python3
 """Per-kernel durations of the LAST `rounds` speculative rounds in a rocprofv3 kernel trace (rocpd sqlite output), i.e.
 the timed region of `bench.py --no-profile` (the core load and warm-up come first).  Also prints the gaps between
-consecutive kernels of those rounds.  usage: trace_summary.py <results.db> <rounds> [out.json]"""
+consecutive kernels of those rounds.  usage: trace_summary.py <results.db | kernel_trace.csv> <rounds> [out.json]"""
 import json
 import sqlite3
 import sys
 
 db, rounds = sys.argv[1], int(sys.argv[2])
-c = sqlite3.connect(db)
-rows = c.execute("select name, start, end from kernels where name like '%o_plan%' or name like '%o_check%' or "
-                 "name like '%o_apply%' or name like '%o_compact%' order by start").fetchall()
+if db.endswith(".csv"):  # rocprofv3 --output-format csv: <prefix>_kernel_trace.csv
+    import csv
+    rows = []
+    for r in csv.DictReader(open(db)):
+        nm = r["Kernel_Name"]
+        if any(k in nm for k in ("o_plan", "o_check", "o_apply", "o_compact")):
+            rows.append((nm, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    rows.sort(key=lambda x: x[1])
+else:  # rocpd sqlite output (the default format)
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, start, end from kernels where name like '%o_plan%' or name like '%o_check%' or "
+                     "name like '%o_apply%' or name like '%o_compact%' order by start").fetchall()
 plans = [i for i, r in enumerate(rows) if "o_plan" in r[0]]
 first = plans[-rounds]
 sel = rows[first:]
