@@ -1,8 +1,11 @@
 // C ABI (include/ppcsr.h) over ppcsr::Engine.  No torch types, plain pointers and sizes.
+#include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ppcsr.h"
@@ -279,13 +282,49 @@ int pppcsr_apply_batch(pppcsr_t h, const ppcsr_op *ops, uint64_t n) {
   std::vector<uint64_t> counts(P);
   int rc = pppcsr_bucket_ops(h->init_n, P, ops, n, b.data(), counts.data());
   if (rc != 0) return rc;
-  uint64_t off = 0;
-  for (uint64_t k = 0; k < P; k++) {
-    rc = ppcsr_apply_batch(h->parts[k], b.data() + off, counts[k]);
+  std::vector<uint64_t> offs(P + 1, 0);
+  for (uint64_t k = 0; k < P; k++) offs[k + 1] = offs[k] + counts[k];
+#if defined(PPCSR_SIM)
+  for (uint64_t k = 0; k < P; k++) {  // (the CPU emulator is single-threaded)
+    rc = ppcsr_apply_batch(h->parts[k], b.data() + offs[k], counts[k]);
     if (rc != 0) return rc;
-    off += counts[k];
   }
   return 0;
+#else
+  // Partitions are independent engines with their own streams (PPPCSR.h:54): host threads drive them side by side, so
+  // the latency-bound round kernels of different partitions overlap on the GPU(s).  Each partition still applies its
+  // own subsequence in stream order.
+  uint64_t T = std::min<uint64_t>(P, 16);
+  if (const char *e = getenv("PPCSR_PP_THREADS")) T = std::max<uint64_t>(1, std::min<uint64_t>(P, strtoull(e, nullptr, 10)));  // measurement hook
+  if (T <= 1) {
+    for (uint64_t k = 0; k < P; k++) {
+      rc = ppcsr_apply_batch(h->parts[k], b.data() + offs[k], counts[k]);
+      if (rc != 0) return rc;
+    }
+    return 0;
+  }
+  std::vector<int> rcs(T, 0);
+  std::vector<std::string> msgs(T);
+  std::vector<std::thread> th;
+  for (uint64_t t = 0; t < T; t++)
+    th.emplace_back([&, t]() {
+      for (uint64_t k = t; k < P; k += T) {
+        const int r = ppcsr_apply_batch(h->parts[k], b.data() + offs[k], counts[k]);
+        if (r != 0) {
+          rcs[t] = r;
+          msgs[t] = ppcsr_last_error();  // (thread-local in the worker)
+          return;
+        }
+      }
+    });
+  for (auto &x : th) x.join();
+  for (uint64_t t = 0; t < T; t++)
+    if (rcs[t] != 0) {
+      g_last_error = msgs[t];
+      return rcs[t];
+    }
+  return 0;
+#endif
 }
 
 }  // extern "C"
