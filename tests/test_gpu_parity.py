@@ -123,6 +123,33 @@ def test_hubs_and_last_vertex(mk, streams):
         _stats_match(eng, o)
 
 
+def test_sparse_hub_searches(mk, streams):
+    """the 64-ary bracket narrowing on a hub whose range is mostly gaps: build a 30 K-edge hub, delete 97 % of it (the
+    array never shrinks below its doubled size while the other vertices keep it dense enough), then look keys up through
+    every exit of the search — exact hits, misses between far-apart survivors, below the first and above the last edge,
+    duplicates — interleaved with inserts that land in the gaps"""
+    m = 30000
+    n = 64
+    d = streams.uniform_ints(11, m, 1 << 28) * 4 + 2
+    hub = np.stack([np.full(m, 5), d, np.ones(m)], 1).astype(np.uint32)
+    filler_s = streams.uniform_ints(12, 60000, n)
+    filler = np.stack([filler_s, streams.uniform_ints(13, 60000, 1 << 30), np.ones(60000)], 1).astype(np.uint32)
+    dele = hub[streams.uniform_ints(14, m, 100) < 97].copy()
+    dele[:, 2] = 0
+    probe_d = np.concatenate([d[:4000] + 1, d[:4000], np.arange(1, 4001, dtype=np.uint64), d[:2000] - 1]).astype(np.uint32)
+    probes = np.stack([np.full(len(probe_d), 5), probe_d, np.ones(len(probe_d))], 1).astype(np.uint32)
+    probes[1::3, 2] = 0  # every third probe is a delete (hit or miss)
+    ops = np.concatenate([hub, filler, dele, probes])
+    for lock in (True, False):
+        eng, o = mk(n, lock), Oracle(n, lock_search=lock)
+        eng.apply(ops)
+        o.apply(ops)
+        _same(eng, o, f"lock={lock}")
+        _stats_match(eng, o)
+        for dd in (int(d[7]), int(d[7]) + 1, 1, (1 << 30) + 7):
+            assert eng.edge_exists(5, dd) == o.edge_exists(5, dd)
+
+
 def test_ascending_and_descending_runs(mk):
     """long slides (descending dests) and end-of-array inserts (ascending dests into the last vertex)"""
     m = 12000

@@ -165,6 +165,30 @@ def test_sim_scan_all_repeated_across_resizes(sim, streams):
     assert e.geometry() == o.geometry()
 
 
+def test_sim_sparse_hub_searches(sim, streams):
+    """64-ary bracket narrowing on a hub that is mostly gaps (built, then 95 % deleted), probed through every exit of the
+    search, under both schedulers and both lock_search settings"""
+    m, n = 2500, 16
+    d = streams.uniform_ints(11, m, 1 << 20) * 4 + 2
+    hub = np.stack([np.full(m, 5), d, np.ones(m)], 1).astype(np.uint32)
+    filler = np.stack([streams.uniform_ints(12, 3000, n), streams.uniform_ints(13, 3000, 1 << 30), np.ones(3000)], 1).astype(np.uint32)
+    dele = hub[streams.uniform_ints(14, m, 100) < 95].copy()
+    dele[:, 2] = 0
+    probe_d = np.concatenate([d[:500] + 1, d[:500], np.arange(1, 301, dtype=np.uint64), d[:300] - 1]).astype(np.uint32)
+    probes = np.stack([np.full(len(probe_d), 5), probe_d, np.ones(len(probe_d))], 1).astype(np.uint32)
+    probes[1::3, 2] = 0
+    ops = np.concatenate([hub, filler, dele, probes])
+    for lock, mode in ((True, 1), (False, 0)):
+        e, o = sim(n, lock, mode=mode), Oracle(n, lock_search=lock)
+        e.apply(ops)
+        o.apply(ops)
+        assert e.geometry() == o.geometry()
+        ei, en = e.state()
+        oi, on = o.state()
+        np.testing.assert_array_equal(en, on)
+        np.testing.assert_array_equal(ei, oi)
+
+
 def test_chain_table_matches_serial_fp64_chain():
     """the piecewise-linear position table (built with the fp64-reciprocal division) == the oracle's serial `x -= step`
     chain (PCSR.cpp:237-247), for windows up to 2^31 slots and densities across the PMA's range"""
