@@ -888,9 +888,12 @@ PMA_DEV void apply_op(const View &v, const Op op, const Plan *plan, uint32_t *ld
   if (kind == K_INSERT) {
     const uint32_t gap = plan->gap;
     if (gap != index) slide_right_wave(v, index, gap);
+    // the rebalance below recounts every leaf of its window; only a gap that lies beyond the window needs its leaf's
+    // count bumped here (a read-modify-write the following fence would otherwise have to wait for)
+    const bool gap_outside = ((uint64_t)gap < (uint64_t)plan->wstart) || ((uint64_t)gap >= (uint64_t)plan->wstart + plan->wlen);
     if (lane == 0) {
       v.items[index] = Edge{op.src, op.dst, op.op};
-      v.leafcnt[gap >> g.sh] += 1u;
+      if (gap_outside) v.leafcnt[gap >> g.sh] += 1u;
       wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 1u);
       wv::atomic_add_u64(&st->redistribute_calls, (unsigned long long)plan->alg_calls);
       wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)plan->alg_slots);
@@ -904,7 +907,8 @@ PMA_DEV void apply_op(const View &v, const Op op, const Plan *plan, uint32_t *ld
     if (lane == 0) {
       v.items[index].value = 0;
       v.items[index].dest = 0;
-      v.leafcnt[index >> g.sh] -= 1u;
+      if ((uint64_t)index < (uint64_t)plan->wstart || (uint64_t)index >= (uint64_t)plan->wstart + plan->wlen)
+        v.leafcnt[index >> g.sh] -= 1u;  // (never: the window contains the slot; its leaves are recounted below)
       wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
       wv::atomic_add_u64(&st->redistribute_calls, (unsigned long long)plan->alg_calls);
       wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)plan->alg_slots);
