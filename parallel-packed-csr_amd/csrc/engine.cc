@@ -591,6 +591,10 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     while ((p.region_slots >> rs) > (uint32_t)p.v.g.logN) rs++;
     bool epoch_open = true;
     uint32_t hint_hor = c.hor[par];
+    // tail sizing of the round chunks: updates still pending and updates committed per round (measured on the last chunk)
+    uint64_t chunk_pending = e1 - e0;
+    double chunk_cpr = 0.9 * (double)c.hor[par];
+    unsigned long long prev_rounds = 0, prev_committed = 0;
     while (epoch_open) {
       OptArgs a;
       a.v = p.v;
@@ -619,7 +623,14 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         GCHK(gpu::h2d(&p.d_octl->max_horizon, &gh, sizeof(uint32_t), p.stream));
         c.max_horizon = gh;
       }
-      const uint32_t rounds = p.rounds_per_sync;
+      // rounds in this chunk: as many as rounds_per_sync while that many are needed, fewer at the tail of the epoch so
+      // that the stream is not padded with launches that find `done` set (each still costs ~2 us of dispatch)
+      uint32_t rounds = p.rounds_per_sync;
+      {
+        const double per_round = std::max(1.0, 0.85 * chunk_cpr);
+        const double est = (double)chunk_pending / per_round + 2.0;
+        if (est < (double)rounds) rounds = (uint32_t)std::max(2.0, est);
+      }
       if (p.profile && p.events.size() < 5ull * rounds) {
         const size_t oldn = p.events.size();
         p.events.resize(5ull * rounds);
@@ -729,6 +740,10 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
           }
         }
         hint_hor = c.hor[npar];
+        chunk_pending = (uint64_t)c.carry_n[npar] + (uint64_t)(c.e1 - c.next_fresh[npar]);
+        if (c.rounds > prev_rounds) chunk_cpr = (double)(c.committed - prev_committed) / (double)(c.rounds - prev_rounds);
+        prev_rounds = c.rounds;
+        prev_committed = c.committed;
         if (hint_hor > gh) {
           // the grid of the next chunk must cover the horizon the device chose
         }
