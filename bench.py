@@ -355,9 +355,9 @@ def main():
             "metric": "edge-updates/sec", "value": value, "unit": "edge-updates/s", "n_gpus": P, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": ("config#3 mixed 50/50 insert+delete" if args.mixed else "config#2 1M random inserts")
+            "config": {"workload": (f"config#3 {args.batch} mixed 50/50 insert+delete" if args.mixed else f"config#2 {args.batch} random inserts")
                        + f" on RMAT scale-{args.scale} / {args.core_edges}-edge core per GPU"
-                       + (f", {P} vertex-range partitions, labels {'permuted' if permute else 'raw'}, RCCL all-to-all" if P > 1 else ", 1 partition"),
+                       + (f", {P} vertex-range partitions, labels {'permuted' if permute else 'raw'}, {'RCCL' if args.backend == 'nccl' else args.backend} all-to-all" if P > 1 else ", 1 partition"),
                        "vertices": n_global, "core_edges": args.core_edges * P, "updates_per_step": args.batch * P,
                        "parallelism": f"partition-per-gpu x{P}", "N_slots": int(s1["N"]), "logN": int(s1["logN"]),
                        "semantics": "sequential stream order (bit-exact vs reference -threads=1)"},
