@@ -226,16 +226,23 @@ def test_seq_stress_edge_exists(pkg):
     assert not eng.edge_exists(0, 5)
 
 
-def test_big_window_rebalance(pkg, streams):
-    """multi-workgroup rebalance kernels on 2^21..2^18-slot windows vs the oracle's redistribute()"""
+@pytest.mark.parametrize("variant,tile,batch", [(2, 0, 1), (2, 32, 1), (2, 256, 0), (1, 0, 1), (0, 0, 1)])
+def test_big_window_rebalance(pkg, streams, variant, tile, batch):
+    """multi-workgroup rebalance kernels on 2^21..2^15-slot windows vs the oracle's redistribute(): the default pipeline
+    (tile sums + in-tile scan + four chunks in flight) at several tile sizes, and the two older scatter variants that stay
+    selectable for A/B measurements; array doublings go through the same pipeline (out of place)"""
     n = 1 << 16
     s, d = streams.rmat_edges(16, 500000, seed=4)
     ops = streams.adds(s, d)
     e, o = pkg.PCSR(n), Oracle(n)
+    e.set_option("scatter_variant", variant)
+    e.set_option("rb_tile", tile)
+    e.set_option("rb_prefetch", batch)
     e.apply(ops)
     o.apply(ops)
+    _same(e, o, "load (with doublings)")
     N = e.geometry()[0]
-    for w in (N, N // 2, N // 8):
+    for w in (N, N // 2, N // 8, N // 64):
         e.bench_rebalance(w, 1)
         o.debug_redistribute(0, w)
         _same(e, o, f"window {w}")
