@@ -341,6 +341,18 @@ def main():
             extra["neighbour_scan"] = {"edges_per_s": tot / (ms * 1e-3), "ms": ms, "edges": int(tot),
                                        "alg_GBps": scan_bytes / (ms * 1e-3) / 1e9,
                                        "frac_of_peak": scan_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            # graph-algorithm consumers on the device: BFS from vertex 0, one PageRank push
+            nv = int(stt["n"])
+            lv, bms = eng.bfs(0, with_ms=True)
+            lv, bms = eng.bfs(0, with_ms=True)
+            reached = int((lv != 0xFFFFFFFF).sum())
+            pr, pms = eng.pagerank(np.ones(nv, np.float32), with_ms=True)
+            pr, pms = eng.pagerank(np.ones(nv, np.float32), with_ms=True)
+            extra["consumers"] = {"bfs_ms": bms, "bfs_levels": int(lv[lv != 0xFFFFFFFF].max()), "bfs_reached": reached,
+                                  "bfs_edges_per_s": tot / (bms * 1e-3), "pagerank_ms": pms,
+                                  "pagerank_edges_per_s": tot / (pms * 1e-3),
+                                  "note": "device time; pagerank = bulk scan + stable radix sort by dest + in-order "
+                                          "segment sums (bit-identical to the reference's fp32 loop)"}
             for label, w in (("window_rebalance", int(stt["N"])), ("window_rebalance_half", int(stt["N"]) // 2)):
                 rms = eng.bench_rebalance(w, 5)
                 extra[label] = {"window_slots": w, "ms_per_call": rms, "alg_GBps": 24.0 * w / (rms * 1e-3) / 1e9,

@@ -88,6 +88,13 @@ int ppcsr_get_neighbourhood(ppcsr_t h, int src, int *out, uint64_t cap, uint64_t
 int ppcsr_read_neighbourhood(ppcsr_t h, int src);
 /* bulk neighbour scan: get_neighbourhood for every vertex at once as CSR (row_offsets[n+1], dests[total]) */
 int ppcsr_scan_all(ppcsr_t h, uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *total);
+/* Graph-algorithm consumers run on the device over the gapped array.
+ * bfs — src/utility/bfs.h:15-36: levels[v] = BFS level of v from `start`, UINT32_MAX when unreachable (levels: n entries).
+ * pagerank — src/utility/pagerank.h:15-29: one push step, out[d] = sum over edges (s, d), in ascending s, of
+ *   node_values[s] / num_neighbors(s) in fp32 — added in the reference's order, so the result is bit-identical to the
+ *   reference template's (node_values, out: n entries).  device_ms (may be NULL): device time of the traversal. */
+int ppcsr_bfs(ppcsr_t h, uint32_t start, uint32_t *levels, double *device_ms);
+int ppcsr_pagerank(ppcsr_t h, const float *node_values, float *out, double *device_ms);
 /* raw state for parity checks: items[N], nodes[n] exactly as the reference holds them (PCSR.h:67,128) */
 int ppcsr_export_state(ppcsr_t h, ppcsr_edge *items, ppcsr_node *nodes);
 int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out);

@@ -107,6 +107,16 @@ int ppcsr_scan_all(ppcsr_t h, uint64_t *row_offsets, int *dests, uint64_t cap, u
   H_CHECK();
   return ret(h->e, h->e->scan_all(row_offsets, dests, cap, total));
 }
+int ppcsr_bfs(ppcsr_t h, uint32_t start, uint32_t *levels, double *device_ms) {
+  H_CHECK();
+  if (!levels) return bad("bfs: null output");
+  return ret(h->e, h->e->bfs(start, levels, device_ms));
+}
+int ppcsr_pagerank(ppcsr_t h, const float *node_values, float *out, double *device_ms) {
+  H_CHECK();
+  if (!node_values || !out) return bad("pagerank: null argument");
+  return ret(h->e, h->e->pagerank(node_values, out, device_ms));
+}
 int ppcsr_export_state(ppcsr_t h, ppcsr_edge *items, ppcsr_node *nodes) {
   H_CHECK();
   return ret(h->e, h->e->export_state(reinterpret_cast<ppcsr::Edge *>(items), reinterpret_cast<ppcsr::Node *>(nodes)));

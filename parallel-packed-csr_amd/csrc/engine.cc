@@ -1041,7 +1041,7 @@ int Engine::read_neighbourhood(int src) {
 // the edge array), exclusive scan, then ONE streaming pass that writes dests (array order == CSR order) and row offsets.
 // (A single-kernel decoupled look-back variant was tried and measured slower on MI355X — 110 us vs 85 us at N = 2^24,
 //  1.5 K polling workgroups disturb the streaming loads — and was removed; see the git history, "one-pass bulk neighbour scan".)
-int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap) {
+int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap, const float *d_values, float *d_contrib) {
   Impl &p = *p_;
   const uint64_t N = p.v.g.N, nchunks = (N + 63) / 64;
   bool fresh_state = (p.scan_nchunks != nchunks);  // the sentinel counts are laid out (and left zeroed) per array size
@@ -1064,7 +1064,151 @@ int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap) {
   GPU_LAUNCH(p.stream, k_chunk_sentinels, grid_for(n(), 256), 256, p.v, d_cs);
   GPU_LAUNCH(p.stream, k_chunk_counts, ntiles, 256, p.v, d_cs, d_cc, tile, p.d_tiles);
   GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, (ChainTable *)nullptr, (uint64_t)0, (uint64_t)0);
-  GPU_LAUNCH(p.stream, k_scan_write, ntiles, 256, p.v, (const uint32_t *)d_cc, tile, (const uint32_t *)p.d_tiles, d_rows, d_dst, cap);
+  GPU_LAUNCH(p.stream, k_scan_write, ntiles, 256, p.v, (const uint32_t *)d_cc, tile, (const uint32_t *)p.d_tiles, d_rows, d_dst, cap,
+             d_values, d_contrib);
+  return PPCSR_OK;
+}
+
+// ---- consumers ------------------------------------------------------------------------------------
+// bfs.h:15-36: level of every vertex from `start` (UINT32_MAX = unreachable); one launch per level over the gapped array
+int Engine::bfs(uint32_t start, uint32_t *levels, double *device_ms) {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  const uint32_t nn = n();
+  if (start >= nn) return fail(PPCSR_EINVAL, "bfs: start vertex out of range");
+  uint32_t *d_lv = nullptr, *d_f0 = nullptr, *d_f1 = nullptr, *d_cnt = nullptr;
+  GCHK(gpu::dmalloc((void **)&d_lv, (uint64_t)nn * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&d_f0, (uint64_t)nn * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&d_f1, (uint64_t)nn * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&d_cnt, 2 * sizeof(uint32_t)));  // [0] vertices found, [1] a hub was left to the streaming pass
+  p.timer.start(p.stream);
+  GCHK(gpu::dset(d_lv, 0xFF, (uint64_t)nn * sizeof(uint32_t), p.stream));
+  const uint32_t zero = 0;
+  GCHK(gpu::h2d(d_lv + start, &zero, sizeof(uint32_t), p.stream));
+  GCHK(gpu::h2d(d_f0, &start, sizeof(uint32_t), p.stream));
+  // Hybrid: a small frontier is expanded one wave per vertex (k_bfs_level, builds the next frontier list); a frontier that
+  // is a sizeable share of the graph is expanded by one streaming pass over the whole gapped array (k_bfs_edges) — its cost
+  // does not depend on hub degrees — and the list is rebuilt only when the frontier becomes small again.
+  uint32_t nfront = 1, level = 0;
+  uint32_t *cur = d_f0, *nxt = d_f1;
+  uint32_t h_cnt[2] = {0, 0};
+  bool have_list = true;
+  const uint64_t N = p.v.g.N;
+  const uint32_t big = (uint32_t)std::max<uint64_t>(64, (uint64_t)nn / 256);  // frontier size from which the pass is cheaper
+  while (nfront > 0) {
+    GCHK(gpu::dset(d_cnt, 0, 2 * sizeof(uint32_t), p.stream));
+    if (nfront >= big) {
+      GPU_LAUNCH(p.stream, k_bfs_edges, grid_for((N + 63) / 64, 4, 8192), 256, p.v, level, d_lv, d_cnt);
+      have_list = false;
+    } else {
+      if (!have_list) {  // (the pass only counted claims — an upper bound; the list gives the exact frontier)
+        GPU_LAUNCH(p.stream, k_bfs_collect, grid_for(nn, 256), 256, (const uint32_t *)d_lv, nn, level, cur, d_cnt);
+        GCHK(gpu::d2h(h_cnt, d_cnt, sizeof(uint32_t), p.stream));
+        GCHK(gpu::sync(p.stream));
+        nfront = h_cnt[0];
+        GCHK(gpu::dset(d_cnt, 0, 2 * sizeof(uint32_t), p.stream));
+      }
+      GPU_LAUNCH(p.stream, k_bfs_level, grid_for(nfront, 4, 16384), 256, p.v, (const uint32_t *)cur, nfront, level, d_lv, nxt, d_cnt);
+      have_list = true;
+      std::swap(cur, nxt);
+    }
+    GCHK(gpu::d2h(h_cnt, d_cnt, 2 * sizeof(uint32_t), p.stream));
+    GCHK(gpu::sync(p.stream));
+    GCHK(gpu::last_error());
+    if (h_cnt[1]) {  // hubs of this level were skipped by the per-vertex kernel: one pass finishes the level
+      GPU_LAUNCH(p.stream, k_bfs_edges, grid_for((N + 63) / 64, 4, 8192), 256, p.v, level, d_lv, d_cnt);
+      GCHK(gpu::d2h(h_cnt, d_cnt, sizeof(uint32_t), p.stream));
+      GCHK(gpu::sync(p.stream));
+      GCHK(gpu::last_error());
+      have_list = false;
+    }
+    nfront = h_cnt[0];
+    level++;
+  }
+  p.timer.stop(p.stream);
+  GCHK(gpu::d2h(levels, d_lv, (uint64_t)nn * sizeof(uint32_t), p.stream));
+  GCHK(gpu::sync(p.stream));
+  if (device_ms) *device_ms = p.timer.ms();
+  GPU_DFREE(d_lv);
+  GPU_DFREE(d_f0);
+  GPU_DFREE(d_f1);
+  GPU_DFREE(d_cnt);
+  return PPCSR_OK;
+}
+
+// stable sort of (key, value) pairs by key: rocPRIM's radix sort on the device, std::stable_sort in the CPU emulator
+static int sort_pairs_stable(gpu::stream_t st, uint32_t *kin, uint32_t *kout, float *vin, float *vout, uint64_t m, unsigned bits) {
+#if defined(PPCSR_SIM)
+  (void)st;
+  (void)bits;
+  std::vector<uint64_t> idx(m);
+  for (uint64_t i = 0; i < m; i++) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) { return kin[a] < kin[b]; });
+  for (uint64_t i = 0; i < m; i++) {
+    kout[i] = kin[idx[i]];
+    vout[i] = vin[idx[i]];
+  }
+  return 0;
+#else
+  size_t tmp_bytes = 0;
+  if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, (size_t)m, 0u, bits, st) != hipSuccess) return 3;
+  void *tmp = nullptr;
+  if (hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) return 2;
+  const hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, (size_t)m, 0u, bits, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  return e == hipSuccess ? 0 : 3;
+#endif
+}
+
+// pagerank.h:15-29: out[d] = sum over edges (s, d), in ascending s, of node_values[s] / num_neighbors(s).  The bulk scan
+// emits (dest, contribution) per edge in CSR order, a STABLE sort by dest keeps ascending source order inside every
+// destination, and one thread per destination adds its run sequentially: the reference's order of fp32 additions.
+int Engine::pagerank(const float *node_values, float *out, double *device_ms) {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  const uint32_t nn = n();
+  const uint64_t N = p.v.g.N;
+  float *d_val = nullptr, *d_c0 = nullptr, *d_c1 = nullptr, *d_out = nullptr;
+  uint32_t *d_k0 = nullptr, *d_k1 = nullptr;
+  GCHK(gpu::dmalloc((void **)&d_val, (uint64_t)nn * sizeof(float)));
+  GCHK(gpu::dmalloc((void **)&d_out, (uint64_t)nn * sizeof(float)));
+  GCHK(gpu::dmalloc((void **)&d_k0, N * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&d_k1, N * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&d_c0, N * sizeof(float)));
+  GCHK(gpu::dmalloc((void **)&d_c1, N * sizeof(float)));
+  GCHK(gpu::h2d(d_val, node_values, (uint64_t)nn * sizeof(float), p.stream));
+  p.timer.start(p.stream);
+  int rc = scan_launch(nullptr, reinterpret_cast<int *>(d_k0), N, d_val, d_c0);
+  if (rc != PPCSR_OK) return rc;
+  GCHK(gpu::d2h(p.h_total, p.d_total, sizeof(unsigned long long), p.stream));
+  GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
+  const uint64_t m = *p.h_total;
+  if (m) {
+    unsigned bits = 1;  // keys are clamped to [0, n]
+    while (bits < 32 && ((uint64_t)nn >> bits) != 0) bits++;
+    rc = sort_pairs_stable(p.stream, d_k0, d_k1, d_c0, d_c1, m, bits);
+    if (rc != 0) return fail(rc == 2 ? PPCSR_ENOMEM : PPCSR_EHIP, "pagerank: device sort failed");
+  }
+  uint32_t *d_long = nullptr;  // [0]: count, [1..]: destinations with long runs
+  GCHK(gpu::dmalloc((void **)&d_long, ((uint64_t)nn + 1) * sizeof(uint32_t)));
+  GCHK(gpu::dset(d_long, 0, sizeof(uint32_t), p.stream));
+  GPU_LAUNCH(p.stream, k_pr_segsum, grid_for(nn, 256), 256, (const uint32_t *)d_k1, (const float *)d_c1, m, nn, d_out, d_long + 1, d_long);
+  GPU_LAUNCH(p.stream, k_pr_longruns, 2048, 256, (const uint32_t *)d_k1, (const float *)d_c1, m, (const uint32_t *)(d_long + 1),
+             (const uint32_t *)d_long, d_out);
+  p.timer.stop(p.stream);
+  GCHK(gpu::d2h(out, d_out, (uint64_t)nn * sizeof(float), p.stream));
+  GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
+  if (device_ms) *device_ms = p.timer.ms();
+  GPU_DFREE(d_val);
+  GPU_DFREE(d_out);
+  GPU_DFREE(d_k0);
+  GPU_DFREE(d_k1);
+  GPU_DFREE(d_c0);
+  GPU_DFREE(d_c1);
+  GPU_DFREE(d_long);
   return PPCSR_OK;
 }
 

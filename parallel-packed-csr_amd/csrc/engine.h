@@ -44,6 +44,9 @@ class Engine {
   int read_neighbourhood(int src);
   int scan_all(uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *total);
   int scan_all_device(double *ms, uint64_t *total);  // device-only timing of the bulk scan (bench)
+  // graph-algorithm consumers over the gapped array (reference: src/utility/bfs.h, src/utility/pagerank.h)
+  int bfs(uint32_t start, uint32_t *levels, double *device_ms);
+  int pagerank(const float *node_values, float *out, double *device_ms);
   int export_state(Edge *items, Node *nodes);
   int check_invariants(uint64_t *bad);  // leafcnt == recount(items)
   int stats(EngineStats *out);
@@ -75,7 +78,7 @@ class Engine {
   int run_speculative(const Op *d_ops, uint64_t n);
   int rebalance_fused(const View &nv, const Edge *src_items, uint64_t src_lo, uint64_t src_len, int src_sh, uint32_t *src_cnt,
                       bool inplace, uint64_t tb_index, uint64_t tb_len, Edge *dst, uint64_t dst_bias, uint32_t *dst_cnt, uint64_t dst_nleaves);
-  int scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap);
+  int scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap, const float *d_values = nullptr, float *d_contrib = nullptr);
 
  public:
   struct Impl;

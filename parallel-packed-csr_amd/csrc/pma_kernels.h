@@ -897,8 +897,10 @@ PMA_KERNEL void k_chunk_counts(View v, uint32_t *chunk_sent, uint32_t *chunkcnt,
 // bulk neighbour scan (CSR export), final streaming pass: one workgroup per tile of chunks.  The tile's chunk counts are
 // scanned in LDS (offset = scanned tile sum + in-tile prefix), then every wave streams its chunks — four in flight —
 // writing dests in array order == CSR order and the row offsets at the sentinels.
+// (contrib != nullptr: also emit, per edge, node_values[src] / num_neighbors(src) — the PageRank push of pagerank.h:21)
 PMA_KERNEL void k_scan_write(View v, const uint32_t *__restrict__ chunkcnt, uint32_t tile_chunks, const uint32_t *__restrict__ tile_excl,
-                             unsigned long long *__restrict__ row_offsets, int *__restrict__ dests, uint64_t cap) {
+                             unsigned long long *__restrict__ row_offsets, int *__restrict__ dests, uint64_t cap,
+                             const float *__restrict__ node_values, float *__restrict__ contrib) {
   PMA_SHARED uint32_t pre[256];
   PMA_SHARED uint32_t wsum[4];
   const int lane = wv::lane(), w = wv::wave_in_block();
@@ -940,12 +942,148 @@ PMA_KERNEL void k_scan_write(View v, const uint32_t *__restrict__ chunkcnt, uint
       const bool live = nn && !sent && (s + 1 < N);
       const uint64_t m = wv::ballot(live);
       const unsigned long long o = base + pre[c0 + q] + dev::lanemask_lt_count(m, lane);
-      if (live && o < cap) dests[o] = (int)e[q].dest;
-      if (sent) {
+      if (live && o < cap) {
+        dests[o] = (int)e[q].dest;
+        if (contrib != nullptr) {
+          if (e[q].dest >= v.g.n) dests[o] = (int)v.g.n;  // (the reference would write out of bounds; keeps the sort keys short)
+          const uint32_t sv = e[q].src;
+          contrib[o] = (sv < v.g.n) ? node_values[sv] / (float)v.nodes[sv].num_neighbors : 0.0f;
+        }
+      }
+      if (sent && row_offsets != nullptr) {
         const uint32_t vid = (e[q].value == kMax) ? 0u : e[q].value;
         row_offsets[vid] = o;
       }
     }
+  }
+}
+
+// ---- graph-algorithm consumers over the gapped array (reference: src/utility/bfs.h, src/utility/pagerank.h) -----------
+// BFS, one level per launch: one wave per frontier vertex walks its slot range (beginning, end) 64 slots at a time, skips
+// nulls, claims unvisited neighbours with a compare-and-swap on their level and appends them to the next frontier (one
+// atomic per wave per 64 slots).  Levels are unique, so the result equals the reference's queue-based walk exactly.
+constexpr uint64_t kBfsWaveSlots = 4096;  // longest slot range one wave walks on its own
+PMA_KERNEL void k_bfs_level(View v, const uint32_t *front, uint32_t nfront, uint32_t level, uint32_t *levels, uint32_t *next,
+                            uint32_t *next_count) {
+  const int lane = wv::lane();
+  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
+  for (uint64_t f = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); f < nfront; f += wstride) {
+    const uint32_t u = front[f];
+    const Node nd = v.nodes[u];
+    if ((uint64_t)nd.end - (uint64_t)nd.beginning > kBfsWaveSlots) {  // a hub: leave it to one streaming pass (k_bfs_edges)
+      if (lane == 0) next_count[1] = 1u;
+      continue;
+    }
+    for (uint64_t base = (uint64_t)nd.beginning + 1; base < (uint64_t)nd.end; base += 64) {
+      const uint64_t s = base + (uint64_t)lane;
+      uint32_t val = 0, dst = 0;
+      if (s < (uint64_t)nd.end) {
+        val = v.items[s].value;
+        dst = v.items[s].dest;
+      }
+      bool won = false;
+      if (val != 0 && dst < v.g.n && levels[dst] == kMax) won = wv::atomic_cas_u32(&levels[dst], kMax, level + 1u) == kMax;
+      const uint64_t m = wv::ballot(won);
+      if (m) {
+        uint32_t b = 0;
+        if (lane == 0) b = wv::atomic_add_u32(next_count, (uint32_t)wv::popc64(m));
+        b = wv::shfl(b, 0);
+        if (won) next[b + dev::lanemask_lt_count(m, lane)] = dst;
+      }
+    }
+  }
+}
+// BFS level for a LARGE frontier: one streaming pass over the gapped array instead of one wave per frontier vertex (whose
+// hubs would serialise the level): every live edge whose source sits on the current level claims its destination.  All
+// writers of a level store the same value, so plain stores suffice; `found` counts the claims (an upper bound is enough:
+// it only steers the choice of the next level's kernel, and zero means "done").
+PMA_KERNEL void k_bfs_edges(View v, uint32_t level, uint32_t *levels, uint32_t *found) {
+  const int lane = wv::lane();
+  const uint64_t N = v.g.N, nchunks = (N + 63) / 64;
+  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
+  uint32_t mine = 0;
+  for (uint64_t ch = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); ch < nchunks; ch += wstride) {
+    const uint64_t s = ch * 64 + (uint64_t)lane;
+    Edge e = null_edge();
+    if (s + 1 < N) e = v.items[s];  // (slot N-1 is never part of a neighbourhood)
+    const bool live = e.value != 0 && !is_sentinel(e) && e.src < v.g.n && e.dest < v.g.n;
+    if (live && levels[e.src] == level && levels[e.dest] == kMax) {
+      levels[e.dest] = level + 1u;
+      mine++;
+    }
+  }
+  mine = wv::reduce_add(mine);
+  if (lane == 0 && mine) wv::atomic_add_u32(found, mine);
+}
+// frontier list of one level (used when a small frontier follows an edge-centric level)
+PMA_KERNEL void k_bfs_collect(const uint32_t *levels, uint32_t n, uint32_t level, uint32_t *front, uint32_t *count) {
+  const int lane = wv::lane();
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t base = (uint64_t)wv::block_idx() * wv::block_dim() + (wv::thread_idx() & ~63u); base < n; base += stride) {
+    const uint64_t u = base + (uint64_t)lane;
+    const bool in = u < n && levels[u] == level;
+    const uint64_t m = wv::ballot(in);
+    if (m) {
+      uint32_t b = 0;
+      if (lane == 0) b = wv::atomic_add_u32(count, (uint32_t)wv::popc64(m));
+      b = wv::shfl(b, 0);
+      if (in) front[b + dev::lanemask_lt_count(m, lane)] = (uint32_t)u;
+    }
+  }
+}
+// PageRank push, last step: contributions sorted (stably) by destination; every destination's run is added IN ORDER —
+// ascending source, the order in which the reference's loop adds them — so the fp32 sums are the reference's bit for bit.
+// One thread per destination handles short runs; a run of kPrLongRun or more is queued for k_pr_longruns.
+constexpr uint32_t kPrLongRun = 128;
+PMA_KERNEL void k_pr_segsum(const uint32_t *__restrict__ keys, const float *__restrict__ vals, uint64_t m, uint32_t n, float *out,
+                            uint32_t *long_list, uint32_t *long_count) {
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t d = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); d < n; d += stride) {
+    uint64_t lo = 0, hi = m;  // first position with keys[pos] >= d
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (keys[mid] < (uint32_t)d) lo = mid + 1; else hi = mid;
+    }
+    uint64_t lo2 = lo, hi2 = (lo + kPrLongRun < m) ? lo + kPrLongRun : m;  // first position (within reach) with keys[pos] > d
+    while (lo2 < hi2) {
+      const uint64_t mid = (lo2 + hi2) >> 1;
+      if (keys[mid] <= (uint32_t)d) lo2 = mid + 1; else hi2 = mid;
+    }
+    if (lo2 - lo >= kPrLongRun) {  // long (or longer) run: a whole wave streams it
+      long_list[wv::atomic_add_u32(long_count, 1u)] = (uint32_t)d;
+      continue;
+    }
+    float acc = 0.0f;
+    for (uint64_t i = lo; i < lo2; i++) acc += vals[i];
+    out[d] = acc;
+  }
+}
+// one wave per long run: 64 contributions are loaded at once, then added one after the other in order (the adds are the
+// serial part by definition; the loads no longer are)
+PMA_KERNEL void k_pr_longruns(const uint32_t *__restrict__ keys, const float *__restrict__ vals, uint64_t m, const uint32_t *long_list,
+                              const uint32_t *long_count, float *out) {
+  const int lane = wv::lane();
+  const uint32_t nl = *long_count;
+  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
+  for (uint64_t w = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); w < nl; w += wstride) {
+    const uint32_t d = long_list[w];
+    uint64_t lo = 0, hi = m;
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi) >> 1;
+      if (keys[mid] < d) lo = mid + 1; else hi = mid;
+    }
+    float acc = 0.0f;
+    for (uint64_t base = lo; base < m; base += 64) {
+      const uint64_t i = base + (uint64_t)lane;
+      const bool in = i < m && keys[i] == d;
+      float x = 0.0f;
+      if (in) x = vals[i];
+      const uint64_t mm = wv::ballot(in);
+      const int cnt = wv::popc64(mm);  // (the run is contiguous: lanes 0 .. cnt-1)
+      for (int q = 0; q < cnt; q++) acc += wv::shfl_f32(x, q);
+      if (cnt < 64) break;
+    }
+    if (lane == 0) out[d] = acc;
   }
 }
 

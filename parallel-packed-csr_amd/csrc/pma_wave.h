@@ -18,6 +18,7 @@ PMA_DEV int lane() { return (int)(threadIdx.x & 63u); }
 PMA_DEV int wave_in_block() { return (int)(threadIdx.x >> 6); }
 PMA_DEV uint64_t ballot(bool p) { return (uint64_t)__ballot(p ? 1 : 0); }
 PMA_DEV uint32_t shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+PMA_DEV float shfl_f32(float v, int src) { return __shfl(v, src, 64); }
 PMA_DEV uint32_t first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 PMA_DEV uint32_t reduce_add(uint32_t v) {
 #pragma unroll
@@ -36,6 +37,7 @@ PMA_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v
 PMA_DEV unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 PMA_DEV uint32_t atomic_max_u32(uint32_t *p, uint32_t v) { return atomicMax(p, v); }
 PMA_DEV uint32_t atomic_exch_u32(uint32_t *p, uint32_t v) { return atomicExch(p, v); }
+PMA_DEV uint32_t atomic_cas_u32(uint32_t *p, uint32_t expect, uint32_t v) { return atomicCAS(p, expect, v); }
 PMA_DEV int popc64(uint64_t m) { return __popcll((unsigned long long)m); }
 PMA_DEV int ctz64(uint64_t m) { return __ffsll((long long)m) - 1; }
 PMA_DEV uint32_t block_idx() { return blockIdx.x; }

@@ -131,6 +131,20 @@ class PCSR {
     nodes->resize(get_n());
     check(ppcsr_export_state(h_, reinterpret_cast<ppcsr_edge *>(items->data()), reinterpret_cast<ppcsr_node *>(nodes->data())));
   }
+  // the reference's consumers (src/utility/bfs.h, pagerank.h) run on the device over the gapped array; host/bfs.h and
+  // host/pagerank.h route the reference's free functions here
+  std::vector<uint32_t> bfs(uint32_t start_node) {
+    flush();
+    std::vector<uint32_t> out(get_n());
+    check(ppcsr_bfs(h_, start_node, out.data(), nullptr));
+    return out;
+  }
+  std::vector<float> pagerank(const std::vector<float> &node_values) {
+    flush();
+    std::vector<float> out(get_n());
+    check(ppcsr_pagerank(h_, node_values.data(), out.data(), nullptr));
+    return out;
+  }
   ppcsr_t handle() { return h_; }
   size_t pending() const { return pending_.size(); }
   static bool &quiet() {

@@ -2,18 +2,23 @@
 // host shims (gtest is not installed).  Same workloads, same assertions; the lock-release checks go through the
 // inert lock stand-ins so the test source reads like the reference's.  Built and run by tests/test_cpp_host.py (-m gpu).
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
 #include "PPPCSR.h"
+#include "bfs.h"
+#include "pagerank.h"
 
 static int failures = 0;
 #define EXPECT_TRUE(c) do { if (!(c)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); failures++; } } while (0)
 #define EXPECT_FALSE(c) EXPECT_TRUE(!(c))
 #define EXPECT_EQ(a, b) do { if (!((a) == (b))) { std::printf("FAIL %s:%d: %s == %s\n", __FILE__, __LINE__, #a, #b); failures++; } } while (0)
 
+// the reference's consumers: engine-backed PCSR -> GPU (host/bfs.h, host/pagerank.h); the templates below are the host
+// statements of src/utility/bfs.h:15-36 and pagerank.h:15-29, used to cross-check the GPU results through the same API
 template <typename T>
-static std::vector<uint32_t> bfs(T &graph, uint32_t start) {  // reference consumer src/utility/bfs.h:15-36
+static std::vector<uint32_t> host_bfs(T &graph, uint32_t start) {
   uint64_t n = graph.get_n();
   std::vector<uint32_t> out(n, UINT32_MAX), queue{start};
   out[start] = 0;
@@ -96,13 +101,17 @@ static void run(bool lock_search) {
     uint64_t x = 1234567ull;
     auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x >> 11); };
     for (int i = 1; i < 50001; ++i) pcsr.add_edge(rnd() % 1000, rnd() % 1000, i);
-    auto res = bfs(pcsr, 0);
+    auto res = bfs(pcsr, 0);  // host/bfs.h -> ppcsr_bfs on the GPU
     EXPECT_EQ(res.size(), 1000u);
+    EXPECT_TRUE(res == host_bfs(pcsr, 0));
     std::vector<float> weights(pcsr.get_n(), 1.0f), output(pcsr.get_n(), 0.0f);
-    for (uint64_t i = 0; i < pcsr.get_n(); i++) {  // src/utility/pagerank.h:15-29
+    for (uint64_t i = 0; i < pcsr.get_n(); i++) {  // src/utility/pagerank.h:15-29 on the host
       const float contrib = weights[i] / pcsr.getNode((int)i).num_neighbors;
       for (int nb : pcsr.get_neighbourhood((int)i)) output[nb] += contrib;
     }
+    auto pr = pagerank(pcsr, weights);  // host/pagerank.h -> ppcsr_pagerank on the GPU
+    EXPECT_EQ(pr.size(), 1000u);
+    EXPECT_TRUE(memcmp(pr.data(), output.data(), output.size() * sizeof(float)) == 0);
     EXPECT_EQ(output.size(), 1000u);
   }
 }

@@ -74,3 +74,39 @@ def replay_golden(make_engine, name, check_every=True):
         np.testing.assert_array_equal(items, g["items"])
         np.testing.assert_array_equal(nodes, g["nodes"])
     return eng
+
+
+def reference_consumers(oracle, start, node_values):
+    """src/utility/bfs.h:15-36 and src/utility/pagerank.h:15-29 evaluated on an oracle's state with numpy: BFS levels
+    (uint32, 0xFFFFFFFF = unreachable) and the one-step PageRank push with fp32 additions in the reference's order
+    (np.add.at applies its updates one by one in index order = ascending source, neighbours in slot order)."""
+    import numpy as np
+    items, nodes = oracle.state()
+    n = len(nodes)
+    live = (items[:, 2] != 0) & (items[:, 1] != 0xFFFFFFFF)
+    live[-1] = False  # slot N-1 is never part of a neighbourhood
+    src = items[live, 0].astype(np.int64)
+    dst = items[live, 1].astype(np.int64)
+    # BFS by levels
+    lv = np.full(n, 0xFFFFFFFF, np.uint32)
+    lv[start] = 0
+    order = np.argsort(src, kind="stable")
+    s_sorted, d_sorted = src[order], dst[order]
+    rows = np.searchsorted(s_sorted, np.arange(n + 1))
+    front = np.array([start], np.int64)
+    level = 0
+    while len(front):
+        nb = np.concatenate([d_sorted[rows[u]:rows[u + 1]] for u in front]) if len(front) else np.empty(0, np.int64)
+        nb = nb[nb < n]
+        nb = np.unique(nb[lv[nb] == 0xFFFFFFFF])
+        level += 1
+        lv[nb] = level
+        front = nb
+    # PageRank push: edges are visited in array order == (source ascending, slot order)
+    vals = np.asarray(node_values, np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        contrib = (vals / nodes[:, 2].astype(np.float32)).astype(np.float32)
+    out = np.zeros(n, np.float32)
+    ok = dst < n
+    np.add.at(out, dst[ok], contrib[src[ok]])
+    return lv, out

@@ -35,6 +35,13 @@ inline int lane() { return sim::cur_tid() & 63; }
 inline int wave_in_block() { return sim::cur_tid() >> 6; }
 inline uint64_t ballot(bool p) { return sim::ballot(p); }
 inline uint32_t shfl(uint32_t v, int src) { return (uint32_t)sim::shfl64(v, src); }
+inline float shfl_f32(float v, int src) {
+  uint32_t b;
+  memcpy(&b, &v, 4);
+  b = (uint32_t)sim::shfl64(b, src);
+  memcpy(&v, &b, 4);
+  return v;
+}
 inline uint32_t first(uint32_t v) { return v; }  // callers only pass wave-uniform values
 inline uint32_t reduce_add(uint32_t v) { return (uint32_t)sim::reduce_add64(v); }
 inline void fence() { (void)sim::shfl64(0, 0); }  // lanes run sequentially between collectives: a fence must be a rendezvous
@@ -46,6 +53,7 @@ inline uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = 
 inline unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline uint32_t atomic_max_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomic_exch_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
+inline uint32_t atomic_cas_u32(uint32_t *p, uint32_t expect, uint32_t v) { uint32_t o = *p; if (o == expect) *p = v; return o; }
 inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 inline int ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
 inline uint32_t block_idx() { return (uint32_t)sim::cur_block(); }

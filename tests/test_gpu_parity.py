@@ -253,6 +253,33 @@ def test_big_window_rebalance(pkg, streams, variant, tile, batch):
     _same(e, o, "updates after the rebalances")
 
 
+def test_consumers_bfs_pagerank(pkg, streams):
+    """GPU BFS / PageRank push over the gapped array == the reference's bfs.h / pagerank.h templates
+    evaluated on the oracle's state; PageRank compared bit for bit (fp32 additions in the reference's order), incl. a
+    vertex whose num_neighbors is 0 or wrapped (division quirks) and dests beyond n (skipped)"""
+    from helpers import reference_consumers
+    scale, m = 14, 300_000
+    n = 1 << scale
+    s, d = streams.rmat_edges(scale, m, seed=31)
+    ops = streams.adds(s, d)
+    dele = ops[::7].copy()
+    dele[:, 2] = 0
+    extra = np.array([[5, n + 3, 1], [9, 1, 0], [9, 1, 0]], np.uint32)  # dest beyond n; deletes of a missing edge (count wraps)
+    ops = np.concatenate([ops, dele, extra])
+    eng, o = pkg.PCSR(n), Oracle(n)
+    eng.apply(ops)
+    o.apply(ops)
+    vals = (streams.uniform_ints(32, n, 1000).astype(np.float32) / np.float32(7.0)).astype(np.float32)
+    for start in (0, 1, int(s[12345])):
+        lv, pr = reference_consumers(o, start, vals)
+        got, ms = eng.bfs(start, with_ms=True)
+        np.testing.assert_array_equal(got, lv)
+    got, ms = eng.pagerank(vals, with_ms=True)
+    assert got.tobytes() == pr.tobytes(), f"pagerank differs at {np.nonzero(got.view(np.uint32) != pr.view(np.uint32))[0][:8]}"
+    with pytest.raises(pkg.PpcsrError):
+        eng.bfs(n)
+
+
 def test_bucket_ops_device_matches_host_routing(pkg, streams):
     """HIP counting-sort bucketing (the multi-GPU exchange's device side) == torch stable sort == host routine"""
     import importlib.util

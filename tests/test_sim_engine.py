@@ -189,6 +189,24 @@ def test_sim_sparse_hub_searches(sim, streams):
         np.testing.assert_array_equal(ei, oi)
 
 
+def test_sim_consumers_bfs_pagerank(sim, streams):
+    """device BFS / PageRank over the gapped array == the reference's templates (bfs.h, pagerank.h) on the oracle state;
+    PageRank bit for bit (same order of fp32 additions)"""
+    from helpers import reference_consumers
+    n = 200
+    ops = streams.random_stream(n, 3000, seed=21, p_delete=0.15)
+    ops[:, 1] %= n
+    e, o = sim(n, mode=1), Oracle(n)
+    e.apply(ops)
+    o.apply(ops)
+    vals = (np.arange(n, dtype=np.float32) % 7 + 0.25).astype(np.float32)
+    for start in (0, 17, n - 1):
+        lv, pr = reference_consumers(o, start, vals)
+        np.testing.assert_array_equal(e.bfs(start), lv)
+    got = e.pagerank(vals)
+    assert got.tobytes() == pr.tobytes()
+
+
 def test_chain_table_matches_serial_fp64_chain():
     """the piecewise-linear position table (built with the fp64-reciprocal division) == the oracle's serial `x -= step`
     chain (PCSR.cpp:237-247), for windows up to 2^31 slots and densities across the PMA's range"""
