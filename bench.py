@@ -353,6 +353,17 @@ def main():
                                   "pagerank_edges_per_s": tot / (pms * 1e-3),
                                   "note": "device time; pagerank = bulk scan + stable radix sort by dest + in-order "
                                           "segment sums (bit-identical to the reference's fp32 loop)"}
+            # non-parity bulk build of the same core graph on a fresh engine beside the parity load above
+            if P == 1:
+                eb = pkg.PCSR(my_n, device=dev_id)
+                tb0 = time.perf_counter()
+                bb_ms = eb.bulk_build(core_blk, with_ms=True)
+                tb1 = time.perf_counter()
+                extra["bulk_build"] = {"edges": int(len(core_blk)), "device_ms": bb_ms, "wall_ms_incl_h2d": (tb1 - tb0) * 1e3,
+                                       "edges_per_s_device": len(core_blk) / (bb_ms * 1e-3), "N_slots": int(eb.geometry()[0]),
+                                       "note": "NOT layout-identical to the one-by-one build (history dependent); same edge "
+                                               "set, values, num_neighbors and invariants"}
+                eb.close()
             for label, w in (("window_rebalance", int(stt["N"])), ("window_rebalance_half", int(stt["N"]) // 2)):
                 rms = eng.bench_rebalance(w, 5)
                 extra[label] = {"window_slots": w, "ms_per_call": rms, "alg_GBps": 24.0 * w / (rms * 1e-3) / 1e9,

@@ -88,6 +88,13 @@ int ppcsr_get_neighbourhood(ppcsr_t h, int src, int *out, uint64_t cap, uint64_t
 int ppcsr_read_neighbourhood(ppcsr_t h, int src);
 /* bulk neighbour scan: get_neighbourhood for every vertex at once as CSR (row_offsets[n+1], dests[total]) */
 int ppcsr_scan_all(ppcsr_t h, uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *total);
+/* Bulk build of an EMPTY graph from a list of adds — an explicit NON-parity fast path: the reference can
+ * only build a graph by single inserts (src/main.cpp:160-189 feeds add_edge one line at a time) and the array layout that
+ * produces depends on the insertion history.  This call yields a valid packed-memory array with the same neighbourhoods,
+ * the same num_neighbors (every add counts, duplicates keep the last value) and the same invariants, but NOT the slot
+ * layout of the one-by-one build; updates applied afterwards go through the ordinary (sequentially exact) path.  Entries
+ * with op == 0 or src >= n are ignored, as add_edge ignores them.  Fails with EINVAL if the graph already holds edges. */
+int ppcsr_bulk_build(ppcsr_t h, const ppcsr_op *adds, uint64_t n, double *device_ms);
 /* Graph-algorithm consumers run on the device over the gapped array.
  * bfs — src/utility/bfs.h:15-36: levels[v] = BFS level of v from `start`, UINT32_MAX when unreachable (levels: n entries).
  * pagerank — src/utility/pagerank.h:15-29: one push step, out[d] = sum over edges (s, d), in ascending s, of

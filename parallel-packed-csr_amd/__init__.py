@@ -38,7 +38,7 @@ class Stats(ctypes.Structure):
 EXPORTED = [
     "ppcsr_create", "ppcsr_destroy", "ppcsr_add_edge", "ppcsr_remove_edge", "ppcsr_add_node", "ppcsr_apply_batch",
     "ppcsr_apply_batch_device", "ppcsr_edge_exists", "ppcsr_get_n", "ppcsr_get_node", "ppcsr_geometry",
-    "ppcsr_get_neighbourhood", "ppcsr_read_neighbourhood", "ppcsr_scan_all", "ppcsr_bfs", "ppcsr_pagerank", "ppcsr_export_state", "ppcsr_stats",
+    "ppcsr_get_neighbourhood", "ppcsr_read_neighbourhood", "ppcsr_scan_all", "ppcsr_bulk_build", "ppcsr_bfs", "ppcsr_pagerank", "ppcsr_export_state", "ppcsr_stats",
     "ppcsr_set_option", "ppcsr_snapshot", "ppcsr_restore", "ppcsr_check_invariants", "ppcsr_bench_scan_all", "ppcsr_bench_rebalance", "ppcsr_strerror",
     "ppcsr_last_error", "ppcsr_device_count", "pppcsr_create", "pppcsr_destroy", "pppcsr_num_partitions",
     "pppcsr_get_partition", "pppcsr_partition_start", "pppcsr_partition", "pppcsr_add_edge", "pppcsr_remove_edge",
@@ -96,6 +96,7 @@ def load_library(path=None):
     L.ppcsr_get_neighbourhood.argtypes = [c_vp, c_int, c_vp, c_u64, ctypes.POINTER(c_u64)]
     L.ppcsr_read_neighbourhood.argtypes = [c_vp, c_int]
     L.ppcsr_scan_all.argtypes = [c_vp, c_vp, c_vp, c_u64, ctypes.POINTER(c_u64)]
+    L.ppcsr_bulk_build.argtypes = [c_vp, c_vp, c_u64, ctypes.POINTER(ctypes.c_double)]
     L.ppcsr_bfs.argtypes = [c_vp, c_u32, c_vp, ctypes.POINTER(ctypes.c_double)]
     L.ppcsr_pagerank.argtypes = [c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_double)]
     L.ppcsr_export_state.argtypes = [c_vp, c_vp, c_vp]
@@ -202,6 +203,13 @@ class PCSR:
 
     def apply_device(self, dev_ptr, n):
         self._chk(self.L.ppcsr_apply_batch_device(self.h, dev_ptr, n))
+
+    def bulk_build(self, ops, with_ms=False):
+        """NON-parity fast path: build an empty graph from a list of adds in a few device passes"""
+        a = _ops(ops)
+        ms = ctypes.c_double(0.0)
+        self._chk(self.L.ppcsr_bulk_build(self.h, a.ctypes.data, len(a), ctypes.byref(ms)))
+        return ms.value if with_ms else None
 
     # consumers on the device (reference: src/utility/bfs.h, src/utility/pagerank.h)
     def bfs(self, start, with_ms=False):

@@ -107,6 +107,11 @@ int ppcsr_scan_all(ppcsr_t h, uint64_t *row_offsets, int *dests, uint64_t cap, u
   H_CHECK();
   return ret(h->e, h->e->scan_all(row_offsets, dests, cap, total));
 }
+int ppcsr_bulk_build(ppcsr_t h, const ppcsr_op *adds, uint64_t n, double *device_ms) {
+  H_CHECK();
+  if (!adds && n) return bad("bulk_build: null input");
+  return ret(h->e, h->e->bulk_build(reinterpret_cast<const ppcsr::Op *>(adds), n, device_ms));
+}
 int ppcsr_bfs(ppcsr_t h, uint32_t start, uint32_t *levels, double *device_ms) {
   H_CHECK();
   if (!levels) return bad("bfs: null output");

@@ -1069,6 +1069,125 @@ int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap, co
   return PPCSR_OK;
 }
 
+// ---- bulk build (kernels k_bb_*) -----------------------------------------------------------------------
+static int sort_edges_stable(gpu::stream_t st, unsigned long long *kin, unsigned long long *kout, uint32_t *vin, uint32_t *vout,
+                             uint64_t m, unsigned bits) {
+#if defined(PPCSR_SIM)
+  (void)st;
+  (void)bits;
+  std::vector<uint64_t> idx(m);
+  for (uint64_t i = 0; i < m; i++) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) { return kin[a] < kin[b]; });
+  for (uint64_t i = 0; i < m; i++) {
+    kout[i] = kin[idx[i]];
+    vout[i] = vin[idx[i]];
+  }
+  return 0;
+#else
+  size_t tmp_bytes = 0;
+  if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, (size_t)m, 0u, bits, st) != hipSuccess) return 3;
+  void *tmp = nullptr;
+  if (hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1) != hipSuccess) return 2;
+  const hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, (size_t)m, 0u, bits, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(tmp);
+  return e == hipSuccess ? 0 : 3;
+#endif
+}
+
+int Engine::bulk_build(const Op *host_ops, uint64_t m, double *device_ms) {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  const uint32_t nn = n();
+  if (nn == 0) return fail(PPCSR_EINVAL, "bulk_build: the graph has no vertices");
+  if (m >= (1ull << 31)) return fail(PPCSR_EUNSUPPORTED, "bulk_build: too many edges for one call");
+  {  // only an EMPTY graph can be bulk-built (everything live must be a sentinel)
+    int rc = rank_scan(p.v.leafcnt, p.v.g.N >> p.v.g.sh, false, 0, 0);
+    if (rc != PPCSR_OK) return rc;
+    GCHK(gpu::d2h(p.h_total, p.d_total, sizeof(unsigned long long), p.stream));
+    GCHK(gpu::sync(p.stream));
+    if (*p.h_total != (unsigned long long)nn) return fail(PPCSR_EINVAL, "bulk_build: the graph already holds edges");
+  }
+  Op *d_ops = nullptr;
+  unsigned long long *d_k0 = nullptr, *d_k1 = nullptr;
+  uint32_t *d_v0 = nullptr, *d_v1 = nullptr, *d_flags = nullptr;
+  const uint64_t mm = std::max<uint64_t>(m, 1);
+  GCHK(gpu::dmalloc((void **)&d_ops, mm * sizeof(Op)));
+  GCHK(gpu::dmalloc((void **)&d_k0, mm * sizeof(unsigned long long)));
+  GCHK(gpu::dmalloc((void **)&d_k1, mm * sizeof(unsigned long long)));
+  GCHK(gpu::dmalloc((void **)&d_v0, mm * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&d_v1, mm * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&d_flags, mm * sizeof(uint32_t)));
+  if (m) GCHK(gpu::h2d(d_ops, host_ops, m * sizeof(Op), p.stream));
+  p.timer.start(p.stream);
+  uint64_t E = 0;
+  if (m) {
+    GPU_LAUNCH(p.stream, k_bb_keys, grid_for(m, 256), 256, (const Op *)d_ops, m, nn, d_k0, d_v0);
+    unsigned bits = 1;  // the source half of the key never exceeds n (entries to ignore carry src = n)
+    while (bits < 32 && ((uint64_t)nn >> bits) != 0) bits++;
+    int rc = sort_edges_stable(p.stream, d_k0, d_k1, d_v0, d_v1, m, 32u + bits);
+    if (rc != 0) return fail(rc == 2 ? PPCSR_ENOMEM : PPCSR_EHIP, "bulk_build: device sort failed");
+    GPU_LAUNCH(p.stream, k_bb_flags, grid_for(m, 256), 256, (const unsigned long long *)d_k1, m, nn, d_flags);
+    rc = rank_scan(d_flags, m, false, 0, 0);
+    if (rc != PPCSR_OK) return rc;
+    GCHK(gpu::d2h(p.h_total, p.d_total, sizeof(unsigned long long), p.stream));
+    GCHK(gpu::sync(p.stream));
+    GCHK(gpu::last_error());
+    E = *p.h_total;
+  } else {
+    const unsigned long long zero = 0;
+    GCHK(gpu::h2d(p.d_total, &zero, sizeof(zero), p.stream));
+  }
+  // array size: the smallest power of two (not below the current one) whose root still accepts one more insert
+  const uint64_t j = (uint64_t)nn + E;
+  const View old = p.v;
+  uint64_t newN = old.g.N;
+  Geometry g;
+  for (;;) {
+    compute_geometry(newN, nn, old.g.lock_search, &g);
+    if (j + 1 < (uint64_t)g.t_up[0] || newN >= (1ull << 31)) break;
+    newN *= 2;
+  }
+  if (j + 1 >= (uint64_t)g.t_up[0]) return fail(PPCSR_EUNSUPPORTED, "bulk_build: edge array would exceed 2^31 slots");
+  View nv = old;
+  nv.g = g;
+  GCHK(gpu::dmalloc((void **)&nv.items, newN * sizeof(Edge)));
+  GCHK(gpu::dmalloc((void **)&nv.leafcnt, (newN >> g.sh) * sizeof(uint32_t)));
+  ChainTable *htb = new ChainTable;
+  build_chain_table(0, newN, j, htb);
+  const bool overflow = htb->overflow != 0;
+  GCHK(gpu::h2d(p.d_table, htb, sizeof(ChainTable), p.stream));
+  GCHK(gpu::sync(p.stream));
+  delete htb;
+  if (overflow) return fail(PPCSR_EINTERNAL, "bulk_build: position table overflow");
+  GPU_LAUNCH(p.stream, k_fill_null, grid_for(newN * 3, 256 * 8), 256, nv.items, (uint64_t)0, newN);
+  GPU_LAUNCH(p.stream, k_bb_vertices, grid_for(nn, 256), 256, nv, (const unsigned long long *)d_k1, m, (const uint32_t *)p.d_rank,
+             (const unsigned long long *)p.d_total, (const ChainTable *)p.d_table);
+  if (m)
+    GPU_LAUNCH(p.stream, k_bb_edges, grid_for(m, 256), 256, nv, (const unsigned long long *)d_k1, (const uint32_t *)d_v1,
+               (const uint32_t *)d_flags, (const uint32_t *)p.d_rank, m, (const ChainTable *)p.d_table);
+  GPU_LAUNCH(p.stream, k_recount, grid_for((newN + 63) / 64, 4), 256, nv, (uint64_t)0, newN);
+  p.timer.stop(p.stream);
+  GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
+  if (device_ms) *device_ms = p.timer.ms();
+  GPU_DFREE(old.items);
+  GPU_DFREE(old.leafcnt);
+  {
+    View tmp = old;
+    free_aux(p, tmp);
+  }
+  p.v = nv;
+  GCHK(alloc_aux(p, p.v));
+  GPU_DFREE(d_ops);
+  GPU_DFREE(d_k0);
+  GPU_DFREE(d_k1);
+  GPU_DFREE(d_v0);
+  GPU_DFREE(d_v1);
+  GPU_DFREE(d_flags);
+  return PPCSR_OK;
+}
+
 // ---- consumers ------------------------------------------------------------------------------------
 // bfs.h:15-36: level of every vertex from `start` (UINT32_MAX = unreachable); one launch per level over the gapped array
 int Engine::bfs(uint32_t start, uint32_t *levels, double *device_ms) {

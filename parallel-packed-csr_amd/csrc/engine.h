@@ -45,6 +45,7 @@ class Engine {
   int scan_all(uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *total);
   int scan_all_device(double *ms, uint64_t *total);  // device-only timing of the bulk scan (bench)
   // graph-algorithm consumers over the gapped array (reference: src/utility/bfs.h, src/utility/pagerank.h)
+  int bulk_build(const Op *host_ops, uint64_t m, double *device_ms);  // non-parity fast path
   int bfs(uint32_t start, uint32_t *levels, double *device_ms);
   int pagerank(const float *node_values, float *out, double *device_ms);
   int export_state(Edge *items, Node *nodes);

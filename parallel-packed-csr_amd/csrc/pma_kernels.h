@@ -958,6 +958,97 @@ PMA_KERNEL void k_scan_write(View v, const uint32_t *__restrict__ chunkcnt, uint
   }
 }
 
+// ---- bulk build: an explicit NON-parity fast path ---------------------------------------------------
+// The reference can only build a graph by single inserts, and the layout that produces is history dependent; this path
+// builds a VALID packed-memory array (same invariants, same neighbourhoods, same num_neighbors) in a handful of passes:
+// sort the adds by (src, dest) (stable: the last value of a duplicate wins, as it does when inserted one by one), then
+// place sentinels and unique edges with the exact redistribute() positions of one whole-array window.
+PMA_KERNEL void k_bb_keys(const Op *ops, uint64_t m, uint32_t n, unsigned long long *keys, uint32_t *vals) {
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t i = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); i < m; i += stride) {
+    const Op o = ops[i];
+    const bool ok = o.op != 0 && o.src < n;  // (add_edge ignores value 0 and src >= n, PCSR.cpp:1375-1377)
+    keys[i] = ok ? (((unsigned long long)o.src << 32) | (unsigned long long)o.dst) : ((unsigned long long)n << 32);  // (sorts last)
+    vals[i] = o.op;
+  }
+}
+PMA_KERNEL void k_bb_flags(const unsigned long long *keys, uint64_t m, uint32_t n, uint32_t *flags) {
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t i = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); i < m; i += stride) {
+    const unsigned long long k = keys[i];
+    flags[i] = ((uint32_t)(k >> 32) < n && (i + 1 == m || keys[i + 1] != k)) ? 1u : 0u;  // last of its run = the value that survives
+  }
+}
+PMA_DEV uint64_t bb_lower_bound(const unsigned long long *keys, uint64_t m, unsigned long long key) {
+  uint64_t lo = 0, hi = m;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// position of element k of the whole-array window, table in LDS, segment found by bisection
+PMA_DEV uint64_t bb_pos(const ChainTable *tb, uint64_t k) {
+  if (k == 0) return tb->index;
+  const uint64_t t = tb->j - 1 - k;
+  int lo = 0, hi = tb->nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tb->seg[mid].t0 <= t) lo = mid; else hi = mid - 1;
+  }
+  const ChainSeg &sg = tb->seg[lo];
+  const uint64_t d = t - sg.t0;
+  const uint64_t M = (d == 0) ? sg.M0 : (sg.M0 - sg.Dfirst - (d - 1) * sg.Drest);
+  return M >> sg.shift;
+}
+PMA_DEV void bb_load_table(ChainTable *stb, const ChainTable *tb) {
+  const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
+  uint32_t *sp = reinterpret_cast<uint32_t *>(stb);
+  const uint32_t words = (uint32_t)((sizeof(ChainTable) - sizeof(ChainSeg) * (size_t)(kMaxSeg - tb->nseg)) / 4);
+  for (uint32_t i = wv::thread_idx(); i < words; i += wv::block_dim()) sp[i] = g[i];
+  wv::block_sync();
+}
+// sentinel of every vertex + nodes[]: vertex u is element u + (unique edges of smaller sources) of the sequence
+PMA_KERNEL void k_bb_vertices(View v, const unsigned long long *keys, uint64_t m, const uint32_t *rank, const unsigned long long *total,
+                              const ChainTable *tb) {
+  PMA_SHARED ChainTable stb;
+  bb_load_table(&stb, tb);
+  const uint64_t E = *total;
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t u = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); u < v.g.n; u += stride) {
+    const uint64_t a = bb_lower_bound(keys, m, (unsigned long long)u << 32);
+    const uint64_t b = bb_lower_bound(keys, m, (unsigned long long)(u + 1) << 32);
+    const uint64_t before = (a < m) ? (uint64_t)rank[a] : E;  // unique edges whose source is smaller than u
+    const uint64_t pos = bb_pos(&stb, u + before);
+    Edge e;
+    e.src = (uint32_t)u;
+    e.dest = kMax;
+    e.value = (u == 0) ? kMax : (uint32_t)u;
+    v.items[pos] = e;
+    v.nodes[u].beginning = (uint32_t)pos;
+    v.nodes[u].num_neighbors = (uint32_t)(b - a);  // every add counts, duplicates included (PCSR.cpp:1408)
+    if (u > 0) v.nodes[u - 1].end = (uint32_t)pos;
+    if (u + 1 == v.g.n) v.nodes[u].end = (uint32_t)(v.g.N - 1);
+  }
+}
+PMA_KERNEL void k_bb_edges(View v, const unsigned long long *keys, const uint32_t *vals, const uint32_t *flags, const uint32_t *rank,
+                           uint64_t m, const ChainTable *tb) {
+  PMA_SHARED ChainTable stb;
+  bb_load_table(&stb, tb);
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t i = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); i < m; i += stride) {
+    if (!flags[i]) continue;
+    const unsigned long long k = keys[i];
+    const uint32_t src = (uint32_t)(k >> 32);
+    const uint64_t pos = bb_pos(&stb, (uint64_t)rank[i] + (uint64_t)src + 1ull);  // sentinels 0..src precede it
+    Edge e;
+    e.src = src;
+    e.dest = (uint32_t)k;
+    e.value = vals[i];
+    v.items[pos] = e;
+  }
+}
+
 // ---- graph-algorithm consumers over the gapped array (reference: src/utility/bfs.h, src/utility/pagerank.h) -----------
 // BFS, one level per launch: one wave per frontier vertex walks its slot range (beginning, end) 64 slots at a time, skips
 // nulls, claims unvisited neighbours with a compare-and-swap on their level and appends them to the next frontier (one

@@ -110,3 +110,33 @@ def reference_consumers(oracle, start, node_values):
     ok = dst < n
     np.add.at(out, dst[ok], contrib[src[ok]])
     return lv, out
+
+
+import numpy as np  # noqa: E402
+
+
+def edge_view(items, nodes):
+    """layout-independent view of a PCSR state: CSR (row lengths, dests, values) + num_neighbors"""
+    live = (items[:, 2] != 0) & (items[:, 1] != 0xFFFFFFFF)
+    live[-1] = False
+    deg = np.bincount(items[live, 0], minlength=len(nodes))
+    return deg, items[live, 1], items[live, 2], nodes[:, 2]
+
+
+def check_pma_invariants(items, nodes):
+    N, n = len(items), len(nodes)
+    live = items[:, 2] != 0
+    nul = items[~live]
+    assert (nul[:, 0] == 0xFFFFFFFF).all() and (nul[:, 1] == 0).all()
+    sent = live & (items[:, 1] == 0xFFFFFFFF)
+    pos = np.nonzero(sent)[0]
+    assert len(pos) == n
+    np.testing.assert_array_equal(items[pos, 0], np.arange(n, dtype=np.uint32))
+    np.testing.assert_array_equal(nodes[:, 0], pos.astype(np.uint32))
+    np.testing.assert_array_equal(nodes[:-1, 1], nodes[1:, 0])
+    assert nodes[-1, 1] == N - 1
+    e = np.nonzero(live & ~sent)[0]
+    owner = np.searchsorted(pos, e, side="right") - 1
+    np.testing.assert_array_equal(items[e, 0], owner.astype(np.uint32))
+    key = items[e, 0].astype(np.uint64) << np.uint64(32) | items[e, 1].astype(np.uint64)
+    assert (np.diff(key.astype(np.int64)) > 0).all()  # sorted and unique inside every neighbourhood

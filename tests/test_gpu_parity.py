@@ -253,6 +253,40 @@ def test_big_window_rebalance(pkg, streams, variant, tile, batch):
     _same(e, o, "updates after the rebalances")
 
 
+def test_bulk_build_fast_path(pkg, streams):
+    """non-parity bulk build of a 1 M-edge RMAT graph: valid PMA invariants, same edge set / values /
+    num_neighbors as the one-by-one build (oracle), consumers agree, and ordinary updates afterwards keep all of it"""
+    from helpers import check_pma_invariants, edge_view, reference_consumers
+    scale, m = 16, 1_000_000
+    n = 1 << scale
+    s, d = streams.rmat_edges(scale, m, seed=51)
+    ops = streams.adds(s, d)
+    ops[::11, 2] = 0            # ignored: value 0
+    ops[3::17, 0] = n + 5       # ignored: src >= n
+    ops[1000:2000] = ops[0:1000]  # duplicates: counted, last value wins
+    ops[1000:2000, 2] = 9
+    eng, o = pkg.PCSR(n), Oracle(n)
+    ms = eng.bulk_build(ops, with_ms=True)
+    o.apply(ops[ops[:, 2] != 0])
+    ei, en = eng.state()
+    check_pma_invariants(ei, en)
+    assert eng.check_invariants() == 0
+    for a, b in zip(edge_view(ei, en), edge_view(*o.state())):
+        np.testing.assert_array_equal(a, b)
+    lv, _ = reference_consumers(o, 0, np.ones(n, np.float32))
+    np.testing.assert_array_equal(eng.bfs(0), lv)
+    s2, d2 = streams.rmat_edges(scale, 200_000, seed=52)
+    more = streams.mixed_existing_stream(ops[(ops[:, 2] != 0) & (ops[:, 0] < n)][:300_000], streams.adds(s2, d2), seed=53)
+    eng.apply(more)
+    o.apply(more)
+    ei, en = eng.state()
+    check_pma_invariants(ei, en)
+    for a, b in zip(edge_view(ei, en), edge_view(*o.state())):
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(pkg.PpcsrError):
+        eng.bulk_build(ops)
+
+
 def test_consumers_bfs_pagerank(pkg, streams):
     """GPU BFS / PageRank push over the gapped array == the reference's bfs.h / pagerank.h templates
     evaluated on the oracle's state; PageRank compared bit for bit (fp32 additions in the reference's order), incl. a

@@ -189,6 +189,37 @@ def test_sim_sparse_hub_searches(sim, streams):
         np.testing.assert_array_equal(ei, oi)
 
 
+def test_sim_bulk_build(sim, streams):
+    """non-parity bulk build: same edge set / values / num_neighbors as the one-by-one build, valid PMA
+    invariants, and ordinary updates afterwards keep both"""
+    from helpers import check_pma_invariants as _check_invariants_numpy, edge_view as _edge_view
+    n = 150
+    ops = streams.random_stream(n, 4000, seed=41, p_delete=0.0)
+    ops[::9, 2] = 0          # ignored entries (value 0)
+    ops[5::13, 0] = n + 7    # ignored entries (src >= n)
+    ops[100:200] = ops[0:100]  # duplicates (count in num_neighbors; last value wins)
+    ops[100:200, 2] += 3
+    e, o = sim(n, mode=1), Oracle(n)
+    e.bulk_build(ops)
+    for r in ops:
+        if r[2] != 0:
+            o.add_edge(int(r[0]), int(r[1]), int(r[2]))
+    ei, en = e.state()
+    _check_invariants_numpy(ei, en)
+    assert e.check_invariants() == 0
+    for a, b in zip(_edge_view(ei, en), _edge_view(*o.state())):
+        np.testing.assert_array_equal(a, b)
+    more = streams.random_stream(n, 3000, seed=42, p_delete=0.4)
+    e.apply(more)
+    o.apply(more)
+    ei, en = e.state()
+    _check_invariants_numpy(ei, en)
+    for a, b in zip(_edge_view(ei, en), _edge_view(*o.state())):
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(Exception):
+        e.bulk_build(ops)  # only an empty graph can be bulk-built
+
+
 def test_sim_consumers_bfs_pagerank(sim, streams):
     """device BFS / PageRank over the gapped array == the reference's templates (bfs.h, pagerank.h) on the oracle state;
     PageRank bit for bit (same order of fp32 additions)"""
