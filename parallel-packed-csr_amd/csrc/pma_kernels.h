@@ -1391,13 +1391,6 @@ PMA_KERNEL void o_check(OptArgs a) {
   }
   const bool anyfail = wv::ballot(fail) != 0;
   const bool anybad = wv::ballot(stamp_bad) != 0;
-  uint32_t glo, ghi;
-  if (writes) {
-    glo = h.wleaf_lo >> a.regshift;
-    ghi = h.wleaf_hi >> a.regshift;
-  } else {
-    glo = ghi = (h.index >> a.v.g.sh) >> a.regshift;
-  }
   if (anyfail && kind != K_NOOP) {
     // a deferred update keeps later updates out of its region(s); its footprint may still creep over a region edge
     // by a slide, so the mark is padded by kRegionPadLeaves leaves on both sides

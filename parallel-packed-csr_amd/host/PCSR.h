@@ -133,6 +133,13 @@ class PCSR {
   }
   // the reference's consumers (src/utility/bfs.h, pagerank.h) run on the device over the gapped array; host/bfs.h and
   // host/pagerank.h route the reference's free functions here
+  // NON-parity fast path (no reference equivalent): build an empty graph from a list of adds in a few device passes;
+  // same neighbourhoods / values / num_neighbors / invariants as inserting them one by one, different slot layout
+  void bulk_build(const std::vector<ppcsr_op> &adds) {
+    flush();
+    check(ppcsr_bulk_build(h_, adds.data(), adds.size(), nullptr));
+    refresh_geometry(false);
+  }
   std::vector<uint32_t> bfs(uint32_t start_node) {
     flush();
     std::vector<uint32_t> out(get_n());

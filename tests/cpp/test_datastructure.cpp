@@ -100,7 +100,12 @@ static void run(bool lock_search) {
     PCSR pcsr(1000, 1000, lock_search, 0);
     uint64_t x = 1234567ull;
     auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x >> 11); };
-    for (int i = 1; i < 50001; ++i) pcsr.add_edge(rnd() % 1000, rnd() % 1000, i);
+    std::vector<ppcsr_op> adds;
+    for (int i = 1; i < 50001; ++i) {
+      const uint32_t s = rnd() % 1000, d = rnd() % 1000;
+      adds.push_back(ppcsr_op{s, d, (uint32_t)i});
+    }
+    for (const auto &a : adds) pcsr.add_edge(a.src, a.dst, a.op);
     auto res = bfs(pcsr, 0);  // host/bfs.h -> ppcsr_bfs on the GPU
     EXPECT_EQ(res.size(), 1000u);
     EXPECT_TRUE(res == host_bfs(pcsr, 0));
@@ -112,6 +117,13 @@ static void run(bool lock_search) {
     auto pr = pagerank(pcsr, weights);  // host/pagerank.h -> ppcsr_pagerank on the GPU
     EXPECT_EQ(pr.size(), 1000u);
     EXPECT_TRUE(memcmp(pr.data(), output.data(), output.size() * sizeof(float)) == 0);
+    // the non-parity bulk build of the same adds gives the same graph (neighbourhoods, BFS levels, PageRank bits)
+    PCSR bulk(1000, 1000, lock_search, 0);
+    bulk.bulk_build(adds);
+    EXPECT_TRUE(bfs(bulk, 0) == res);
+    EXPECT_TRUE(bulk.get_neighbourhood(7) == pcsr.get_neighbourhood(7));
+    auto pr2 = pagerank(bulk, weights);
+    EXPECT_TRUE(memcmp(pr2.data(), pr.data(), pr.size() * sizeof(float)) == 0);
     EXPECT_EQ(output.size(), 1000u);
   }
 }
