@@ -84,6 +84,7 @@ struct Engine::Impl {
   uint32_t start_horizon = 6144;
   uint32_t adaptive = 0;
   uint32_t scatter_blocks = 8192;
+  uint32_t small_batch = 256;    // batches up to this size take the strict rounds even in speculative mode
   uint32_t rb_tile = 0;          // leaves per rebalance tile (power of two <= 256); 0 = pick per window
   uint32_t rb_min_tiles = 4096;  // auto tile: shrink the tile until the window has at least this many
   uint32_t rb_prefetch = 1;  // 1: four chunks in flight per wave, 0: one
@@ -365,6 +366,10 @@ int Engine::set_option(const char *key, int64_t value) {
     p.scatter_blocks = (uint32_t)std::max<int64_t>(64, value);
     return PPCSR_OK;
   }
+  if (k == "small_batch") {
+    p.small_batch = value < 0 ? 0u : (uint32_t)value;
+    return PPCSR_OK;
+  }
   if (k == "rb_tile") {
     uint32_t t = 0;
     if (value > 0) for (t = 8; t < (uint32_t)value && t < kRbTile; t <<= 1) {}
@@ -434,7 +439,11 @@ int Engine::apply_batch_device(const Op *d_ops, uint64_t n) {
   const uint64_t kChunk = 1ull << 30;
   for (uint64_t off = 0; off < n; off += kChunk) {
     const uint64_t m = std::min(kChunk, n - off);
-    int rc = (p.mode == 1) ? run_speculative(d_ops + off, m) : run_rounds(d_ops + off, m);
+    // a speculative epoch has a fixed cost (rollback snapshot of the whole array, stamp resets: ~180 us at 16 M slots);
+    // a handful of updates — the single-update API above all — is cheaper through the strict prefix rounds, which need
+    // neither (same result: both are exact)
+    const bool small = m <= p.small_batch;
+    int rc = (p.mode == 1 && !small) ? run_speculative(d_ops + off, m) : run_rounds(d_ops + off, m);
     if (rc != PPCSR_OK) return rc;
   }
   p.timer.stop(p.stream);
@@ -478,7 +487,15 @@ int Engine::run_rounds(const Op *d_ops, uint64_t n) {
         p.events.resize(4ull * p.rounds_per_sync);
         for (size_t i = old; i < p.events.size(); i++) GCHK(p.events[i].init());
       }
-      for (uint32_t r = 0; r < p.rounds_per_sync; r++) {
+      // rounds in this chunk: at least one per `hor` pending updates (every strict round commits at least one update and
+      // at most the horizon), capped by rounds_per_sync; short batches — the single-update API — get 1-2 rounds, not 32
+      uint32_t chunk_rounds = p.rounds_per_sync;
+      {
+        const uint64_t pending = n - cur;
+        const uint64_t need = (pending + std::max<uint32_t>(hor, 1u) - 1) / std::max<uint32_t>(hor, 1u) + 1;
+        if (need < chunk_rounds) chunk_rounds = (uint32_t)need;
+      }
+      for (uint32_t r = 0; r < chunk_rounds; r++) {
         a.round = ++p.round;
         if (p.profile) p.events[4 * r + 0].record(p.stream);
         GPU_LAUNCH(p.stream, k_plan, blocks, 256, a);
@@ -492,7 +509,7 @@ int Engine::run_rounds(const Op *d_ops, uint64_t n) {
       GCHK(gpu::sync(p.stream));
       GCHK(gpu::last_error());
       if (p.profile) {
-        for (uint32_t r = 0; r < p.rounds_per_sync; r++) {
+        for (uint32_t r = 0; r < chunk_rounds; r++) {
           p.st.prof_plan_ms += gpu::Event::elapsed_ms(p.events[4 * r + 0], p.events[4 * r + 1]);
           p.st.prof_check_ms += gpu::Event::elapsed_ms(p.events[4 * r + 1], p.events[4 * r + 2]);
           p.st.prof_apply_ms += gpu::Event::elapsed_ms(p.events[4 * r + 2], p.events[4 * r + 3]);

@@ -21,8 +21,9 @@ def pkg():
 # validated rollback (mode 1, the default); small horizons/epochs/regions force rollbacks to happen in the tests
 MODES = {
     "strict": dict(mode=0),
-    "speculative": dict(mode=1),
-    "speculative-small": dict(mode=1, opt_horizon=1024, epoch_ops=4096, region_slots=256),
+    "speculative": dict(mode=1, small_batch=0),  # (small_batch=0: even tiny batches go through the speculative rounds)
+    "speculative-small": dict(mode=1, opt_horizon=1024, epoch_ops=4096, region_slots=256, small_batch=0),
+    "default": dict(),  # engine defaults: speculative rounds, batches of <= 256 updates through the strict rounds
 }
 
 

@@ -42,6 +42,7 @@ def sim():
         e.set_option("min_horizon", opts.get("min_horizon", 4))
         e.set_option("init_horizon", opts.get("init_horizon", 8))
         e.set_option("rounds_per_sync", opts.get("rounds_per_sync", 2))
+        e.set_option("small_batch", opts.get("small_batch", 0))  # keep small streams on the scheduler under test
         return e
     return make
 

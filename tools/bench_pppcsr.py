@@ -30,3 +30,7 @@ for k in range(3):
     e.apply(ops)
     t1 = time.perf_counter()
     print(f"P={P}: batch of 1M in {(t1-t0)*1e3:.1f} ms = {1/(t1-t0):.1f} M updates/s (host buffers: bucketing + H2D inside)")
+    if os.environ.get("PPCSR_PP_STATS"):
+        for q in range(P):
+            stq = e.partition(q).stats()
+            print("   part", q, {k2: stq[k2] for k2 in ("N", "rounds", "rollbacks", "exclusive_ops", "double_calls", "last_batch_ms")})
