@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel durations of the LAST `rounds` speculative rounds in a rocprofv3 kernel trace (rocpd sqlite output), i.e.
 the timed region of `bench.py --no-profile` (the core load and warm-up come first).  Also prints the gaps between
-consecutive kernels of those rounds.  usage: trace_summary.py <results.db | kernel_trace.csv> <rounds> [out.json]"""
+consecutive kernels of those rounds.  usage: trace_summary.py <results.db | kernel_trace.csv> <rounds> [out.json] [rounds_to_skip_at_the_end]"""
 import json
 import sqlite3
 import sys
@@ -20,8 +20,10 @@ else:  # rocpd sqlite output (the default format)
     rows = c.execute("select name, start, end from kernels where name like '%o_plan%' or name like '%o_check%' or "
                      "name like '%o_apply%' or name like '%o_compact%' order by start").fetchall()
 plans = [i for i, r in enumerate(rows) if "o_plan" in r[0]]
-first = plans[-rounds]
-sel = rows[first:]
+skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # rounds to leave out at the end (e.g. bench.py's profiled replay)
+first = plans[-(rounds + skip)]
+last = plans[-skip] if skip else len(rows)
+sel = rows[first:last]
 out = {}
 for key in ("o_plan", "o_check", "o_apply", "o_compact"):
     d = [r[2] - r[1] for r in sel if key in r[0]]
