@@ -39,7 +39,7 @@ typedef enum {
   PPCSR_STATUS_EINVAL = 1,
   PPCSR_STATUS_ENOMEM = 2,
   PPCSR_STATUS_EHIP = 3,         /* HIP runtime error or no GPU */
-  PPCSR_STATUS_EUNSUPPORTED = 4, /* slide ran off both ends of the array (PCSR.cpp:347-351,378-383) */
+  PPCSR_STATUS_EUNSUPPORTED = 4, /* no null slot on either side of a slide (PCSR.cpp:378-383), > 2^31 slots */
   PPCSR_STATUS_EINTERNAL = 5,
   PPCSR_STATUS_ERANGE = 6        /* output buffer too small; *count holds the needed size */
 } ppcsr_status;

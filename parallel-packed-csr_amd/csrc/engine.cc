@@ -26,7 +26,7 @@ const char *error_string(int code) {
     case PPCSR_EINVAL: return "invalid argument";
     case PPCSR_ENOMEM: return "out of memory";
     case PPCSR_EHIP: return "HIP runtime error";
-    case PPCSR_EUNSUPPORTED: return "unsupported rare path (slide ran off the end of the array)";
+    case PPCSR_EUNSUPPORTED: return "unsupported rare path (no null slot on either side of a slide: completely full array)";
     case PPCSR_EINTERNAL: return "internal error";
     case PPCSR_ERANGE: return "output buffer too small";
     default: return "unknown error";

@@ -674,6 +674,37 @@ PMA_DEV void slide_right_wave(const View &v, uint32_t index, uint32_t gap) {
   }
 }
 
+// last null slot in [0, from]; kMax if there is none (slide_left's scan, PCSR.cpp:367)
+PMA_DEV uint32_t find_gap_left(const View &v, uint32_t from) {
+  const int lane = wv::lane();
+  for (int64_t hi = (int64_t)from; hi >= 0; hi -= 64) {
+    const int64_t s = hi - (int64_t)lane;
+    bool nul = false;
+    if (s >= 0) nul = (v.items[s].value == 0);
+    const uint64_t m = wv::ballot(nul);
+    if (m) return (uint32_t)(hi - (int64_t)wv::ctz64(m));
+  }
+  return kMax;
+}
+// shift items[gap+1 .. last] one slot to the left (the net effect of slide_left(last), PCSR.cpp:360-390, whose carry
+// stops at the null slot `gap`); slot `last` is left for the caller to overwrite
+PMA_DEV void slide_left_wave(const View &v, uint32_t gap, uint32_t last) {
+  const int lane = wv::lane();
+  Edge *items = v.items;
+  for (uint64_t lo = (uint64_t)gap + 1; lo <= (uint64_t)last; lo += 64) {
+    const uint64_t s = lo + (uint64_t)lane;
+    const bool act = s <= (uint64_t)last;
+    Edge e = null_edge();
+    if (act) e = items[s];
+    wv::fence();
+    if (act) {
+      items[s - 1] = e;
+      fix_sentinel(v, e, (uint32_t)(s - 1));
+    }
+    wv::fence();
+  }
+}
+
 // ---- full per-op planning (search + window plan) -------------------------------------------------------
 // What the planning kernels need from the plan right away (the full record goes to memory for the later kernels)
 struct PlanRegs {

@@ -221,23 +221,48 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
                               occupied ? dev::find_gap_right(v, index + 1, kMaxSlide) : index, rr);
         status = ip.status;
       }
+      if (status == dev::PS_SLIDE_OFF_END || status == dev::PS_SLIDE_LONG) status = dev::PS_OK;  // (the window plan is complete)
       uint32_t gap = index;
+      bool off_end = false;
       if (occupied) {
         gap = dev::find_gap_right(v, index + 1, kMax - 1u);
-        if ((uint64_t)gap == g.N) status = dev::PS_SLIDE_OFF_END;
+        off_end = ((uint64_t)gap == g.N);
       }
-      if (status == dev::PS_SLIDE_OFF_END) {
-        result = X_UNSUPPORTED;
+      uint32_t gleft = kMax;
+      if (off_end) gleft = (index >= 2) ? dev::find_gap_left(v, index - 2u) : kMax;
+      if (off_end && gleft == kMax) {
+        result = X_UNSUPPORTED;  // no null slot on either side: the reference doubles and slides from slot 0 (PCSR.cpp:378-383)
       } else {
-        if (status == dev::PS_SLIDE_LONG) status = dev::PS_OK;  // the wave slides any length here
         wv::fence();  // planning reads are complete in every lane before the state is modified
-        if (gap != index) dev::slide_right_wave(v, index, gap);
-        if (lane == 0) {
-          v.items[index] = elem;
-          v.leafcnt[gap >> sh] += 1u;
-          wv::atomic_add_u64(&st->slide_slots, (unsigned long long)(gap - index));
+        if (off_end) {
+          // The slide ran off the end of the array (PCSR.cpp:347-351).  The reference slides everything back (its
+          // slide_left from slot N-1 restores [index, N-1] exactly), then insert() steps one slot to the left and slides
+          // THAT way (PCSR.cpp:541-544): the block [gleft+1, index-1] moves one slot left and the element lands on
+          // index-1.  One side effect survives: the element of slot N-1 went through fix_sentinel(.., N) on the way out
+          // and is written back without one, so a sentinel there keeps the out-of-range position N in nodes[].
+          const Edge last = v.items[g.N - 1];
+          dev::slide_left_wave(v, gleft, index - 1u);
+          if (lane == 0) {
+            v.items[index - 1u] = elem;
+            dev::fix_sentinel(v, last, (uint32_t)g.N);
+            wv::atomic_add_u64(&st->slide_slots, (unsigned long long)(g.N - 1 - index));
+          }
+          wv::fence();
+          for (uint64_t lf = (uint64_t)(gleft >> sh) + (uint64_t)lane; lf <= (uint64_t)((index - 1u) >> sh); lf += 64) {
+            uint32_t cnt = 0;  // recount the leaves the left slide touched
+            for (uint32_t q = 0; q < logN; q++) cnt += (v.items[(lf << sh) + q].value != 0) ? 1u : 0u;
+            v.leafcnt[lf] = cnt;
+          }
+          wv::fence();
+        } else {
+          if (gap != index) dev::slide_right_wave(v, index, gap);
+          if (lane == 0) {
+            v.items[index] = elem;
+            v.leafcnt[gap >> sh] += 1u;
+            wv::atomic_add_u64(&st->slide_slots, (unsigned long long)(gap - index));
+          }
+          wv::fence();
         }
-        wv::fence();
         const uint32_t leaf = index >> sh;
         const uint32_t cpost = v.leafcnt[leaf];
         uint64_t ws, wn;

@@ -104,7 +104,7 @@ enum ExclResult : uint32_t {
   X_NEED_HALF = 2,          // half_list() completes the op (PCSR.cpp:624-626)
   X_NEED_REDIST = 3,        // host must run the multi-workgroup window rebalance on (wstart,wlen)
   X_DOUBLE_THEN_RETRY = 4,  // slot N-1 occupied: double_list(), re-search, insert(..., nullptr) (PCSR.cpp:533-540)
-  X_UNSUPPORTED = 5,        // slide ran off both ends (reference: PCSR.cpp:347-351, 378-383) — never observed
+  X_UNSUPPORTED = 5,        // a slide found no null slot on either side (reference: PCSR.cpp:378-383) — never observed
 };
 struct ExclOut {
   uint32_t result;

@@ -140,3 +140,14 @@ def check_pma_invariants(items, nodes):
     np.testing.assert_array_equal(items[e, 0], owner.astype(np.uint32))
     key = items[e, 0].astype(np.uint64) << np.uint64(32) | items[e, 1].astype(np.uint64)
     assert (np.diff(key.astype(np.int64)) > 0).all()  # sorted and unique inside every neighbourhood
+
+
+# sources of 80 ascending-dest inserts into the last three of 4096 vertices: the 47th makes slide_right run off the end
+# of the array (PCSR.cpp:347-351) — found by tools/fuzz_parity.py (seed 5069); the reference recovers through slide_left
+SLIDE_OFF_END_SRC = [4094, 4094, 4094, 4093, 4094, 4095, 4094, 4095, 4094, 4093, 4093, 4094, 4095, 4095, 4094, 4095, 4093, 4095, 4094, 4094, 4094, 4093, 4093, 4095, 4094, 4093, 4094, 4093, 4095, 4095, 4093, 4094, 4094, 4095, 4094, 4093, 4095, 4095, 4093, 4093, 4094, 4093, 4095, 4094, 4095, 4093, 4094, 4093, 4095, 4093, 4095, 4095, 4095, 4093, 4093, 4095, 4093, 4093, 4095, 4095, 4093, 4094, 4094, 4094, 4094, 4093, 4095, 4094, 4094, 4093, 4095, 4094, 4094, 4095, 4094, 4094, 4095, 4094, 4094, 4093]
+
+
+def slide_off_end_stream():
+    import numpy as np
+    src = np.array(SLIDE_OFF_END_SRC, np.uint32)
+    return np.stack([src, np.arange(len(src), dtype=np.uint32), np.ones(len(src), np.uint32)], 1)

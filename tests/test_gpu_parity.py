@@ -124,6 +124,23 @@ def test_hubs_and_last_vertex(mk, streams):
         _stats_match(eng, o)
 
 
+def test_slide_off_the_end_of_the_array(mk, streams):
+    """slide_right runs off the end of the array (PCSR.cpp:347-351) and the reference recovers through slide_left
+    (PCSR.cpp:360-390, 541-544) — a path tools/fuzz_parity.py found on ascending inserts into the last vertices"""
+    from helpers import slide_off_end_stream
+    ops = slide_off_end_stream()
+    more = streams.random_stream(4096, 20000, seed=78, p_delete=0.2)
+    more[:, 0] = 4096 - 1 - (more[:, 0] % 40)
+    for lock in (True, False):
+        eng, o = mk(4096, lock), Oracle(4096, lock_search=lock)
+        for part in (ops, more):
+            eng.apply(part)
+            o.apply(part)
+            _same(eng, o, f"lock={lock}")
+        _stats_match(eng, o)
+        assert o.stats()["slide_left_calls"] >= 2
+
+
 def test_sparse_hub_searches(mk, streams):
     """the 64-ary bracket narrowing on a hub whose range is mostly gaps: build a 30 K-edge hub, delete 97 % of it (the
     array never shrinks below its doubled size while the other vertices keep it dense enough), then look keys up through

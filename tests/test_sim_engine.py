@@ -190,6 +190,26 @@ def test_sim_sparse_hub_searches(sim, streams):
         np.testing.assert_array_equal(ei, oi)
 
 
+def test_sim_slide_off_the_end(sim, streams):
+    """slide_right runs off the end of the array (PCSR.cpp:347-351): the reference slides back and then to the LEFT
+    (slide_left, PCSR.cpp:360-390, + insert():541-544); oracle counts 2 slide_left calls on this stream"""
+    from helpers import slide_off_end_stream
+    ops = slide_off_end_stream()
+    more = streams.random_stream(4096, 1500, seed=77, p_delete=0.2)
+    more[:, 0] = 4096 - 1 - (more[:, 0] % 40)  # keep working at the end of the array
+    for lock, mode in ((True, 1), (False, 0), (False, 1)):
+        e, o = sim(4096, lock, mode=mode), Oracle(4096, lock_search=lock)
+        for part in (ops, more):
+            e.apply(part)
+            o.apply(part)
+            assert e.geometry() == o.geometry()
+            ei, en = e.state()
+            oi, on = o.state()
+            np.testing.assert_array_equal(en, on)
+            np.testing.assert_array_equal(ei, oi)
+        assert o.stats()["slide_left_calls"] >= 2
+
+
 def test_sim_bulk_build(sim, streams):
     """non-parity bulk build: same edge set / values / num_neighbors as the one-by-one build, valid PMA
     invariants, and ordinary updates afterwards keep both"""
