@@ -366,6 +366,10 @@ int Engine::set_option(const char *key, int64_t value) {
     p.scatter_blocks = (uint32_t)std::max<int64_t>(64, value);
     return PPCSR_OK;
   }
+  if (k == "search_narrow") {  // 0: the literal binary walk only (what a structure add_node has corrupted falls back to)
+    p.v.g.narrow = value ? 1u : 0u;
+    return PPCSR_OK;
+  }
   if (k == "small_batch") {
     p.small_batch = value < 0 ? 0u : (uint32_t)value;
     return PPCSR_OK;
@@ -788,10 +792,19 @@ int Engine::run_exclusive(Op op, uint32_t flags) {
         int rc = resize(p.v.g.N * 2);
         if (rc != PPCSR_OK) return rc;
         flags |= XF_FORCE_NOINFO | XF_SKIP_COUNT;
-        if (flags & XF_ADD_NODE) flags |= XF_RESEARCH;
+        if (flags & XF_ADD_NODE) {
+          // add_node found the end of the array occupied: the reference doubles and then re-searches the new sentinel's
+          // place through a node record the doubling could not update (PCSR.cpp:533-540, 681-703).  The sentinel can land
+          // in the middle of another vertex's range; the reference then searches unsorted ranges, which only the literal
+          // walk reproduces — the 64-ary narrowing is switched off for good.
+          flags |= XF_RESEARCH;
+          p.v.g.narrow = 0u;
+        }
         break;
       }
       case X_UNSUPPORTED: return fail(PPCSR_EUNSUPPORTED, error_string(PPCSR_EUNSUPPORTED));
+      case X_WINDOW_BEYOND_ARRAY:
+        return fail(PPCSR_EUNSUPPORTED, "rebalance window exceeds a one-leaf array (the reference reads past the end of its array here: undefined behaviour)");
       default: return fail(PPCSR_EINTERNAL, "bad exclusive result");
     }
   }
@@ -874,6 +887,7 @@ int Engine::resize(uint64_t newN) {
   const uint64_t old_leaves = oldN >> old.g.sh;
   Geometry g;
   compute_geometry(newN, old.g.n, old.g.lock_search, &g);
+  g.narrow = old.g.narrow;
   View nv = old;
   nv.g = g;
   const uint64_t new_leaves = newN >> g.sh;
@@ -1162,6 +1176,7 @@ int Engine::bulk_build(const Op *host_ops, uint64_t m, double *device_ms) {
   Geometry g;
   for (;;) {
     compute_geometry(newN, nn, old.g.lock_search, &g);
+    g.narrow = old.g.narrow;
     if (j + 1 < (uint64_t)g.t_up[0] || newN >= (1ull << 31)) break;
     newN *= 2;
   }

@@ -125,7 +125,8 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
   // 64 samples at a time — one round trip per factor of ~64 instead of one per factor of 2 — and the reference's walk
   // then finishes it from registers.  Only the two samples that become the new bracket are recorded as reads: with a
   // sorted neighbourhood the others cannot change the outcome.
-  while (end - start > 64) {
+  while (v.g.narrow && end > start && end - start > 64) {  // (end < start happens: add_node after a doubling can leave a vertex whose
+                                             // recorded range is inverted, PCSR.cpp:533-540 + 681-703; the walk below copes)
     const uint32_t len = end - start;
     // samples sit on an ABSOLUTE power-of-two grid (multiples of 2^sshift), not at offsets from `start`: a deferred
     // update that is planned again after its vertex's range has shifted by a slot or two then reads the same sample
@@ -164,7 +165,7 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
     if (!progress) break;  // sparse samples: let the reference's walk take over from here
   }
   while (start + 1 < end) {
-    if (!cached && end - start <= 64) {
+    if (!cached && end > start && end - start <= 64) {
       cbase = start;
       cend = end;
       const uint32_t s = start + (uint32_t)lane;

@@ -27,6 +27,7 @@ inline void compute_geometry(uint64_t N, uint32_t n, int lock_search, Geometry *
   g->N = N;
   g->n = n;
   g->lock_search = lock_search;
+  g->narrow = 1u;
   g->logN = 1 << bsr64((uint64_t)(bsr64(N) * 2 + 1));
   g->sh = bsr64((uint64_t)g->logN);
   g->H = bsr64(N / (uint64_t)g->logN);

@@ -320,7 +320,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
         }
         if (result == X_DONE) {
           if (ws + wn > g.N) {
-            result = X_UNSUPPORTED;
+            result = X_WINDOW_BEYOND_ARRAY;
           } else if (wn <= kExclInWave) {
             dev::redistribute_wave(v, ws, wn, lds);
           } else {

@@ -44,6 +44,10 @@ struct Geometry {
   uint32_t n;
   int logN, sh, H;
   int lock_search;
+  // 1: neighbourhood ranges are sorted and disjoint (always, unless add_node has hit the reference's re-search-after-
+  // doubling path, PCSR.cpp:533-540, which can drop the new sentinel into the middle of another vertex's range: from
+  // then on the reference searches unsorted ranges and only the literal walk follows it) -> the 64-ary narrowing is valid
+  uint32_t narrow;
   uint32_t t_up[kMaxLevels];
   uint32_t t_lo[kMaxLevels];
 };
@@ -105,6 +109,8 @@ enum ExclResult : uint32_t {
   X_NEED_REDIST = 3,        // host must run the multi-workgroup window rebalance on (wstart,wlen)
   X_DOUBLE_THEN_RETRY = 4,  // slot N-1 occupied: double_list(), re-search, insert(..., nullptr) (PCSR.cpp:533-540)
   X_UNSUPPORTED = 5,        // a slide found no null slot on either side (reference: PCSR.cpp:378-383) — never observed
+  X_WINDOW_BEYOND_ARRAY = 6,  // the 2-leaf rebalance of a full leaf on a ONE-leaf array (N == logN): the reference reads and
+                              // writes past the end of its array there (PCSR.cpp:555-557 with len*2 > N) — undefined behaviour
 };
 struct ExclOut {
   uint32_t result;
