@@ -447,7 +447,20 @@ int Engine::apply_batch_device(const Op *d_ops, uint64_t n) {
     // a handful of updates — the single-update API above all — is cheaper through the strict prefix rounds, which need
     // neither (same result: both are exact)
     const bool small = m <= p.small_batch;
-    int rc = (p.mode == 1 && !small) ? run_speculative(d_ops + off, m) : run_rounds(d_ops + off, m);
+    int rc;
+    if (p.v.g.narrow == 0u) {
+      // The reference's add_node-after-doubling path has left a structure whose vertex ranges overlap (see
+      // run_exclusive): footprints computed from sorted, disjoint ranges no longer describe what an update touches, so
+      // nothing may run side by side — one update per round, i.e. plain sequential execution of the exact kernels.
+      const uint32_t mh = p.max_horizon, mi = p.min_horizon, ih = p.init_horizon;
+      p.max_horizon = p.min_horizon = p.init_horizon = 1;
+      rc = run_rounds(d_ops + off, m);
+      p.max_horizon = mh;
+      p.min_horizon = mi;
+      p.init_horizon = ih;
+    } else {
+      rc = (p.mode == 1 && !small) ? run_speculative(d_ops + off, m) : run_rounds(d_ops + off, m);
+    }
     if (rc != PPCSR_OK) return rc;
   }
   p.timer.stop(p.stream);

@@ -124,19 +124,20 @@ def test_hubs_and_last_vertex(mk, streams):
         _stats_match(eng, o)
 
 
-@pytest.mark.parametrize("seed", [100, 123, 128, 137, 151])
+@pytest.mark.parametrize("seed", [100, 123, 128, 137, 151, 2395, 2554, 3663])
 def test_api_sequences_found_by_the_fuzzer(pkg, streams, seed):
     """random API sequences (add_edge / remove_edge / add_node / queries / batches) that tools/fuzz_api.py caught diverging:
     a one-vertex graph shrunk to a single leaf (the reference reads out of bounds there: the run stops before it), and
     add_node after edges + a doubling, which drops the new sentinel into another vertex's range (PCSR.cpp:533-540,
-    681-703) so that later searches run over inverted / unsorted ranges — the engine then follows the literal walk"""
+    681-703) so that later searches run over inverted / unsorted ranges — the engine then follows the literal walk and
+    runs one update per round (footprints computed from disjoint ranges no longer hold)"""
     import importlib.util
     import os
     from helpers import ROOT
     spec = importlib.util.spec_from_file_location("fuzz_api", os.path.join(ROOT, "tools", "fuzz_api.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    ok, desc = fz.run_case(pkg, streams, seed)
+    ok, desc = fz.run_case_tolerant(pkg, streams, seed)
     assert ok, desc
 
 
