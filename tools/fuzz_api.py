@@ -38,6 +38,31 @@ def run_case(pkg, st, seed):
         e.close()
         o.close()
         return ok, f"PPPCSR n={n} P={P} lock={lock}"
+    if rng.integers(0, 5) == 0:  # non-parity bulk build + exact updates + consumers: edge sets, invariants, BFS, PageRank
+        from helpers import check_pma_invariants, edge_view, reference_consumers
+        n = int(rng.choice([3, 300, 20000]))
+        m = int(rng.choice([50, 5000, 200000]))
+        adds = st.random_stream(n, m, seed=int(rng.integers(1 << 30)), p_delete=0.1)
+        adds[:, 1] %= max(n, 2) + 3  # a few dests beyond n
+        e, o = pkg.PCSR(n, lock_search=lock), Oracle(n, lock_search=lock)
+        e.bulk_build(adds)
+        o.apply(adds[adds[:, 2] != 0])
+        upd = st.random_stream(n, int(rng.choice([10, 3000])), seed=int(rng.integers(1 << 30)), p_delete=0.4)
+        upd[:, 1] %= max(n, 2) + 3
+        e.apply(upd)
+        o.apply(upd)
+        ei, en = e.state()
+        check_pma_invariants(ei, en)
+        ok = e.check_invariants() == 0
+        for a, b in zip(edge_view(ei, en), edge_view(*o.state())):
+            ok = ok and np.array_equal(a, b)
+        vals = (rng.random(n) * 3).astype(np.float32)
+        start = int(rng.integers(0, n))
+        lv, pr = reference_consumers(o, start, vals)
+        ok = ok and np.array_equal(e.bfs(start), lv) and e.pagerank(vals).tobytes() == pr.tobytes()
+        e.close()
+        o.close()
+        return ok, f"bulk_build n={n} m={m} lock={lock}"
     n = int(rng.choice([1, 5, 64, 2000]))
     e, o = pkg.PCSR(n, lock_search=lock), Oracle(n, lock_search=lock)
     if rng.integers(0, 2):
