@@ -2,10 +2,13 @@
 // running the update path on MI355X through the host shims.  Flags (same prefix matching, same order sensitivity):
 //   -threads=N  -size=N  -lock_free  -insert  -delete  -ppcsr  -pppcsr  -pppcsrnuma  -partitions_per_domain=N
 //   -core_graph=FILE  -update_file=FILE        additions:  -gpus=N (devices 0..N-1 for -pppcsr*)  -device=D  -verify
+//   -bulk_core (with -ppcsr): load the core graph through the NON-parity bulk build instead of single inserts (same graph,
+//               different slot layout; the timed update phase is unchanged)
 // Edge-list lines: "src<sep>dst[<sep>1|0]" with a single separator character (main.cpp:29-62); the optional third
 // column selects ADD (1) / DELETE (0), otherwise the default bound when -update_file= is parsed applies.
 // The bench scripts of the reference scrape the SECOND "Elapsed wall clock time:" line (benchmark-strong-scaling.sh:116).
 #include <algorithm>
+#include <chrono>
 #include <fstream>
 #include <iostream>
 #include <memory>
@@ -61,8 +64,27 @@ static void update_existing_graph(const OpList &input, Pool *pool, int threads, 
 }
 
 template <typename Pool>
-static void execute(int threads, int size, const OpList &core, const OpList &updates, Pool *pool, bool verify) {
-  update_existing_graph(core, pool, threads, (int)core.size());  // phase 1: load the core graph
+static void update_existing_graph(const OpList &input, Pool *pool, int threads, int size);
+template <typename Pool>
+static void bulk_core(const OpList &core, Pool *pool, int threads) {  // partitioned structures: no bulk path, load as usual
+  std::cerr << "-bulk_core applies to -ppcsr only; loading the core graph through single inserts" << std::endl;
+  update_existing_graph(core, pool, threads, (int)core.size());
+}
+static void bulk_core(const OpList &core, ThreadPool *pool, int) {  // phase 1 through ppcsr_bulk_build; prints the phase-1 time line too
+  std::vector<ppcsr_op> adds;
+  adds.reserve(core.size());
+  for (const auto &c : core)
+    if (std::get<0>(c) == Operation::ADD) adds.push_back(ppcsr_op{(uint32_t)std::get<1>(c), (uint32_t)std::get<2>(c), 1u});
+  const auto t0 = std::chrono::steady_clock::now();
+  pool->pcsr->bulk_build(adds);
+  const auto t1 = std::chrono::steady_clock::now();
+  std::cout << "Elapsed wall clock time: " << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << std::endl;
+}
+
+template <typename Pool>
+static void execute(int threads, int size, const OpList &core, const OpList &updates, Pool *pool, bool verify, bool bulk = false) {
+  if (bulk) bulk_core(core, pool, threads);
+  else update_existing_graph(core, pool, threads, (int)core.size());  // phase 1: load the core graph
   update_existing_graph(updates, pool, threads, size);           // phase 2: the timed updates
   if (verify) {  // the reference's commented-out debugging check (main.cpp:93-106), enabled by -verify
     long missing = 0;
@@ -74,7 +96,7 @@ static void execute(int threads, int size, const OpList &core, const OpList &upd
 
 int main(int argc, char *argv[]) {
   int threads = 8, size = 1000000, num_nodes = 0, partitions_per_domain = 1, gpus = 1, device = 0;
-  bool lock_search = true, insert = true, verify = false;
+  bool lock_search = true, insert = true, verify = false, bulk = false;
   enum class Version { PPCSR, PPPCSR, PPPCSRNUMA } v = Version::PPPCSRNUMA;
   OpList core, updates;
   for (int i = 1; i < argc; i++) {
@@ -91,6 +113,7 @@ int main(int argc, char *argv[]) {
     else if (starts_with(s, "-gpus=")) gpus = std::max(1, std::stoi(after(s, "-gpus=")));
     else if (starts_with(s, "-device=")) device = std::stoi(after(s, "-device="));
     else if (starts_with(s, "-verify")) verify = true;
+    else if (starts_with(s, "-bulk_core")) bulk = true;
     else if (starts_with(s, "-core_graph=")) {
       int t = 0;
       std::tie(core, t) = read_input(after(s, "-core_graph="), Operation::ADD);
@@ -118,7 +141,7 @@ int main(int argc, char *argv[]) {
   switch (v) {
     case Version::PPCSR: {
       auto pool = std::make_unique<ThreadPool>(threads, lock_search, num_nodes + 1, partitions_per_domain, device);
-      execute(threads, size, core, updates, pool.get(), verify);
+      execute(threads, size, core, updates, pool.get(), verify, bulk);
       break;
     }
     case Version::PPPCSR: {

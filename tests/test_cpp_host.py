@@ -71,3 +71,23 @@ def test_cli_protocol_matches_reference(tmp_path, flags):
         assert rkeep == keep and relapsed == elapsed
         if "-ppcsr" in flags:  # one PCSR: the last resize line is the final geometry
             assert rlast == last_edges, (rlast, last_edges)
+
+
+def test_cli_bulk_core_keeps_the_protocol(tmp_path):
+    """-bulk_core (an addition): the core graph goes through the non-parity bulk build, the two `Elapsed wall clock time`
+    lines the bench scripts scrape are still there, and every inserted update is found afterwards (-verify)"""
+    _ensure_built()
+    st = load_streams()
+    s, d = st.rmat_edges(12, 40000, seed=1)
+    core = st.adds(s, d)
+    fresh = st.random_stream(4096, 6000, seed=2, p_delete=0.0)
+    cf, uf = str(tmp_path / "core.txt"), str(tmp_path / "upd.txt")
+    _write_edges(cf, core, False)
+    _write_edges(uf, fresh, False)
+    args = ["-threads=1", "-size=6000", "-ppcsr", "-insert", "-bulk_core", "-verify", f"-core_graph={cf}", f"-update_file={uf}"]
+    mine = subprocess.run([CLI] + args, capture_output=True, text=True, timeout=300)
+    assert mine.returncode == 0, mine.stdout + mine.stderr
+    keep, elapsed, _ = _filtered(mine.stdout)
+    assert elapsed == 2
+    assert any(l.startswith("Core graph size: 40000") for l in keep)
+    assert "verify: 0 inserted updates not found" in mine.stdout
