@@ -47,7 +47,11 @@ def log(rank, *a):
 
 def gen_block(streams, kind, scale, count, seed, offset, n_global, permute, core=None, mixed_seed=0):
     """counter-based block [offset, offset+count) of the global stream `seed`"""
-    s, d = streams.rmat_edges(scale, count, seed=seed, offset=offset)
+    if kind == "zipf":  # config #5: hot-vertex stream, src = Zipf(1.2) rank, dst uniform, all ADD
+        s = streams.zipf_sources(n_global, count, seed=seed, alpha=1.2, offset=offset)
+        d = streams.uniform_ints(seed + 7, count, n_global, offset=offset)
+    else:
+        s, d = streams.rmat_edges(scale, count, seed=seed, offset=offset)
     if permute:
         s = streams.permute_labels(s, n_global)
         d = streams.permute_labels(d, n_global)
@@ -67,6 +71,7 @@ def main():
     ap.add_argument("--core-edges", type=int, default=10_000_000, help="core edges per GPU")
     ap.add_argument("--batch", type=int, default=1_000_000, help="updates per GPU per step")
     ap.add_argument("--mixed", action="store_true", help="config #3: alternate insert / delete-existing")
+    ap.add_argument("--zipf", action="store_true", help="config #5: updates with Zipf(1.2) sources (hot-vertex rebalance cascades)")
     ap.add_argument("--labels", choices=["permuted", "raw"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-cli", action="store_true", help="skip the multi-threaded run of the reference's own CLI binary")
@@ -111,7 +116,7 @@ def main():
     permute = (args.labels or ("permuted" if P > 1 else "raw")) == "permuted"
     starts, sizes = exch.partition_layout(n_global, P)
     my_n = int(sizes[rank])
-    kind = "mixed" if args.mixed else "insert"
+    kind = "mixed" if args.mixed else ("zipf" if args.zipf else "insert")
 
     t0 = time.time()
     core_blk = gen_block(streams, "insert", gscale, args.core_edges, 1, rank * args.core_edges, n_global, permute)
@@ -378,7 +383,8 @@ def main():
             "metric": "edge-updates/sec", "value": value, "unit": "edge-updates/s", "n_gpus": P, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": (f"config#3 {args.batch} mixed 50/50 insert+delete" if args.mixed else f"config#2 {args.batch} random inserts")
+            "config": {"workload": (f"config#3 {args.batch} mixed 50/50 insert+delete" if args.mixed else
+                                    (f"config#5 {args.batch} Zipf(1.2)-source inserts" if args.zipf else f"config#2 {args.batch} random inserts"))
                        + f" on RMAT scale-{args.scale} / {args.core_edges}-edge core per GPU"
                        + (f", {P} vertex-range partitions, labels {'permuted' if permute else 'raw'}, {'RCCL' if args.backend == 'nccl' else args.backend} all-to-all" if P > 1 else ", 1 partition"),
                        "vertices": n_global, "core_edges": args.core_edges * P, "updates_per_step": args.batch * P,

@@ -80,12 +80,12 @@ def mixed_existing_stream(core, fresh, seed):
     return out
 
 
-def zipf_sources(n, count, seed, alpha=1.2):
-    """Zipf(alpha) ranks in [0,n) by inverse CDF on a precomputed table (config #5)."""
+def zipf_sources(n, count, seed, alpha=1.2, offset=0):
+    """Zipf(alpha) ranks in [0,n) by inverse CDF on a precomputed table (config #5); counters offset..offset+count-1."""
     w = 1.0 / np.power(np.arange(1, n + 1, dtype=np.float64), alpha)
     cdf = np.cumsum(w)
     cdf /= cdf[-1]
-    u = _u01(seed, np.arange(count, dtype=np.uint64))
+    u = _u01(seed, np.arange(offset, offset + count, dtype=np.uint64))
     return np.minimum(np.searchsorted(cdf, u, side="right"), n - 1).astype(np.uint32)
 
 

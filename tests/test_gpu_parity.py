@@ -141,6 +141,20 @@ def test_api_sequences_found_by_the_fuzzer(pkg, streams, seed):
     assert ok, desc
 
 
+def test_config1_plumbing_case(mk, streams):
+    """BASELINE config #1: scale-14 RMAT, 200 000-edge core (seed 1) + 100 000 inserts (seed 2) — the
+    reference's own CPU-runnable case, as a slot-by-slot parity test"""
+    n = 1 << 14
+    s, d = streams.rmat_edges(14, 200_000, seed=1)
+    s2, d2 = streams.rmat_edges(14, 100_000, seed=2)
+    eng, o = mk(n), Oracle(n)
+    for part in (streams.adds(s, d), streams.adds(s2, d2)):
+        eng.apply(part)
+        o.apply(part)
+    _same(eng, o, "config #1")
+    _stats_match(eng, o)
+
+
 def test_slide_off_the_end_of_the_array(mk, streams):
     """slide_right runs off the end of the array (PCSR.cpp:347-351) and the reference recovers through slide_left
     (PCSR.cpp:360-390, 541-544) — a path tools/fuzz_parity.py found on ascending inserts into the last vertices"""
