@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <map>
+#include <vector>
 #include <chrono>
 
 #include "gpu_rt.h"
@@ -19,6 +20,21 @@ namespace ppcsr {
     int _e = (expr);                                                                     \
     if (_e != 0) return fail(PPCSR_EHIP, std::string(#expr) + ": " + gpu::err_str(_e)); \
   } while (0)
+
+// frees the device buffers registered with it on every exit path (error returns included) unless dismissed
+struct DevGuard {
+  std::vector<void **> slots;
+  template <class T>
+  void add(T **p) { slots.push_back(reinterpret_cast<void **>(p)); }
+  void dismiss() { slots.clear(); }
+  ~DevGuard() {
+    for (void **q : slots)
+      if (*q) {
+        gpu::dfree(*q);
+        *q = nullptr;
+      }
+  }
+};
 
 const char *error_string(int code) {
   switch (code) {
@@ -40,6 +56,7 @@ struct Engine::Impl {
   uint64_t leaves_cap = 0;   // capacity of leafcnt/wres
   Control *d_ctl = nullptr, *h_ctl = nullptr;
   Plan *d_plans = nullptr;
+  uint64_t plans_cap = 0;  // records in d_plans (shared by the strict and the speculative rounds)
   StatShard *d_stats = nullptr, *h_stats = nullptr, *d_stats_snap = nullptr;
   ExclOut *d_xout = nullptr, *h_xout = nullptr;
   Op *d_ops = nullptr;
@@ -96,6 +113,21 @@ struct Engine::Impl {
 };
 
 Engine::Engine() : p_(new Impl()) {}
+
+// d_plans is shared by both schedulers: it must hold one record per wave of the widest grid either may launch
+// (+8: the per-wave arrays are padded to the launch grid, whose waves load their record before the early-exit tests)
+static int ensure_plans(Engine::Impl &p) {
+  const uint64_t need = (uint64_t)std::max(p.opt_horizon, p.max_horizon) + 8;
+  if (p.plans_cap >= need) return 0;
+  int e = gpu::sync(p.stream);
+  if (e) return e;
+  Plan *np = nullptr;
+  if ((e = gpu::dmalloc((void **)&np, need * sizeof(Plan)))) return e;
+  if (p.d_plans) GPU_DFREE(p.d_plans);
+  p.d_plans = np;
+  p.plans_cap = need;
+  return 0;
+}
 
 // every round-tagged reservation array restarts together with the round counter (stale keys must never meet a reused tag)
 static int reset_tags(Engine::Impl &p) {
@@ -238,7 +270,7 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   GCHK(gpu::dmalloc((void **)&p.d_total, sizeof(unsigned long long)));
   GCHK(gpu::hmalloc((void **)&p.h_total, sizeof(unsigned long long)));
   GCHK(gpu::dmalloc((void **)&p.d_table, sizeof(ChainTable)));
-  GCHK(gpu::dmalloc((void **)&p.d_plans, ((uint64_t)p.max_horizon + 8) * sizeof(Plan)));
+  GCHK(ensure_plans(p));
   memset(p.h_ctl, 0, sizeof(Control));
 
   // constructor layout (PCSR.cpp:796-837): sentinel positions come from an fp64 accumulator, O(n) on the host
@@ -320,12 +352,8 @@ int Engine::set_option(const char *key, int64_t value) {
   if (k == "max_horizon") {
     if (value < 1 || value > (1 << 20)) return fail(PPCSR_EINVAL, "max_horizon out of range");
     gpu::set_device(device_);
-    gpu::sync(p.stream);
-    Plan *np = nullptr;
-    GCHK(gpu::dmalloc((void **)&np, (uint64_t)value * sizeof(Plan)));
-    GPU_DFREE(p.d_plans);
-    p.d_plans = np;
     p.max_horizon = (uint32_t)value;
+    GCHK(ensure_plans(p));
     if (p.min_horizon > p.max_horizon) p.min_horizon = p.max_horizon;
     if (p.init_horizon > p.max_horizon) p.init_horizon = p.max_horizon;
     return PPCSR_OK;
@@ -358,6 +386,8 @@ int Engine::set_option(const char *key, int64_t value) {
   if (k == "opt_horizon") {
     if (value < 1 || value > (1 << 20)) return fail(PPCSR_EINVAL, "opt_horizon out of range");
     p.opt_horizon = (uint32_t)value;
+    gpu::set_device(device_);
+    GCHK(ensure_plans(p));
     p.start_horizon = std::min<uint32_t>(p.start_horizon, p.opt_horizon);
     if (!p.adaptive) p.start_horizon = p.opt_horizon;
     return PPCSR_OK;
@@ -472,6 +502,7 @@ int Engine::apply_batch_device(const Op *d_ops, uint64_t n) {
 int Engine::run_rounds(const Op *d_ops, uint64_t n) {
   Impl &p = *p_;
   if (p.round > 0xFFFF0000u) GCHK(reset_tags(p));  // reservation tags would wrap
+  GCHK(ensure_plans(p));
   uint64_t cur = 0;
   uint32_t hor = (uint32_t)std::min<uint64_t>(p.init_horizon, n);
   while (cur < n) {
@@ -566,6 +597,7 @@ static int snap_load(Engine::Impl &p, Engine::Impl::Snap &sn);
 // snapshot; a validation failure replays the epoch with the strict prefix rounds, an exclusive update ends the epoch.
 int Engine::run_speculative(const Op *d_ops, uint64_t n) {
   Impl &p = *p_;
+  GCHK(ensure_plans(p));
   // per-slot and carry arrays
   if (p.hslot_cap < p.opt_horizon) {
     if (p.d_opidx) GPU_DFREE(p.d_opidx);
@@ -576,9 +608,6 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     GCHK(gpu::dmalloc((void **)&p.d_status, ((uint64_t)p.opt_horizon + 8) * sizeof(uint32_t)));
     if (p.d_vdbg) GPU_DFREE(p.d_vdbg);
     GCHK(gpu::dmalloc((void **)&p.d_vdbg, ((uint64_t)p.opt_horizon + 8) * 4 * sizeof(uint32_t)));
-    GPU_DFREE(p.d_plans);
-    p.d_plans = nullptr;
-    GCHK(gpu::dmalloc((void **)&p.d_plans, ((uint64_t)std::max(p.opt_horizon, p.max_horizon) + 8) * sizeof(Plan)));
     p.hslot_cap = p.opt_horizon;
   }
   const uint64_t carry_need = (uint64_t)std::max<uint64_t>(p.epoch_ops, p.opt_horizon) + 8;  // (padded to the launch grid)
@@ -904,6 +933,11 @@ int Engine::resize(uint64_t newN) {
   View nv = old;
   nv.g = g;
   const uint64_t new_leaves = newN >> g.sh;
+  nv.items = nullptr;
+  nv.leafcnt = nullptr;
+  DevGuard guard;  // a failure below leaves the engine on its old (intact) arrays
+  guard.add(&nv.items);
+  guard.add(&nv.leafcnt);
   GCHK(gpu::dmalloc((void **)&nv.items, newN * sizeof(Edge)));
   GCHK(gpu::dmalloc((void **)&nv.leafcnt, new_leaves * sizeof(uint32_t)));
   int rc = PPCSR_OK;
@@ -927,6 +961,7 @@ int Engine::resize(uint64_t newN) {
                (uint64_t)0);
   GCHK(gpu::sync(p.stream));
   GCHK(gpu::last_error());
+  guard.dismiss();
   GPU_DFREE(old.items);
   GPU_DFREE(old.leafcnt);
   {
@@ -934,6 +969,7 @@ int Engine::resize(uint64_t newN) {
     free_aux(p, tmp);
   }
   p.v = nv;
+  p.v.wres = p.v.rres = p.v.dres = nullptr;
   GCHK(alloc_aux(p, p.v));  // fresh reservation / stamp arrays for the new leaf count
   if (newN > oldN) p.st.double_calls++; else p.st.half_calls++;
   p.st.redistribute_calls++;
@@ -1029,7 +1065,9 @@ int Engine::add_node() {  // PCSR.cpp:681-703
   GCHK(gpu::sync(p.stream));
   p.v.g.n = len + 1;
   Op op{len, nd.beginning, sval};
-  return run_exclusive(op, XF_ADD_NODE | XF_FORCE_NOINFO);
+  const int rc = run_exclusive(op, XF_ADD_NODE | XF_FORCE_NOINFO);
+  if (rc != PPCSR_OK) p.v.g.n = len;  // the vertex was not added
+  return rc;
 }
 
 int Engine::edge_exists(uint32_t s, uint32_t d, int *out) {
@@ -1155,6 +1193,8 @@ int Engine::bulk_build(const Op *host_ops, uint64_t m, double *device_ms) {
   Op *d_ops = nullptr;
   unsigned long long *d_k0 = nullptr, *d_k1 = nullptr;
   uint32_t *d_v0 = nullptr, *d_v1 = nullptr, *d_flags = nullptr;
+  DevGuard tmpg;
+  tmpg.add(&d_ops); tmpg.add(&d_k0); tmpg.add(&d_k1); tmpg.add(&d_v0); tmpg.add(&d_v1); tmpg.add(&d_flags);
   const uint64_t mm = std::max<uint64_t>(m, 1);
   GCHK(gpu::dmalloc((void **)&d_ops, mm * sizeof(Op)));
   GCHK(gpu::dmalloc((void **)&d_k0, mm * sizeof(unsigned long long)));
@@ -1196,6 +1236,11 @@ int Engine::bulk_build(const Op *host_ops, uint64_t m, double *device_ms) {
   if (j + 1 >= (uint64_t)g.t_up[0]) return fail(PPCSR_EUNSUPPORTED, "bulk_build: edge array would exceed 2^31 slots");
   View nv = old;
   nv.g = g;
+  nv.items = nullptr;
+  nv.leafcnt = nullptr;
+  DevGuard nvg;
+  nvg.add(&nv.items);
+  nvg.add(&nv.leafcnt);
   GCHK(gpu::dmalloc((void **)&nv.items, newN * sizeof(Edge)));
   GCHK(gpu::dmalloc((void **)&nv.leafcnt, (newN >> g.sh) * sizeof(uint32_t)));
   ChainTable *htb = new ChainTable;
@@ -1216,6 +1261,7 @@ int Engine::bulk_build(const Op *host_ops, uint64_t m, double *device_ms) {
   GCHK(gpu::sync(p.stream));
   GCHK(gpu::last_error());
   if (device_ms) *device_ms = p.timer.ms();
+  nvg.dismiss();
   GPU_DFREE(old.items);
   GPU_DFREE(old.leafcnt);
   {
@@ -1223,13 +1269,8 @@ int Engine::bulk_build(const Op *host_ops, uint64_t m, double *device_ms) {
     free_aux(p, tmp);
   }
   p.v = nv;
+  p.v.wres = p.v.rres = p.v.dres = nullptr;
   GCHK(alloc_aux(p, p.v));
-  GPU_DFREE(d_ops);
-  GPU_DFREE(d_k0);
-  GPU_DFREE(d_k1);
-  GPU_DFREE(d_v0);
-  GPU_DFREE(d_v1);
-  GPU_DFREE(d_flags);
   return PPCSR_OK;
 }
 
@@ -1241,6 +1282,8 @@ int Engine::bfs(uint32_t start, uint32_t *levels, double *device_ms) {
   const uint32_t nn = n();
   if (start >= nn) return fail(PPCSR_EINVAL, "bfs: start vertex out of range");
   uint32_t *d_lv = nullptr, *d_f0 = nullptr, *d_f1 = nullptr, *d_cnt = nullptr;
+  DevGuard tmpg;
+  tmpg.add(&d_lv); tmpg.add(&d_f0); tmpg.add(&d_f1); tmpg.add(&d_cnt);
   GCHK(gpu::dmalloc((void **)&d_lv, (uint64_t)nn * sizeof(uint32_t)));
   GCHK(gpu::dmalloc((void **)&d_f0, (uint64_t)nn * sizeof(uint32_t)));
   GCHK(gpu::dmalloc((void **)&d_f1, (uint64_t)nn * sizeof(uint32_t)));
@@ -1293,10 +1336,6 @@ int Engine::bfs(uint32_t start, uint32_t *levels, double *device_ms) {
   GCHK(gpu::d2h(levels, d_lv, (uint64_t)nn * sizeof(uint32_t), p.stream));
   GCHK(gpu::sync(p.stream));
   if (device_ms) *device_ms = p.timer.ms();
-  GPU_DFREE(d_lv);
-  GPU_DFREE(d_f0);
-  GPU_DFREE(d_f1);
-  GPU_DFREE(d_cnt);
   return PPCSR_OK;
 }
 
@@ -1335,6 +1374,9 @@ int Engine::pagerank(const float *node_values, float *out, double *device_ms) {
   const uint64_t N = p.v.g.N;
   float *d_val = nullptr, *d_c0 = nullptr, *d_c1 = nullptr, *d_out = nullptr;
   uint32_t *d_k0 = nullptr, *d_k1 = nullptr;
+  uint32_t *d_long = nullptr;  // [0]: count, [1..]: destinations with long runs
+  DevGuard tmpg;
+  tmpg.add(&d_val); tmpg.add(&d_c0); tmpg.add(&d_c1); tmpg.add(&d_out); tmpg.add(&d_k0); tmpg.add(&d_k1); tmpg.add(&d_long);
   GCHK(gpu::dmalloc((void **)&d_val, (uint64_t)nn * sizeof(float)));
   GCHK(gpu::dmalloc((void **)&d_out, (uint64_t)nn * sizeof(float)));
   GCHK(gpu::dmalloc((void **)&d_k0, N * sizeof(uint32_t)));
@@ -1355,7 +1397,6 @@ int Engine::pagerank(const float *node_values, float *out, double *device_ms) {
     rc = sort_pairs_stable(p.stream, d_k0, d_k1, d_c0, d_c1, m, bits);
     if (rc != 0) return fail(rc == 2 ? PPCSR_ENOMEM : PPCSR_EHIP, "pagerank: device sort failed");
   }
-  uint32_t *d_long = nullptr;  // [0]: count, [1..]: destinations with long runs
   GCHK(gpu::dmalloc((void **)&d_long, ((uint64_t)nn + 1) * sizeof(uint32_t)));
   GCHK(gpu::dset(d_long, 0, sizeof(uint32_t), p.stream));
   GPU_LAUNCH(p.stream, k_pr_segsum, grid_for(nn, 256), 256, (const uint32_t *)d_k1, (const float *)d_c1, m, nn, d_out, d_long + 1, d_long);
@@ -1366,13 +1407,6 @@ int Engine::pagerank(const float *node_values, float *out, double *device_ms) {
   GCHK(gpu::sync(p.stream));
   GCHK(gpu::last_error());
   if (device_ms) *device_ms = p.timer.ms();
-  GPU_DFREE(d_val);
-  GPU_DFREE(d_out);
-  GPU_DFREE(d_k0);
-  GPU_DFREE(d_k1);
-  GPU_DFREE(d_c0);
-  GPU_DFREE(d_c1);
-  GPU_DFREE(d_long);
   return PPCSR_OK;
 }
 
@@ -1382,6 +1416,8 @@ int Engine::scan_all_device(double *ms, uint64_t *total) {
   const uint64_t N = p.v.g.N;
   unsigned long long *d_rows = nullptr;
   int *d_dst = nullptr;
+  DevGuard tmpg;
+  tmpg.add(&d_rows); tmpg.add(&d_dst);
   GCHK(gpu::dmalloc((void **)&d_rows, ((uint64_t)n() + 1) * sizeof(unsigned long long)));
   GCHK(gpu::dmalloc((void **)&d_dst, N * sizeof(int)));
   int rc = scan_launch(d_rows, d_dst, N);  // warm-up (sizes the tile-state array)
@@ -1395,8 +1431,6 @@ int Engine::scan_all_device(double *ms, uint64_t *total) {
   GCHK(gpu::last_error());
   if (ms) *ms = p.timer.ms();
   if (total) *total = *p.h_total;
-  GPU_DFREE(d_rows);
-  GPU_DFREE(d_dst);
   return PPCSR_OK;
 }
 
@@ -1406,6 +1440,8 @@ int Engine::scan_all(uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *
   const uint32_t nn = n();
   unsigned long long *d_rows = nullptr;
   int *d_dst = nullptr;
+  DevGuard tmpg;
+  tmpg.add(&d_rows); tmpg.add(&d_dst);
   GCHK(gpu::dmalloc((void **)&d_rows, ((uint64_t)nn + 1) * sizeof(unsigned long long)));
   GCHK(gpu::dmalloc((void **)&d_dst, std::max<uint64_t>(cap, 1) * sizeof(int)));
   int rc = scan_launch(d_rows, d_dst, cap);
@@ -1424,8 +1460,6 @@ int Engine::scan_all(uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *
     GCHK(gpu::d2h(dests, d_dst, std::min(cap, tot) * sizeof(int), p.stream));
     GCHK(gpu::sync(p.stream));
   }
-  GPU_DFREE(d_rows);
-  GPU_DFREE(d_dst);
   return (tot > cap && dests) ? PPCSR_ERANGE : PPCSR_OK;
 }
 

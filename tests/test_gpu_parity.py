@@ -106,6 +106,25 @@ def test_random_mixed_vs_oracle(mk, streams, seed, n, lock):
     _stats_match(eng, o)
 
 
+def test_horizon_options_changed_between_batches(pkg, streams):
+    """the plan-record buffer is shared by both schedulers; shrinking max_horizon after a speculative batch
+    (or growing opt_horizon) must never leave it smaller than the widest grid either may launch"""
+    n = 5000
+    ops = streams.random_stream(n, 90000, seed=77, p_delete=0.15)
+    eng, o = pkg.PCSR(n), Oracle(n)
+    eng.set_option("small_batch", 0)
+    eng.apply(ops[:30000])               # speculative, 6144-wide rounds
+    eng.set_option("max_horizon", 1024)  # used to reallocate the shared buffer with 1024 records
+    eng.apply(ops[30000:60000])          # speculative again: o_plan writes plans[wid] for wid < 6144
+    eng.set_option("mode", 0)
+    eng.apply(ops[60000:75000])          # strict rounds on the same buffer
+    eng.set_option("mode", 1)
+    eng.set_option("opt_horizon", 8192)  # wider than anything allocated so far
+    eng.apply(ops[75000:])
+    o.apply(ops)
+    _same(eng, o, "after option changes")
+
+
 def test_hubs_and_last_vertex(mk, streams):
     m = 20000
     for src_mode in ("last", "first", "tail"):

@@ -105,6 +105,22 @@ def test_sim_speculative_stats_survive_rollback(sim, streams):
         assert se[k] == so[k], k
 
 
+def test_sim_horizon_options_changed_between_batches(sim, streams):
+    """the shared plan-record buffer follows max(opt_horizon, max_horizon) whenever either option changes"""
+    ops = streams.random_stream(400, 9000, seed=12, p_delete=0.2)
+    e, o = sim(400, mode=1, opt_horizon=256, epoch_ops=2048, region_slots=64, max_horizon=64), Oracle(400)
+    e.apply(ops[:3000])
+    e.set_option("max_horizon", 8)
+    e.apply(ops[3000:6000])
+    e.set_option("mode", 0)
+    e.apply(ops[6000:7500])
+    e.set_option("mode", 1)
+    e.set_option("opt_horizon", 512)
+    e.apply(ops[7500:])
+    o.apply(ops)
+    _same(e, o)
+
+
 def test_sim_big_window_rebalance(sim, streams):
     """the multi-workgroup rebalance (rank scan + exact position table + fused scatter/fill) on whole-array and
     partial windows, against the reference's redistribute() run by the oracle on the same window"""
