@@ -105,8 +105,14 @@ int ppcsr_pagerank(ppcsr_t h, const float *node_values, float *out, double *devi
 /* raw state for parity checks: items[N], nodes[n] exactly as the reference holds them (PCSR.h:67,128) */
 int ppcsr_export_state(ppcsr_t h, ppcsr_edge *items, ppcsr_node *nodes);
 int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out);
-/* knobs: "mode" (0 strict prefix rounds, 1 speculative rounds + validated rollback), "opt_horizon", "epoch_ops",
- * "region_slots", "max_horizon", "min_horizon", "init_horizon", "rounds_per_sync", "profile" */
+/* knobs (int64 values):
+ *   scheduler  "mode" (0 strict prefix rounds, 1 speculative rounds + validated rollback; default 1), "opt_horizon",
+ *              "start_horizon", "adaptive", "epoch_ops", "region_slots", "small_batch" (batches up to this size take the
+ *              strict rounds), "max_horizon" / "min_horizon" / "init_horizon" (strict rounds), "rounds_per_sync"
+ *   rebalance  "scatter_variant" (0 LDS-staged, 1 register runs, 2 runs + in-tile leaf scan), "scatter_blocks",
+ *              "rb_tile", "rb_min_tiles", "rb_prefetch"
+ *   search     "search_narrow" (0: literal binary walk only)
+ *   measuring  "profile" (1: HIP events around every round kernel, reported through ppcsr_stats) */
 int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value);
 /* device-side copy of the whole state and return to it (used by the benchmark to replay a batch on the same
  * core graph, and by the engine itself as the rollback point of speculative rounds); no reference equivalent */
@@ -125,6 +131,11 @@ int ppcsr_device_count(void);
  * devices[p % n_devices] (n_devices may be 1: all partitions on one GPU) */
 int pppcsr_create(uint32_t init_n, uint32_t src_n, int lock_search, int num_domains, int parts_per_domain,
                   const int *devices, int n_devices, pppcsr_t *out);
+/* the same layout, but only partitions [first_part, first_part + n_local_parts) are created, all on `device`: the form a
+ * multi-process run uses (one rank per GPU holding the partitions of its domain; the other partitions live in other
+ * processes and calls that route to them fail with EINVAL) */
+int pppcsr_create_local(uint32_t init_n, int lock_search, int num_domains, int parts_per_domain, uint64_t first_part,
+                        uint64_t n_local_parts, int device, pppcsr_t *out);
 int pppcsr_destroy(pppcsr_t h);
 int pppcsr_num_partitions(pppcsr_t h, uint64_t *out);
 /* PPPCSR::get_partiton — PPPCSR.cpp:58-66 */
@@ -142,6 +153,14 @@ int pppcsr_add_node(pppcsr_t h);
 /* bucket a host stream by owner (stable: per-partition order == stream order, src made partition-local as in
  * PPPCSR.cpp:46-52) and apply each bucket on its partition's GPU */
 int pppcsr_apply_batch(pppcsr_t h, const ppcsr_op *ops, uint64_t n);
+/* the same for a batch already resident in HBM (all partitions on that one GPU): device-side stable bucketing, then every
+ * partition applies its bucket on its own stream, driven by one host thread each — the reference's ThreadPoolPPPCSR runs
+ * its domains' workers concurrently in the same way (thread_pool_pppcsr.cpp:121-156) */
+int pppcsr_apply_batch_device(pppcsr_t h, const ppcsr_op *d_ops, uint64_t n);
+/* already routed subsequences (partition-local src, stream order), one device pointer per partition of
+ * [first_part, first_part + n_parts): what a rank holds after the all-to-all exchange; applied concurrently as above */
+int pppcsr_apply_parts_device(pppcsr_t h, uint64_t first_part, uint64_t n_parts, const ppcsr_op *const *d_ops,
+                              const uint64_t *counts);
 /* owner-bucketing primitive for the multi-process (one rank per GPU) path: counts[p] = ops owned by p,
  * bucketed = ops stably grouped by owner with partition-local src.  Pure host routine. */
 int pppcsr_bucket_ops(uint32_t init_n, uint64_t n_parts, const ppcsr_op *ops, uint64_t n, ppcsr_op *bucketed,

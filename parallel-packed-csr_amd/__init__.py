@@ -44,6 +44,7 @@ EXPORTED = [
     "pppcsr_get_partition", "pppcsr_partition_start", "pppcsr_partition", "pppcsr_add_edge", "pppcsr_remove_edge",
     "pppcsr_edge_exists", "pppcsr_get_neighbourhood", "pppcsr_get_node", "pppcsr_get_n", "pppcsr_add_node",
     "pppcsr_apply_batch", "pppcsr_bucket_ops", "pppcsr_bucket_ops_device",
+    "pppcsr_create_local", "pppcsr_apply_batch_device", "pppcsr_apply_parts_device",
 ]
 
 _LIBS = {}
@@ -126,6 +127,9 @@ def load_library(path=None):
     L.pppcsr_apply_batch.argtypes = [c_vp, c_vp, c_u64]
     L.pppcsr_bucket_ops.argtypes = [c_u32, c_u64, c_vp, c_u64, c_vp, c_vp]
     L.pppcsr_bucket_ops_device.argtypes = [c_u32, c_u64, c_vp, c_u64, c_vp, c_vp, c_vp]
+    L.pppcsr_create_local.argtypes = [c_u32, c_int, c_int, c_int, c_u64, c_u64, c_int, ctypes.POINTER(c_vp)]
+    L.pppcsr_apply_batch_device.argtypes = [c_vp, c_vp, c_u64]
+    L.pppcsr_apply_parts_device.argtypes = [c_vp, c_u64, c_u64, c_vp, c_vp]
     _LIBS[path] = L
     return L
 
@@ -280,12 +284,18 @@ class PPPCSR:
     """Mirror of the reference class PPPCSR (PPPCSR.h:11-60): vertex-range partitions, one per GPU."""
 
     def __init__(self, init_n, src_n=None, lock_search=True, numDomain=1, partitionsPerDomain=1, use_numa=False,
-                 devices=None, lib=None):
+                 devices=None, lib=None, local=None):
+        """local=(first_part, n_parts, device): create only that range of the layout's partitions (multi-process runs:
+        one rank per GPU holds the partitions of its domain)"""
         self.L = lib or load_library()
         self.h = c_vp()
-        devs = np.array(devices if devices else [0], np.int32)
-        rc = self.L.pppcsr_create(init_n, init_n if src_n is None else src_n, int(lock_search), numDomain,
-                                  partitionsPerDomain, devs.ctypes.data, len(devs), ctypes.byref(self.h))
+        if local is not None:
+            rc = self.L.pppcsr_create_local(init_n, int(lock_search), numDomain, partitionsPerDomain, local[0], local[1],
+                                            local[2], ctypes.byref(self.h))
+        else:
+            devs = np.array(devices if devices else [0], np.int32)
+            rc = self.L.pppcsr_create(init_n, init_n if src_n is None else src_n, int(lock_search), numDomain,
+                                      partitionsPerDomain, devs.ctypes.data, len(devs), ctypes.byref(self.h))
         if rc != 0:
             raise PpcsrError(f"pppcsr_create: status {rc}: {self.L.ppcsr_last_error().decode()}")
 
@@ -355,6 +365,17 @@ class PPPCSR:
         a = _ops(ops)
         if len(a):
             self._chk(self.L.pppcsr_apply_batch(self.h, a.ctypes.data, len(a)))
+
+    def apply_device(self, dev_ptr, n):
+        """global stream resident in HBM (all partitions on that GPU): device bucketing + concurrent per-partition apply"""
+        self._chk(self.L.pppcsr_apply_batch_device(self.h, dev_ptr, n))
+
+    def apply_parts_device(self, first_part, dev_ptrs, counts):
+        """already routed device-resident subsequences, one per partition of [first_part, first_part + len(counts))"""
+        k = len(counts)
+        ptrs = (c_vp * k)(*[int(x) for x in dev_ptrs])
+        cnts = (c_u64 * k)(*[int(x) for x in counts])
+        self._chk(self.L.pppcsr_apply_parts_device(self.h, first_part, k, ptrs, cnts))
 
 
 def bucket_ops(init_n, n_parts, ops, lib=None):

@@ -40,15 +40,17 @@ def build_engine(force=False, verbose=False):
 HOST_DIR = os.path.join(HERE, "host")
 CLI = os.path.join(HOST_DIR, "ppcsr_cli")
 CPP_TEST = os.path.join(ROOT, "tests", "cpp", "test_datastructure")
+CPP_PAR_TEST = os.path.join(ROOT, "tests", "cpp", "test_parallel")
 
 
 def build_host():
     """the C++ host side above the C ABI: CLI with the reference's flags + the restated DataStructureTest binary"""
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + HOST_DIR]
     link = ["-L" + CSRC, "-lppcsr_hip", "-Wl,-rpath," + CSRC]
-    base = ["g++", "-std=c++17", "-O2", "-Wall"]
+    base = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread"]
     subprocess.run(base + inc + [os.path.join(HOST_DIR, "main.cpp")] + link + ["-o", CLI], check=True)
     subprocess.run(base + inc + [os.path.join(ROOT, "tests", "cpp", "test_datastructure.cpp")] + link + ["-o", CPP_TEST], check=True)
+    subprocess.run(base + inc + [os.path.join(ROOT, "tests", "cpp", "test_parallel.cpp")] + link + ["-o", CPP_PAR_TEST], check=True)
     return CLI
 
 

@@ -13,6 +13,12 @@
 
 using ppcsr::Engine;
 
+// small device helpers implemented in engine.cc (this file stays free of runtime headers)
+int capi_set_device(int d);
+int capi_dev_alloc(void **p, size_t bytes);
+int capi_dev_free(void *p);
+int capi_d2h_sync(void *dst, const void *src, size_t bytes);  // on the NULL stream, after whatever it holds
+
 static thread_local std::string g_last_error;
 
 struct ppcsr_engine {
@@ -155,9 +161,14 @@ const char *ppcsr_last_error(void) { return g_last_error.c_str(); }
 }  // extern "C"
 
 struct pppcsr_engine {
-  std::vector<ppcsr_engine *> parts;
+  std::vector<ppcsr_engine *> parts;   // one per partition of the GLOBAL layout; nullptr = not resident in this process
   std::vector<uint64_t> distribution;  // first vertex of each partition (PPPCSR.h:57)
+  std::vector<int> device;             // device of each resident partition
   uint32_t init_n;
+  // device-resident routing scratch of pppcsr_apply_batch_device (bucketed copy of the batch + bucket sizes)
+  ppcsr_op *d_bucketed = nullptr;
+  uint64_t bucketed_cap = 0;
+  uint64_t *d_counts = nullptr;
 };
 
 // PPPCSR.cpp:20-29: partitionSize = floor(init_n / P) (the std::ceil wraps an integer division); last takes the rest
@@ -179,37 +190,57 @@ static uint64_t owner_of(const std::vector<uint64_t> &dist, uint64_t v) {
 
 extern "C" {
 
-int pppcsr_create(uint32_t init_n, uint32_t src_n, int lock_search, int num_domains, int parts_per_domain, const int *devices,
-                  int n_devices, pppcsr_t *out) {
-  (void)src_n;
+// partitions [first, first + n_local) of the global layout are created in this process; partition k lives on the device
+// of its DOMAIN (the reference allocates the partitions of domain d on NUMA node d, PPPCSR.cpp:24-31): devices[(k / ppd) % n]
+static int create_parts(uint32_t init_n, int lock_search, int num_domains, int parts_per_domain, uint64_t first, uint64_t n_local,
+                        const int *devices, int n_devices, pppcsr_t *out) {
   if (!out || num_domains < 1 || parts_per_domain < 1) return bad("bad partition counts");
   *out = nullptr;
   const uint64_t P = (uint64_t)num_domains * (uint64_t)parts_per_domain;
+  if (first + n_local > P) return bad("local partition range exceeds the layout");
   std::unique_ptr<pppcsr_engine> pp(new pppcsr_engine());
   pp->init_n = init_n;
   std::vector<uint64_t> sizes;
   partition_layout(init_n, P, &pp->distribution, &sizes);
-  for (uint64_t k = 0; k < P; k++) {
+  pp->parts.assign(P, nullptr);
+  pp->device.assign(P, 0);
+  for (uint64_t k = first; k < first + n_local; k++) {
     ppcsr_t h = nullptr;
-    const int dev = (devices && n_devices > 0) ? devices[k % (uint64_t)n_devices] : 0;
+    const int dev = (devices && n_devices > 0) ? devices[(k / (uint64_t)parts_per_domain) % (uint64_t)n_devices] : 0;
     int rc = ppcsr_create((uint32_t)sizes[k], (uint32_t)sizes[k], lock_search, dev, &h);
     if (rc != 0) {
       for (auto *q : pp->parts) ppcsr_destroy(q);
       return rc;
     }
-    pp->parts.push_back(h);
+    pp->parts[k] = h;
+    pp->device[k] = dev;
   }
   *out = pp.release();
   return 0;
 }
+int pppcsr_create(uint32_t init_n, uint32_t src_n, int lock_search, int num_domains, int parts_per_domain, const int *devices,
+                  int n_devices, pppcsr_t *out) {
+  (void)src_n;
+  if (num_domains < 1 || parts_per_domain < 1) return bad("bad partition counts");
+  return create_parts(init_n, lock_search, num_domains, parts_per_domain, 0, (uint64_t)num_domains * (uint64_t)parts_per_domain, devices,
+                      n_devices, out);
+}
+int pppcsr_create_local(uint32_t init_n, int lock_search, int num_domains, int parts_per_domain, uint64_t first_part,
+                        uint64_t n_local_parts, int device, pppcsr_t *out) {
+  return create_parts(init_n, lock_search, num_domains, parts_per_domain, first_part, n_local_parts, &device, 1, out);
+}
 int pppcsr_destroy(pppcsr_t h) {
   if (!h) return 0;
   for (auto *q : h->parts) ppcsr_destroy(q);
+  if (h->d_bucketed) capi_dev_free(h->d_bucketed);
+  if (h->d_counts) capi_dev_free(h->d_counts);
   delete h;
   return 0;
 }
 #define PP_CHECK() \
   if (!h) return bad("null handle")
+#define PP_PART(k) \
+  if ((k) >= h->parts.size() || !h->parts[(k)]) return bad("partition not resident in this process")
 int pppcsr_num_partitions(pppcsr_t h, uint64_t *out) { PP_CHECK(); *out = h->parts.size(); return 0; }
 int pppcsr_get_partition(pppcsr_t h, uint64_t v, uint64_t *part) { PP_CHECK(); *part = owner_of(h->distribution, v); return 0; }
 int pppcsr_partition_start(pppcsr_t h, uint64_t part, uint64_t *first) {
@@ -221,43 +252,49 @@ int pppcsr_partition_start(pppcsr_t h, uint64_t part, uint64_t *first) {
 int pppcsr_partition(pppcsr_t h, uint64_t part, ppcsr_t *out) {
   PP_CHECK();
   if (part >= h->parts.size()) return bad("partition out of range");
+  PP_PART(part);
   *out = h->parts[part];
   return 0;
 }
 int pppcsr_add_edge(pppcsr_t h, uint32_t s, uint32_t d, uint32_t v) {
   PP_CHECK();
   const uint64_t k = owner_of(h->distribution, s);
+  PP_PART(k);
   return ppcsr_add_edge(h->parts[k], (uint32_t)(s - h->distribution[k]), d, v);
 }
 int pppcsr_remove_edge(pppcsr_t h, uint32_t s, uint32_t d) {
   PP_CHECK();
   const uint64_t k = owner_of(h->distribution, s);
+  PP_PART(k);
   return ppcsr_remove_edge(h->parts[k], (uint32_t)(s - h->distribution[k]), d);
 }
 int pppcsr_edge_exists(pppcsr_t h, uint32_t s, uint32_t d, int *exists) {
   PP_CHECK();
   const uint64_t k = owner_of(h->distribution, s);
+  PP_PART(k);
   return ppcsr_edge_exists(h->parts[k], (uint32_t)(s - h->distribution[k]), d, exists);
 }
 int pppcsr_get_neighbourhood(pppcsr_t h, int src, int *out, uint64_t cap, uint64_t *count) {
   PP_CHECK();
   if (src < 0) { if (count) *count = 0; return 0; }
   const uint64_t k = owner_of(h->distribution, (uint64_t)src);
+  PP_PART(k);
   return ppcsr_get_neighbourhood(h->parts[k], (int)((uint64_t)src - h->distribution[k]), out, cap, count);
 }
 int pppcsr_get_node(pppcsr_t h, uint32_t v, ppcsr_node *out) {
   PP_CHECK();
   const uint64_t k = owner_of(h->distribution, v);
+  PP_PART(k);
   return ppcsr_get_node(h->parts[k], (uint32_t)(v - h->distribution[k]), out);
 }
 int pppcsr_get_n(pppcsr_t h, uint64_t *n) {
   PP_CHECK();
   uint64_t t = 0;
-  for (auto *q : h->parts) { uint64_t x = 0; ppcsr_get_n(q, &x); t += x; }
+  for (auto *q : h->parts) { uint64_t x = 0; if (q) ppcsr_get_n(q, &x); t += x; }  // (resident partitions)
   *n = t;
   return 0;
 }
-int pppcsr_add_node(pppcsr_t h) { PP_CHECK(); return ppcsr_add_node(h->parts.back()); }  // PPPCSR.cpp:44
+int pppcsr_add_node(pppcsr_t h) { PP_CHECK(); PP_PART(h->parts.size() - 1); return ppcsr_add_node(h->parts.back()); }  // PPPCSR.cpp:44
 
 int pppcsr_bucket_ops(uint32_t init_n, uint64_t n_parts, const ppcsr_op *ops, uint64_t n, ppcsr_op *bucketed, uint64_t *counts) {
   if (n_parts < 1 || (!ops && n) || !bucketed || !counts) return bad("bad arguments");
@@ -290,41 +327,46 @@ int pppcsr_bucket_ops_device(uint32_t init_n, uint64_t n_parts, const ppcsr_op *
   return rc;
 }
 
-int pppcsr_apply_batch(pppcsr_t h, const ppcsr_op *ops, uint64_t n) {
-  PP_CHECK();
-  const uint64_t P = h->parts.size();
-  std::vector<ppcsr_op> b(n);
-  std::vector<uint64_t> counts(P);
-  int rc = pppcsr_bucket_ops(h->init_n, P, ops, n, b.data(), counts.data());
-  if (rc != 0) return rc;
-  std::vector<uint64_t> offs(P + 1, 0);
-  for (uint64_t k = 0; k < P; k++) offs[k + 1] = offs[k] + counts[k];
+// Partitions are independent engines with their own streams (PPPCSR.h:54): host threads drive them side by side — the
+// reference runs every domain's workers concurrently (thread_pool_pppcsr.cpp:121-156) — so the latency-bound round
+// kernels of different partitions overlap on the GPU(s).  Each partition still applies its own subsequence in stream order.
+// ops[i] / counts[i] belong to partition first + i; `device_resident` selects the entry point.
+static int apply_parts(pppcsr_t h, uint64_t first, uint64_t np, const ppcsr_op *const *ops, const uint64_t *counts, bool device_resident) {
+  for (uint64_t i = 0; i < np; i++)
+    if (counts[i] && (first + i >= h->parts.size() || !h->parts[first + i])) return bad("partition not resident in this process");
+  auto one = [&](uint64_t i) -> int {
+    if (!counts[i]) return 0;
+    return device_resident ? ppcsr_apply_batch_device(h->parts[first + i], ops[i], counts[i])
+                           : ppcsr_apply_batch(h->parts[first + i], ops[i], counts[i]);
+  };
 #if defined(PPCSR_SIM)
-  for (uint64_t k = 0; k < P; k++) {  // (the CPU emulator is single-threaded)
-    rc = ppcsr_apply_batch(h->parts[k], b.data() + offs[k], counts[k]);
+  for (uint64_t i = 0; i < np; i++) {  // (the CPU emulator is single-threaded)
+    const int rc = one(i);
     if (rc != 0) return rc;
   }
   return 0;
 #else
-  // Partitions are independent engines with their own streams (PPPCSR.h:54): host threads drive them side by side, so
-  // the latency-bound round kernels of different partitions overlap on the GPU(s).  Each partition still applies its
-  // own subsequence in stream order.
-  uint64_t T = std::min<uint64_t>(P, 16);
-  if (const char *e = getenv("PPCSR_PP_THREADS")) T = std::max<uint64_t>(1, std::min<uint64_t>(P, strtoull(e, nullptr, 10)));  // measurement hook
+  uint64_t T = std::min<uint64_t>(np, 16);
+  if (const char *e = getenv("PPCSR_PP_THREADS")) T = std::max<uint64_t>(1, std::min<uint64_t>(np, strtoull(e, nullptr, 10)));  // measurement hook
   if (T <= 1) {
-    for (uint64_t k = 0; k < P; k++) {
-      rc = ppcsr_apply_batch(h->parts[k], b.data() + offs[k], counts[k]);
+    for (uint64_t i = 0; i < np; i++) {
+      const int rc = one(i);
       if (rc != 0) return rc;
     }
     return 0;
   }
+  // largest subsequences first: with skewed partitions (raw RMAT labels put 44 % of the edges in partition 0) the batch
+  // takes as long as its largest partition, which must not start last
+  std::vector<uint64_t> order(np);
+  for (uint64_t i = 0; i < np; i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return counts[a] > counts[b]; });
   std::vector<int> rcs(T, 0);
   std::vector<std::string> msgs(T);
   std::vector<std::thread> th;
   for (uint64_t t = 0; t < T; t++)
     th.emplace_back([&, t]() {
-      for (uint64_t k = t; k < P; k += T) {
-        const int r = ppcsr_apply_batch(h->parts[k], b.data() + offs[k], counts[k]);
+      for (uint64_t j = t; j < np; j += T) {
+        const int r = one(order[j]);
         if (r != 0) {
           rcs[t] = r;
           msgs[t] = ppcsr_last_error();  // (thread-local in the worker)
@@ -340,6 +382,59 @@ int pppcsr_apply_batch(pppcsr_t h, const ppcsr_op *ops, uint64_t n) {
     }
   return 0;
 #endif
+}
+
+int pppcsr_apply_batch(pppcsr_t h, const ppcsr_op *ops, uint64_t n) {
+  PP_CHECK();
+  if (n == 0) return 0;
+  const uint64_t P = h->parts.size();
+  std::vector<ppcsr_op> b(n);
+  std::vector<uint64_t> counts(P);
+  int rc = pppcsr_bucket_ops(h->init_n, P, ops, n, b.data(), counts.data());
+  if (rc != 0) return rc;
+  std::vector<const ppcsr_op *> ptrs(P);
+  uint64_t off = 0;
+  for (uint64_t k = 0; k < P; k++) {
+    ptrs[k] = b.data() + off;
+    off += counts[k];
+  }
+  return apply_parts(h, 0, P, ptrs.data(), counts.data(), false);
+}
+
+int pppcsr_apply_parts_device(pppcsr_t h, uint64_t first_part, uint64_t n_parts, const ppcsr_op *const *d_ops, const uint64_t *counts) {
+  PP_CHECK();
+  if (!d_ops || !counts) return bad("null argument");
+  return apply_parts(h, first_part, n_parts, d_ops, counts, true);
+}
+
+int pppcsr_apply_batch_device(pppcsr_t h, const ppcsr_op *d_ops, uint64_t n) {
+  PP_CHECK();
+  if (n == 0) return 0;
+  const uint64_t P = h->parts.size();
+  if (P > 64) return bad("pppcsr_apply_batch_device: more than 64 partitions");
+  for (uint64_t k = 0; k < P; k++)
+    if (!h->parts[k] || h->device[k] != h->device[0]) return bad("pppcsr_apply_batch_device: every partition must be resident on the device that holds the batch");
+  int rc = capi_set_device(h->device[0]);
+  if (rc != 0) return rc;
+  if (h->bucketed_cap < n) {
+    if (h->d_bucketed) capi_dev_free(h->d_bucketed);
+    h->d_bucketed = nullptr;
+    h->bucketed_cap = 0;
+    if (capi_dev_alloc((void **)&h->d_bucketed, n * sizeof(ppcsr_op)) != 0) return bad("pppcsr_apply_batch_device: out of device memory");
+    h->bucketed_cap = n;
+  }
+  if (!h->d_counts && capi_dev_alloc((void **)&h->d_counts, 64 * sizeof(uint64_t)) != 0) return bad("pppcsr_apply_batch_device: out of device memory");
+  rc = pppcsr_bucket_ops_device(h->init_n, P, d_ops, n, h->d_bucketed, h->d_counts, nullptr);
+  if (rc != 0) return rc;
+  std::vector<uint64_t> counts(P);
+  if (capi_d2h_sync(counts.data(), h->d_counts, P * sizeof(uint64_t)) != 0) return bad("pppcsr_apply_batch_device: device-to-host copy failed");
+  std::vector<const ppcsr_op *> ptrs(P);
+  uint64_t off = 0;
+  for (uint64_t k = 0; k < P; k++) {
+    ptrs[k] = h->d_bucketed + off;
+    off += counts[k];
+  }
+  return apply_parts(h, 0, P, ptrs.data(), counts.data(), true);
 }
 
 }  // extern "C"

@@ -1637,3 +1637,12 @@ int bucket_ops_device(uint32_t init_n, uint32_t n_parts, const Op *d_ops, uint64
 }  // namespace ppcsr
 
 int gpu_device_count_for_capi(int *n) { return gpu::device_count(n); }
+int capi_set_device(int d) { return gpu::set_device(d) ? ppcsr::PPCSR_EHIP : 0; }
+int capi_dev_alloc(void **p, size_t bytes) { return gpu::dmalloc(p, bytes); }
+int capi_dev_free(void *p) { return gpu::dfree(p); }
+int capi_d2h_sync(void *dst, const void *src, size_t bytes) {
+  gpu::stream_t st = gpu::stream_from_ptr(nullptr);
+  int e = gpu::d2h(dst, src, bytes, st);
+  if (e) return e;
+  return gpu::sync(st);
+}

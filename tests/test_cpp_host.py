@@ -14,11 +14,12 @@ from helpers import ROOT, load_streams
 pytestmark = pytest.mark.gpu
 CLI = os.path.join(ROOT, "parallel-packed-csr_amd", "host", "ppcsr_cli")
 CPP_TEST = os.path.join(ROOT, "tests", "cpp", "test_datastructure")
+CPP_PAR_TEST = os.path.join(ROOT, "tests", "cpp", "test_parallel")
 REF_CLI = os.path.join(ROOT, "oracle", "_ref", "ref_cli")
 
 
 def _ensure_built():
-    if not (os.path.exists(CLI) and os.path.exists(CPP_TEST)):
+    if not (os.path.exists(CLI) and os.path.exists(CPP_TEST) and os.path.exists(CPP_PAR_TEST)):
         import importlib.util
         spec = importlib.util.spec_from_file_location("ppcsr_build", os.path.join(ROOT, "parallel-packed-csr_amd", "build.py"))
         b = importlib.util.module_from_spec(spec)
@@ -31,6 +32,57 @@ def test_reference_datastructure_suite_restated():
     _ensure_built()
     r = subprocess.run([CPP_TEST], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_reference_parallel_tests_restated():
+    """DataStructureTest.cpp:81-120 and :146-174 (OpenMP there, 8 std::threads here) on one PCSR, and the same contract
+    on a 4-partition PPPCSR; the host-side locking itself is checked under TSan by tests/test_host_tsan.py"""
+    _ensure_built()
+    r = subprocess.run([CPP_PAR_TEST, "8", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_cli_pppcsr_drives_all_partitions_at_once(tmp_path):
+    """-pppcsrnuma -partitions_per_domain=8 on one GPU: the CLI's PPPCSR shim sits on pppcsr_apply_batch (owner bucketing +
+    one host thread and stream per partition), so its phase-2 time must be that of the threaded C-ABI call — not 8
+    partitions one after the other (which measured 1.6x slower)"""
+    import time
+    import pandas as pd
+    from helpers import load_pkg
+    _ensure_built()
+    st = load_streams()
+    pkg = load_pkg()
+    scale, m, u = 18, 2_000_000, 500_000
+    s, d = st.rmat_edges(scale, m, seed=1)
+    n0 = 1 << scale
+    core = st.adds(st.permute_labels(s, n0), d)
+    s2, d2 = st.rmat_edges(scale, u, seed=2)
+    upd = st.adds(st.permute_labels(s2, n0), d2)
+    n = int(max(core[:, :2].max(), upd[:, :2].max())) + 1  # the CLI sizes the graph by the largest id it reads
+    cf, uf = str(tmp_path / "core.txt"), str(tmp_path / "upd.txt")
+    pd.DataFrame(core[:, :2]).to_csv(cf, sep=" ", header=False, index=False)
+    pd.DataFrame(upd[:, :2]).to_csv(uf, sep=" ", header=False, index=False)
+    args = ["-threads=8", f"-size={u}", "-insert", "-pppcsrnuma", "-partitions_per_domain=8", "-gpus=1",
+            f"-core_graph={cf}", f"-update_file={uf}"]
+    best_cli = None
+    for _ in range(2):
+        r = subprocess.run([CLI] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+        assert "Number of partitions: 8" in r.stdout
+        el = [int(l.split(":")[1]) for l in r.stdout.splitlines() if l.startswith("Elapsed wall clock time")]
+        assert len(el) == 2
+        best_cli = el[1] if best_cli is None else min(best_cli, el[1])
+    best_py = None
+    for _ in range(2):
+        pp = pkg.PPPCSR(n, numDomain=1, partitionsPerDomain=8)
+        pp.apply(core)
+        t0 = time.perf_counter()
+        pp.apply(upd)
+        ms = (time.perf_counter() - t0) * 1e3
+        best_py = ms if best_py is None else min(best_py, ms)
+        pp.close()
+    print(f"cli phase 2: {best_cli} ms, pppcsr_apply_batch from python: {best_py:.1f} ms")
+    assert best_cli <= 1.3 * best_py + 3.0, (best_cli, best_py)  # (+3: the CLI reports whole milliseconds)
 
 
 def _write_edges(path, ops, third_col):
