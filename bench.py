@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — edge-updates/s of the MI355X PMA engine on BASELINE.json's workloads.
 
-One "step" = one pass of the hot path over one batch of synthetic updates already resident in HBM:
-  N = 1 : config #2 — RMAT scale-20 core graph (10 M edges, a/b/c = .57/.19/.19), single partition,
-          each step applies a fresh batch of 1 M RMAT inserts (or --mixed: config #3, 50/50 insert +
-          delete of existing core edges) in stream order.
-  N > 1 : configs #4/#5 shape, weak scaling — N * 2^20 vertices, N * 10 M core edges, N * 1 M updates per
-          step; every rank owns one vertex-range partition (PPPCSR.cpp:13-34 rule), holds a contiguous
-          block of the global stream, buckets it by owner (stable) and exchanges buckets with one RCCL
-          all-to-all; the receiver concatenates in source-rank order == global stream order.
+One "step" = one pass of the hot path over one batch of synthetic updates already resident in HBM (every step starts
+from the same core graph: the device-to-device restore of the core snapshot is part of the step and inside the timed
+region).  `--config` picks the BASELINE.json configuration; the default is #2 on one GPU and #4 on several:
+
+  #2  RMAT scale-20 core (10 M edges, a/b/c = .57/.19/.19), one partition, 1 M fresh RMAT inserts per step
+  #3  same core, 1 M mixed updates per step: inserts alternating with deletes of existing core edges
+  #4  n = 10 000 000 vertices (scale-24 RMAT ids folded % n), 100 M-edge core, 10 M inserts per step, P = 8 vertex-range
+      partitions (partitionSize = 1 250 000, PPPCSR.cpp:20-29).  STRONG scaling: the same graph and the same stream on
+      1, 2, 4 or 8 ranks, rank r holding partitions [r * 8/N, (r + 1) * 8/N) (the reference's partitions_per_domain);
+      every rank holds a contiguous block of the global stream, buckets it by owner (stable) and swaps buckets with ONE
+      all-to-all (RCCL over xGMI); received buckets are concatenated in source-rank order == global stream order.
+      Headline: labels permuted by v -> v * 2654435761 mod n (balanced partitions); `raw_labels` beside it (44 % of the
+      edges in partition 0: the skew bounds the speed-up exactly as in the reference).
+  #5  the config #4 graph, 10 M updates per step whose sources follow Zipf(1.2) (hot-vertex rebalance cascades)
+
 Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
-Prints ONE JSON line on rank 0 (see DESIGN.md §6 for the field definitions).
+Prints ONE JSON line on rank 0 (DESIGN.md section 6 defines the fields).  Unless --no-check, the state of the timed
+engines is compared slot by slot with the reference / oracle after the timed region (`parity_checked`).
 """
 import argparse
-import ctypes
 import importlib.util
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -38,28 +46,65 @@ def _load(name, path, pkg=False):
 
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+T_BENCH0 = time.time()
 
 
 def log(rank, *a):
     if rank == 0:
-        print("[bench]", *a, file=sys.stderr, flush=True)
+        print(f"[bench +{time.time() - T_BENCH0:5.1f}s]", *a, file=sys.stderr, flush=True)
 
 
-def gen_block(streams, kind, scale, count, seed, offset, n_global, permute, core=None, mixed_seed=0):
-    """counter-based block [offset, offset+count) of the global stream `seed`"""
-    if kind == "zipf":  # config #5: hot-vertex stream, src = Zipf(1.2) rank, dst uniform, all ADD
-        s = streams.zipf_sources(n_global, count, seed=seed, alpha=1.2, offset=offset)
-        d = streams.uniform_ints(seed + 7, count, n_global, offset=offset)
-    else:
-        s, d = streams.rmat_edges(scale, count, seed=seed, offset=offset)
-    if permute:
-        s = streams.permute_labels(s, n_global)
-        d = streams.permute_labels(d, n_global)
-    ops = streams.adds(s, d)
-    if kind == "mixed":
-        half = count // 2
-        ops = streams.mixed_existing_stream(core, ops[:half], seed=mixed_seed)
-    return ops
+class Workload:
+    """the synthetic graph + update streams of one BASELINE config; element i of every stream depends on (seed, i) only,
+    so any rank can regenerate any block"""
+
+    def __init__(self, streams, cfg, n, scale, core_edges, batch, permute):
+        self.st, self.cfg, self.n, self.scale, self.core_edges, self.batch, self.permute = streams, cfg, n, scale, core_edges, batch, permute
+        self.folded = (1 << scale) != n
+
+    def _labels(self, s, d):
+        if self.permute:
+            s = self.st.permute_labels(s, self.n)
+            d = self.st.permute_labels(d, self.n)
+        return s, d
+
+    def _rmat(self, count, seed, offset):
+        if self.folded:
+            return self.st.rmat_edges_folded(self.n, self.scale, count, seed=seed, offset=offset)
+        return self.st.rmat_edges(self.scale, count, seed=seed, offset=offset)
+
+    def core(self, offset, count):
+        s, d = self._labels(*self._rmat(count, 1, offset))
+        return self.st.adds(s, d)
+
+    def updates(self, k, offset, count, core_for_mixed=None):
+        """block [offset, offset + count) of update batch k"""
+        if self.cfg == 5:  # src = Zipf(1.2) rank, dst uniform, all ADD
+            s = self.st.zipf_sources(self.n, count, seed=4 + 10 * k, alpha=1.2, offset=offset)
+            d = self.st.uniform_ints(11 + 10 * k, count, self.n, offset=offset)
+            s, d = self._labels(s, d)
+            return self.st.adds(s, d)
+        s, d = self._labels(*self._rmat(count, 2 + 10 * k, offset))
+        ops = self.st.adds(s, d)
+        if self.cfg == 3:
+            ops = self.st.mixed_existing_stream(core_for_mixed, ops[:count // 2], seed=3 + 10 * k)
+        return ops
+
+    def name(self, P, world):
+        lab = "permuted" if self.permute else "raw"
+        if self.cfg == 2:
+            w = f"config#2 {self.batch} random inserts on RMAT scale-{self.scale} / {self.core_edges}-edge core"
+        elif self.cfg == 3:
+            w = f"config#3 {self.batch} mixed 50/50 insert+delete on RMAT scale-{self.scale} / {self.core_edges}-edge core"
+        elif self.cfg == 4:
+            w = f"config#4 {self.batch} inserts on {self.n}-vertex / {self.core_edges}-edge RMAT (scale-{self.scale} ids % n)"
+        else:
+            w = f"config#5 {self.batch} Zipf(1.2)-source inserts on {self.n}-vertex / {self.core_edges}-edge RMAT (scale-{self.scale} ids % n)"
+        if P > 1:
+            w += f", {P} vertex-range partitions over {world} GPU(s), labels {lab}"
+        else:
+            w += f", 1 partition, labels {lab}"
+        return w
 
 
 def main():
@@ -67,22 +112,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scale", type=int, default=20, help="RMAT scale per GPU")
-    ap.add_argument("--core-edges", type=int, default=10_000_000, help="core edges per GPU")
-    ap.add_argument("--batch", type=int, default=1_000_000, help="updates per GPU per step")
-    ap.add_argument("--mixed", action="store_true", help="config #3: alternate insert / delete-existing")
-    ap.add_argument("--zipf", action="store_true", help="config #5: updates with Zipf(1.2) sources (hot-vertex rebalance cascades)")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.json config (default: 2 on one GPU, 4 on several)")
+    ap.add_argument("--mixed", action="store_true", help="= --config 3")
+    ap.add_argument("--zipf", action="store_true", help="config #5's stream shape on the config #2 graph (one GPU stress case)")
+    ap.add_argument("--scale", type=int, default=0, help="override the RMAT scale")
+    ap.add_argument("--vertices", type=int, default=0, help="override n (configs 4/5)")
+    ap.add_argument("--core-edges", type=int, default=0, help="override the core size (whole graph)")
+    ap.add_argument("--batch", type=int, default=0, help="override the updates per step (whole job)")
+    ap.add_argument("--parts", type=int, default=0, help="override the number of partitions (configs 4/5: 8)")
     ap.add_argument("--labels", choices=["permuted", "raw"], default=None)
+    ap.add_argument("--distinct-batches", type=int, default=4, help="update batches generated (steps cycle through them)")
+    ap.add_argument("--no-check", action="store_true", help="skip the slot-by-slot parity check after the timed region")
+    ap.add_argument("--check", action="store_true", help="(parity is checked by default; kept for compatibility)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ref-cli", action="store_true", help="skip the multi-threaded run of the reference's own CLI binary")
-    ap.add_argument("--no-profile", action="store_true", help="do not bracket round kernels with HIP events")
+    ap.add_argument("--no-ref-cli", action="store_true", help="skip the multi-threaded runs of the reference's own CLI binary")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event replay that yields the roofline block")
+    ap.add_argument("--no-secondary", action="store_true", help="skip scan / rebalance / consumers / raw-label / zipf legs")
     ap.add_argument("--mode", type=int, default=-1, help="0 strict prefix rounds, 1 speculative rounds (engine default)")
-    ap.add_argument("--opt-horizon", type=int, default=0)
-    ap.add_argument("--epoch-ops", type=int, default=0)
-    ap.add_argument("--region-slots", type=int, default=0)
-    ap.add_argument("--max-horizon", type=int, default=0)
-    ap.add_argument("--rounds-per-sync", type=int, default=0)
-    ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (slow)")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' only for functional tests of the N > 1 path on one GPU")
     args = ap.parse_args()
 
@@ -92,16 +139,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    P = args.gpus
-    if world != P:
-        raise SystemExit(f"--gpus {P} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {P}")
+    N = args.gpus
+    if world != N:
+        raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {N}")
     if not torch.cuda.is_available():
         raise SystemExit("no GPU: the engine is HIP-only (no CPU fallback)")
     ndev = torch.cuda.device_count()
     dev_id = local_rank % max(ndev, 1)  # (one rank per GPU in real runs; ranks share a GPU only in the gloo functional test)
     torch.cuda.set_device(dev_id)
     dev = torch.device("cuda", dev_id)
-    if P > 1:
+    if N > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
@@ -110,290 +157,419 @@ def main():
     exch = _load("ppcsr_exchange", os.path.join(ROOT, "parallel-packed-csr_amd", "exchange.py"))
     pkg.load_library()  # in-tree HIP build; raises if missing
 
-    gscale = args.scale + int(np.log2(P))
-    assert (1 << (gscale - args.scale)) == P, "--gpus must be a power of two"
-    n_global = 1 << gscale
-    permute = (args.labels or ("permuted" if P > 1 else "raw")) == "permuted"
+    cfg = args.config or (3 if args.mixed else (2 if N == 1 else 4))
+    if cfg in (2, 3):
+        # one partition per GPU; with N > 1 (only on request) the per-GPU work is fixed: weak scaling
+        scale = (args.scale or 20) + int(np.log2(N))
+        n_global = 1 << scale
+        core_edges = args.core_edges or 10_000_000 * N
+        batch = args.batch or 1_000_000 * N
+        P = args.parts or N
+        scaling = "weak"
+        permute = (args.labels or ("permuted" if P > 1 else "raw")) == "permuted"
+    else:
+        n_global = args.vertices or 10_000_000
+        scale = args.scale or 24
+        core_edges = args.core_edges or 100_000_000
+        batch = args.batch or 10_000_000
+        P = args.parts or 8
+        scaling = "strong"
+        permute = (args.labels or "permuted") == "permuted"
+    assert P % N == 0, "--gpus must divide the number of partitions"
+    ppr = P // N
+    wl = Workload(streams, 5 if args.zipf else cfg, n_global, scale, core_edges, batch, permute)
     starts, sizes = exch.partition_layout(n_global, P)
-    my_n = int(sizes[rank])
-    kind = "mixed" if args.mixed else ("zipf" if args.zipf else "insert")
-
-    t0 = time.time()
-    core_blk = gen_block(streams, "insert", gscale, args.core_edges, 1, rank * args.core_edges, n_global, permute)
-    nsteps = args.warmup + args.steps + (0 if args.no_profile else 0)
-    upd = []
-    for k in range(nsteps):
-        upd.append(gen_block(streams, kind, gscale, args.batch, 2 + 10 * k, rank * args.batch, n_global, permute,
-                             core=core_blk, mixed_seed=3 + 10 * k))
-    log(rank, f"generated core {len(core_blk)} + {nsteps} x {args.batch} updates per rank in {time.time() - t0:.1f}s "
-              f"(n_global={n_global}, labels={'permuted' if permute else 'raw'})")
-
-    eng = pkg.PCSR(my_n, device=dev_id)
-    if args.mode >= 0:
-        eng.set_option("mode", args.mode)
-    if args.opt_horizon:
-        eng.set_option("opt_horizon", args.opt_horizon)
-    if args.epoch_ops:
-        eng.set_option("epoch_ops", args.epoch_ops)
-    if args.region_slots:
-        eng.set_option("region_slots", args.region_slots)
-    if args.max_horizon:
-        eng.set_option("max_horizon", args.max_horizon)
-    if args.rounds_per_sync:
-        eng.set_option("rounds_per_sync", args.rounds_per_sync)
-
+    single = (P == 1)
     xdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the exchange runs
+    assert core_edges % N == 0 and batch % N == 0
+    my_core, my_batch = core_edges // N, batch // N
 
     def to_dev(a):
-        return torch.from_numpy(a.view(np.int32)).to(xdev if P > 1 else dev)
+        return torch.from_numpy(a.view(np.int32)).to(xdev if N > 1 else dev)
 
-    keep_alive = []  # device tensors handed to the engine must outlive the (asynchronous) apply
-
-    def run_step(ops_dev):
-        """bucket by owner + all-to-all (N > 1), then apply in stream order on this rank's partition"""
-        if P > 1:
-            mine = exch.exchange_ops(ops_dev, n_global, P, dist.group.WORLD).to(dev)
-            # the exchange ran on torch's stream; the engine applies on its own HIP stream
-            torch.cuda.current_stream().synchronize()
-            keep_alive.append(mine)
+    # ---- engines -------------------------------------------------------------------------------------------------
+    def make_engines():
+        if single:
+            e = pkg.PCSR(n_global, device=dev_id)
+            es = [e]
+            pp = None
         else:
-            mine = ops_dev
-        if mine.shape[0]:
-            eng.apply_device(mine.data_ptr(), mine.shape[0])
-        return mine.shape[0]
+            pp = pkg.PPPCSR(n_global, numDomain=N, partitionsPerDomain=ppr, local=(rank * ppr, ppr, dev_id))
+            es = [pp.partition(rank * ppr + q) for q in range(ppr)]
+        for e in es:
+            if args.mode >= 0:
+                e.set_option("mode", args.mode)
+            for kv in args.opt:
+                k, v = kv.split("=")
+                e.set_option(k, int(v))
+        return pp, es
 
-    # ---- core load (untimed) ----
-    t0 = time.time()
-    core_dev = to_dev(core_blk)
-    run_step(core_dev)
-    torch.cuda.synchronize()
-    del core_dev
-    st = eng.stats()
-    log(rank, f"core loaded in {time.time() - t0:.1f}s: N={st['N']} logN={st['logN']} rounds={st['rounds']} "
-              f"exclusive={st['exclusive_ops']} doubles={st['double_calls']} rollbacks={st['rollbacks']}")
+    def sum_stats(es):
+        tot = {}
+        for e in es:
+            for k, v in e.stats().items():
+                if k in ("N", "n", "logN", "H", "last_batch_ms", "last_batch_h2d_ms"):
+                    tot.setdefault(k, []).append(v)
+                else:
+                    tot[k] = tot.get(k, 0) + v
+        return tot
 
-    # every step starts from the SAME core graph (config #2/#3 exactly): the device-to-device restore of the
-    # core snapshot is part of the step and inside the timed region (2 x 12 B/slot of HBM traffic, ~0.1 ms)
-    eng.snapshot()
-    upd_dev = [to_dev(u) for u in upd]
-    for k in range(args.warmup):
-        eng.restore()
-        run_step(upd_dev[k])
-    torch.cuda.synchronize()
+    def run_step(pp, es, ops_dev):
+        """route (N > 1 or several partitions) + apply in stream order on this rank's partition(s)"""
+        if single:
+            if ops_dev.shape[0]:
+                es[0].apply_device(ops_dev.data_ptr(), ops_dev.shape[0])
+            return
+        if N == 1:
+            pp.apply_device(ops_dev.data_ptr(), ops_dev.shape[0])  # device bucketing + all partitions concurrently
+            return
+        parts, cnts = exch.exchange_parts(ops_dev, n_global, P, N, dist.group.WORLD)
+        parts = [t.to(dev) for t in parts]
+        torch.cuda.current_stream().synchronize()  # the exchange ran on torch's stream; the engines apply on their own
+        pp.apply_parts_device(rank * ppr, [t.data_ptr() for t in parts], cnts)
 
-    s0 = eng.stats()
-    if P > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    applied = 0
-    for k in range(args.warmup, args.warmup + args.steps):
-        eng.restore()
-        applied += run_step(upd_dev[k])
-    torch.cuda.synchronize()
-    if P > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    s1 = eng.stats()
-    if P > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    total_updates = args.batch * P * args.steps
-    value = total_updates / elapsed
-    dstat = {k: s1[k] - s0[k] for k in ("rounds", "committed", "planned", "exclusive_ops", "rollbacks", "round_syncs",
-                                         "redistribute_slots", "redistribute_calls", "ops_applied", "double_calls")}
-    dstat["updates_per_round"] = dstat["committed"] / max(dstat["rounds"], 1)
-    dstat["device_ms_last_batch"] = s1["last_batch_ms"]
-
-    # ---- roofline of the dominant round kernel ------------------------------------------------------------------
-    # HIP events recorded on the engine's own stream around every round kernel.  Recording ~5 events per round costs
-    # 25-35 % of throughput, so `value` above comes from the un-instrumented timed region and the SAME K steps are
-    # replayed here with the events on (same inputs, same state: every step restarts from the core snapshot).
-    roofline = None
-    if not args.no_profile:
-        eng.set_option("profile", 1)
-        p0 = eng.stats()
-        for k in range(args.warmup, args.warmup + args.steps):
-            eng.restore()
-            run_step(upd_dev[k])
+    def run_workload(wl_, label, steps, warmup, want_profile):
+        """core load (untimed), snapshot, warm-up, timed steps [, profiled replay]; returns a result dict"""
+        t0 = time.time()
+        core_blk = wl_.core(rank * my_core, my_core)
+        nb = max(1, min(args.distinct_batches, warmup + steps))
+        upd = [wl_.updates(k, rank * my_batch, my_batch, core_for_mixed=core_blk) for k in range(nb)]
+        log(rank, f"{label}: generated core {len(core_blk)} + {nb} x {len(upd[0])} updates per rank in {time.time() - t0:.1f}s "
+                  f"(n={wl_.n}, labels={'permuted' if wl_.permute else 'raw'})")
+        pp, es = make_engines()
+        t0 = time.time()
+        core_dev = to_dev(core_blk)
+        torch.cuda.synchronize()  # (the engines run on their own non-blocking streams)
+        run_step(pp, es, core_dev)
         torch.cuda.synchronize()
-        p1 = eng.stats()
-        eng.set_option("profile", 0)
-        launches = p1["prof_launches"]
-        kern = {"plan": p1["prof_plan_ms"], "check": p1["prof_check_ms"], "apply": p1["prof_apply_ms"],
-                "compact": p1["prof_compact_ms"]}
-        spec = args.mode != 0  # engine default: speculative rounds (o_* kernels; the compaction is folded into o_apply)
-        names = {"plan": "o_plan" if spec else "k_plan", "check": "o_check" if spec else "k_check",
-                 "apply": "o_apply" if spec else "k_apply", "compact": "o_compact"}
-        dom = max(kern, key=kern.get)
-        d = {k: p1[k] - p0[k] for k in ("redistribute_slots", "ops_applied", "committed", "rounds", "planned")}
-        # algorithmic bytes (SURVEY.md §8d): 12 B op record + 24 B per slot of every redistribute() the reference makes
-        alg_bytes = 12.0 * d["ops_applied"] + 24.0 * d["redistribute_slots"]
-        avg_ms = kern[dom] / max(launches, 1)
-        achieved = (alg_bytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc passes of this same command (offline)
-            try:
-                traffic = json.load(open(tpath)).get(names[dom], {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "launches": int(launches), "avg_launch_us": avg_ms * 1e3,
-                    "alg_bytes_per_launch": alg_bytes / max(launches, 1),
-                    "alg_bytes_per_update": alg_bytes / max(d["ops_applied"], 1),
-                    "kernel_ms": {names[k]: round(v, 3) for k, v in kern.items() if v > 0},
-                    "measured_on": "profiled replay of the timed steps (HIP events on the engine stream)"}
+        del core_dev
+        st = sum_stats(es)
+        log(rank, f"{label}: core loaded in {time.time() - t0:.1f}s: N={st['N']} logN={st['logN']} rounds={st['rounds']} "
+                  f"exclusive={st['exclusive_ops']} doubles={st['double_calls']} rollbacks={st['rollbacks']}")
+        for e in es:
+            e.snapshot()
+        upd_dev = [to_dev(u) for u in upd]
+        torch.cuda.synchronize()
 
-    # ---- CPU baseline beside it (rank 0, N == 1): the reference (oracle/_ref) or the oracle port, 1 thread ----
-    cpu = None
-    extra = {}
-    if rank == 0 and P == 1 and not args.no_cpu_baseline:
+        def step(k):
+            for e in es:
+                e.restore()
+            run_step(pp, es, upd_dev[k % nb])
+
+        for k in range(warmup):
+            step(k)
+        torch.cuda.synchronize()
+        s0 = sum_stats(es)
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for k in range(warmup, warmup + steps):
+            step(k)
+        torch.cuda.synchronize()
+        if N > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t_start
+        s1 = sum_stats(es)
+        if N > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        total_updates = len(upd[0]) * N * steps
+        keys = ("rounds", "committed", "planned", "exclusive_ops", "rollbacks", "round_syncs", "redistribute_slots",
+                "redistribute_calls", "ops_applied", "double_calls", "wasted_rounds")
+        dstat = {k: s1[k] - s0[k] for k in keys if k in s1}
+        dstat["updates_per_round"] = dstat["committed"] / max(dstat["rounds"], 1)
+        dstat["replan_factor"] = dstat["planned"] / max(dstat["committed"], 1)
+        dstat["device_ms_last_batch"] = max(s1["last_batch_ms"])
+        res = {"value": total_updates / elapsed, "ms_per_step": elapsed / steps * 1e3, "engine": dstat,
+               "N_slots": [int(x) for x in s1["N"]], "logN": int(s1["logN"][0]), "last_k": (warmup + steps - 1) % nb,
+               "core_blk": core_blk, "upd": upd, "es": es, "pp": pp, "step": step}
+        # ---- roofline of the dominant round kernel: HIP events on the engines' own streams around every round kernel.
+        # Recording ~5 events per round costs 25-35 % of throughput, so `value` comes from the un-instrumented timed
+        # region and the SAME steps are replayed here with the events on (same inputs, same state).
+        if want_profile:
+            for e in es:
+                e.set_option("profile", 1)
+            p0 = sum_stats(es)
+            for k in range(warmup, warmup + steps):
+                step(k)
+            torch.cuda.synchronize()
+            p1 = sum_stats(es)
+            for e in es:
+                e.set_option("profile", 0)
+            launches = p1["prof_launches"]
+            kern = {"plan": p1["prof_plan_ms"], "check": p1["prof_check_ms"], "apply": p1["prof_apply_ms"], "compact": p1["prof_compact_ms"]}
+            spec = args.mode != 0
+            names = {"plan": "o_plan" if spec else "k_plan", "check": "o_check" if spec else "k_check",
+                     "apply": "o_apply" if spec else "k_apply", "compact": "o_compact"}
+            dom = max(kern, key=kern.get)
+            d = {k: p1[k] - p0[k] for k in ("redistribute_slots", "ops_applied")}
+            # algorithmic bytes (SURVEY.md section 8d): 12 B op record + 24 B per slot of every redistribute() the reference makes
+            alg_bytes = 12.0 * d["ops_applied"] + 24.0 * d["redistribute_slots"]
+            avg_ms = kern[dom] / max(launches, 1)
+            achieved = (alg_bytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            traffic, tsrc = None, None
+            tpath = os.path.join(ROOT, "profiles", "r02_roofline.json")
+            if cfg == 2 and N == 1 and os.path.exists(tpath):
+                # HBM bytes per launch of the timed rounds, from the committed rocprofv3 --pmc passes of THIS command
+                # (tools/roofline_profile.sh); tagged with the commit it was measured at
+                try:
+                    pj = json.load(open(tpath))
+                    traffic = pj["timed_rounds"][names[dom]]["hbm_bytes_per_launch"]
+                    tsrc = {"file": "profiles/r02_roofline.json", "commit": pj.get("commit"), "command": pj.get("command")}
+                except Exception:
+                    traffic = None
+            res["roofline"] = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                               "launches": int(launches), "avg_launch_us": avg_ms * 1e3,
+                               "alg_bytes_per_launch": alg_bytes / max(launches, 1),
+                               "alg_bytes_per_update": alg_bytes / max(d["ops_applied"], 1),
+                               "kernel_ms": {names[k]: round(v, 3) for k, v in kern.items() if v > 0},
+                               "measured_on": "profiled replay of the timed steps (HIP events on the engine stream)"
+                                              + ("" if len(es) == 1 else f", summed over this rank's {len(es)} partitions")}
+            # leave the engines in the state of the last timed step for the parity check
+        return res
+
+    def expected_subsequences(wl_, kinds):
+        """this rank's partitions' subsequences of the GLOBAL stream, regenerated from the counters block by block and
+        routed with numpy (PPPCSR.cpp:46-66) — independent of the device bucketing and of the exchange.
+        kinds: list of ('core',) / ('upd', k)"""
+        ps = n_global // P
+        out = [[] for _ in range(ppr)]
+        for kind in kinds:
+            for r in range(N):
+                if kind[0] == "core":
+                    g = wl_.core(r * my_core, my_core)
+                else:
+                    cb = wl_.core(r * my_core, my_core) if wl_.cfg == 3 else None
+                    g = wl_.updates(kind[1], r * my_batch, my_batch, core_for_mixed=cb)
+                own = np.minimum(g[:, 0].astype(np.int64) // ps, P - 1) if P > 1 else np.zeros(len(g), np.int64)
+                for q in range(ppr):
+                    part = rank * ppr + q
+                    sub = g[own == part].copy()
+                    sub[:, 0] -= np.uint32(starts[part])
+                    out[q].append(sub)
+        return [np.concatenate(x) for x in out]
+
+    def parity_check(wl_, res):
+        """every resident partition against the reference (N == 1, one partition, oracle/_ref built) or the oracle, fed with
+        the partition's subsequence of core + the last timed batch; host threads (ctypes releases the GIL)"""
         from oracle_lib import Oracle, RefPCSR, have_ref
+        if N == 1 and single:
+            seqs = [np.concatenate([res["core_blk"], res["upd"][res["last_k"]]])]
+        else:
+            seqs = expected_subsequences(wl_, [("core",), ("upd", res["last_k"])])
+        use_ref = have_ref() and single
+        oks = [False] * ppr
+        secs = [0.0] * ppr
+
+        def one(q):
+            part = rank * ppr + q
+            o = (RefPCSR if use_ref else Oracle)(int(sizes[part]))
+            t0 = time.time()
+            o.apply(seqs[q])
+            secs[q] = time.time() - t0
+            e = res["es"][q]
+            ei, en = e.state()
+            oi, on = o.state()
+            oks[q] = tuple(e.geometry()) == tuple(o.geometry()) and np.array_equal(ei, oi) and np.array_equal(en, on)
+            o.close()
+        th = [threading.Thread(target=one, args=(q,)) for q in range(ppr)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        ok = all(oks)
+        if N > 1:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=xdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(t.item())
+        return ok, ("reference (oracle/_ref)" if use_ref else "oracle"), max(secs), sum(len(s) for s in seqs)
+
+    # ================================================ headline ====================================================
+    res = run_workload(wl, f"config#{wl.cfg}", args.steps, args.warmup, not args.no_profile)
+    extra = {}
+    if not args.no_check:
+        t0 = time.time()
+        ok, against, osecs, nops = parity_check(wl, res)
+        log(rank, f"parity vs {against}: {'bit-exact' if ok else 'MISMATCH'} ({nops} updates replayed per rank, {osecs:.1f}s, total {time.time() - t0:.1f}s)")
+        extra["parity_checked"] = ok
+        extra["parity"] = {"against": against, "what": "N/logN/H + every slot of edges[] + every nodes[] triple of every partition, after core + the last timed batch",
+                           "cpu_updates_per_s_one_thread": nops / max(osecs, 1e-9) / max(ppr, 1)}
+        if not ok:
+            raise SystemExit("PARITY FAILURE: engine state differs from the " + against)
+
+    # ---- CPU baseline beside it (rank 0, N == 1): the reference's own CLI binary with its thread pools on this box's cores
+    cpu = None
+    if rank == 0 and N == 1 and not args.no_cpu_baseline:
+        from oracle_lib import Oracle, RefPCSR, have_ref
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            cores = os.cpu_count() or 1
         kindc = "reference" if have_ref() else "port"
         Cls = RefPCSR if have_ref() else Oracle
-        c = Cls(my_n)
+        part0 = 0
+        # bounded sample: ONE partition's subsequence (the reference's partitions are independent PCSRs), sequential order
+        if single:
+            seq_core, seq_upd = res["core_blk"], res["upd"][0]
+        else:
+            sq = expected_subsequences(wl, [("core",)])[part0], expected_subsequences(wl, [("upd", 0)])[part0]
+            seq_core, seq_upd = sq
+        c = Cls(int(sizes[part0]))
         tl = time.time()
-        c.apply(core_blk)
+        c.apply(seq_core)
         tl = time.time() - tl
         tc = time.time()
-        c.apply(upd[args.warmup])
+        c.apply(seq_upd)
         tc = time.time() - tc
-        cpu = {"value": len(upd[args.warmup]) / tc, "unit": "edge-updates/s", "cores": 1, "kind": kindc,
-               "sample": f"same {args.core_edges}-edge core ({tl:.1f}s load, untimed) + the first timed batch of "
-                         f"{len(upd[args.warmup])} updates in stream order on one host thread ({tc:.2f}s)"}
-        if args.check:
-            c2 = Oracle(my_n)
-            c2.apply(core_blk)
-            c2.apply(upd[args.warmup + args.steps - 1])  # the engine holds core + the last timed batch
-            ei, en = eng.state()
-            oi, on = c2.state()
-            assert eng.geometry() == c2.geometry() and np.array_equal(ei, oi) and np.array_equal(en, on), "PARITY FAILURE"
-            extra["parity_checked"] = True
         c.close()
-        # the reference's own binary with its thread pools (the north_star's "-pppcsrnuma CPU path on the same box"):
-        # text edge lists in /tmp, phase-2 time = the SECOND "Elapsed wall clock time" line (reference bench protocol)
+        one_thread = len(seq_upd) / tc
+        cpu = {"value": one_thread, "unit": "edge-updates/s", "cores": 1, "kind": kindc,
+               "sample": (f"{'partition 0 of ' + str(P) + ': ' if not single else ''}{len(seq_core)}-edge core ({tl:.1f}s load, untimed) + "
+                          f"one batch of {len(seq_upd)} updates in stream order on one host thread ({tc:.2f}s) — the sequential order is "
+                          "the parity semantics"),
+               "cores_visible": cores}
         ref_cli = os.path.join(ROOT, "oracle", "_ref", "ref_cli")
-        if os.path.exists(ref_cli) and not args.no_ref_cli and not args.mixed:
+        if os.path.exists(ref_cli) and not args.no_ref_cli and cfg == 2:
+            # the north_star's comparison: the reference's -pppcsrnuma path on the same box's host cores.  Text edge lists in
+            # /tmp; phase-2 time = the SECOND "Elapsed wall clock time" line (benchmark-strong-scaling.sh:114-126); 3
+            # repetitions here, the full protocol (thread sweep, 5 repetitions) is tools/cpu_baseline_protocol.py ->
+            # profiles/r02_cpu_baseline.json
             try:
                 import subprocess
                 import pandas as pd
-                cores = os.cpu_count() or 1
-                try:
-                    cores = len(os.sched_getaffinity(0))
-                except Exception:
-                    pass
                 cf, uf = "/tmp/ppcsr_bench_core.txt", "/tmp/ppcsr_bench_upd.txt"
-                pd.DataFrame(core_blk[:, :2]).to_csv(cf, sep=" ", header=False, index=False)
-                pd.DataFrame(upd[args.warmup][:, :2]).to_csv(uf, sep=" ", header=False, index=False)
-                runs = {}
+                pd.DataFrame(res["core_blk"][:, :2]).to_csv(cf, sep=" ", header=False, index=False)
+                pd.DataFrame(res["upd"][0][:, :2]).to_csv(uf, sep=" ", header=False, index=False)
                 share = min(cores, 16)  # the box's CPU share for one GPU
-                for label, thr, flags in (("ppcsr_t8", 8, ["-ppcsr"]), (f"ppcsr_t{share}", share, ["-ppcsr"]),
-                                          (f"pppcsrnuma_t{share}", share, ["-pppcsrnuma", "-partitions_per_domain=8"])):
-                    r = subprocess.run([ref_cli, f"-threads={thr}", f"-size={args.batch}", "-insert"] + flags +
-                                       [f"-core_graph={cf}", f"-update_file={uf}"], capture_output=True, text=True, timeout=600)
-                    el = [int(l.split(":")[1]) for l in r.stdout.splitlines() if l.startswith("Elapsed wall clock time")]
-                    if len(el) >= 2 and el[1] > 0:
-                        runs[label] = {"updates_per_s": args.batch / (el[1] * 1e-3), "ms": el[1], "core_load_ms": el[0], "threads": thr}
-                    else:
-                        runs[label] = {"failed": r.returncode, "stderr": r.stderr[-200:], "stdout_tail": r.stdout[-200:]}
-                extra["cpu_reference_cli"] = {"cores_visible": cores, "runs": runs,
-                                              "note": "unmodified reference binary (oracle/_ref/ref_cli); multi-threaded runs are "
-                                                      "not deterministic in layout (SURVEY.md §8c)"}
+                runs = {}
+                for label, thr, flags in ((f"pppcsrnuma_t{share}", share, ["-pppcsrnuma", "-partitions_per_domain=8"]),
+                                          (f"ppcsr_t{share}", share, ["-ppcsr"])):
+                    vals = []
+                    for _ in range(3):
+                        r = subprocess.run([ref_cli, f"-threads={thr}", f"-size={len(res['upd'][0])}", "-insert"] + flags +
+                                           [f"-core_graph={cf}", f"-update_file={uf}"], capture_output=True, text=True, timeout=600)
+                        el = [int(l.split(":")[1]) for l in r.stdout.splitlines() if l.startswith("Elapsed wall clock time")]
+                        if len(el) >= 2 and el[1] > 0:
+                            vals.append(len(res["upd"][0]) / (el[1] * 1e-3))
+                    if vals:
+                        runs[label] = {"updates_per_s_mean": float(np.mean(vals)), "updates_per_s_std": float(np.std(vals, ddof=1)) if len(vals) > 1 else 0.0,
+                                       "repetitions": len(vals), "threads": thr}
                 os.remove(cf)
                 os.remove(uf)
+                if runs:
+                    best = max(runs, key=lambda k: runs[k]["updates_per_s_mean"])
+                    cpu["multi_thread"] = {"best": best, "runs": runs,
+                                           "note": "unmodified reference binary (oracle/_ref/ref_cli); multi-threaded runs are not "
+                                                   "deterministic in layout (SURVEY.md section 8c); full sweep: profiles/r02_cpu_baseline.json"}
+                    # the reported baseline is the reference's best figure on this box's cores
+                    cpu["value"] = runs[best]["updates_per_s_mean"]
+                    cpu["cores"] = runs[best]["threads"]
+                    cpu["one_thread_sequential"] = one_thread
+                    cpu["sample"] = (f"reference CLI {best.split('_')[0]} -threads={runs[best]['threads']}, same {len(res['core_blk'])}-edge core (phase 1, "
+                                     f"untimed) + the first batch of {len(res['upd'][0])} updates (phase 2), mean of {runs[best]['repetitions']} runs")
             except Exception as e:
-                extra["cpu_reference_cli_error"] = str(e)
+                cpu["multi_thread_error"] = str(e)
 
-    if P > 1 and args.check:
-        # tier-A parity per partition: this rank's partition must equal the oracle fed with the partition's subsequence
-        # of the GLOBAL stream (block r of every batch is regenerated from its counters)
-        from oracle_lib import Oracle
-        o = Oracle(my_n)
-
-        def mine_of(kind_, count, seed, mixed_seed=0, corefor=None):
-            parts = []
-            for r in range(P):
-                cb = None
-                if kind_ == "mixed":
-                    cb = gen_block(streams, "insert", gscale, args.core_edges, 1, r * args.core_edges, n_global, permute)
-                parts.append(gen_block(streams, kind_, gscale, count, seed, r * count, n_global, permute, core=cb, mixed_seed=mixed_seed))
-            g = np.concatenate(parts)
-            ps = n_global // P
-            own = np.minimum(g[:, 0].astype(np.int64) // ps, P - 1)
-            sub = g[own == rank].copy()
-            sub[:, 0] -= np.uint32(starts[rank])
-            return sub
-        o.apply(mine_of("insert", args.core_edges, 1))
-        k = args.warmup + args.steps - 1
-        o.apply(mine_of(kind, args.batch, 2 + 10 * k, mixed_seed=3 + 10 * k))
-        ei, en = eng.state()
-        oi, on = o.state()
-        okp = eng.geometry() == o.geometry() and np.array_equal(ei, oi) and np.array_equal(en, on)
-        t = torch.tensor([1 if okp else 0], dtype=torch.int64, device=xdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        extra["parity_checked_all_partitions"] = bool(t.item())
-        assert t.item() == 1, "PARITY FAILURE on some partition"
-    # ---- secondary kernels: bulk neighbour scan + whole-window rebalance (HBM-roofline kernels, SURVEY §8d) ----
-    if rank == 0:
+    # ================================================ secondary legs ===============================================
+    es = res["es"]
+    if rank == 0 and not args.no_secondary:
         try:
+            eng = es[0]
             ms, tot = eng.bench_scan_all()
             ms, tot = eng.bench_scan_all()
             stt = eng.stats()
             scan_bytes = 12.0 * stt["N"] + 12.0 * stt["n"] + 4.0 * tot
             extra["neighbour_scan"] = {"edges_per_s": tot / (ms * 1e-3), "ms": ms, "edges": int(tot),
                                        "alg_GBps": scan_bytes / (ms * 1e-3) / 1e9,
-                                       "frac_of_peak": scan_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            # graph-algorithm consumers on the device (SURVEY §8f.3): BFS from vertex 0, one PageRank push
-            nv = int(stt["n"])
-            lv, bms = eng.bfs(0, with_ms=True)
-            lv, bms = eng.bfs(0, with_ms=True)
-            reached = int((lv != 0xFFFFFFFF).sum())
-            pr, pms = eng.pagerank(np.ones(nv, np.float32), with_ms=True)
-            pr, pms = eng.pagerank(np.ones(nv, np.float32), with_ms=True)
-            extra["consumers"] = {"bfs_ms": bms, "bfs_levels": int(lv[lv != 0xFFFFFFFF].max()), "bfs_reached": reached,
-                                  "bfs_edges_per_s": tot / (bms * 1e-3), "pagerank_ms": pms,
-                                  "pagerank_edges_per_s": tot / (pms * 1e-3),
-                                  "note": "device time; pagerank = bulk scan + stable radix sort by dest + in-order "
-                                          "segment sums (bit-identical to the reference's fp32 loop)"}
-            # non-parity bulk build of the same core graph on a fresh engine (SURVEY §8f.2) beside the parity load above
-            if P == 1:
-                eb = pkg.PCSR(my_n, device=dev_id)
-                tb0 = time.perf_counter()
-                bb_ms = eb.bulk_build(core_blk, with_ms=True)
-                tb1 = time.perf_counter()
-                extra["bulk_build"] = {"edges": int(len(core_blk)), "device_ms": bb_ms, "wall_ms_incl_h2d": (tb1 - tb0) * 1e3,
-                                       "edges_per_s_device": len(core_blk) / (bb_ms * 1e-3), "N_slots": int(eb.geometry()[0]),
-                                       "note": "NOT layout-identical to the one-by-one build (history dependent); same edge "
-                                               "set, values, num_neighbors and invariants"}
-                eb.close()
+                                       "frac_of_peak": scan_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "partition": 0 if not single else None}
             for label, w in (("window_rebalance", int(stt["N"])), ("window_rebalance_half", int(stt["N"]) // 2)):
                 rms = eng.bench_rebalance(w, 5)
                 extra[label] = {"window_slots": w, "ms_per_call": rms, "alg_GBps": 24.0 * w / (rms * 1e-3) / 1e9,
                                 "frac_of_peak": 24.0 * w / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "note": "device time (HIP events) of rank scan + position table + fused scatter/fill"
-                                        + ("" if w == int(stt["N"]) else " + copy-back")}
+                                "note": "device time (HIP events) of tile sums + position table + fused scatter/fill"}
+            if single:
+                # graph-algorithm consumers on the device (SURVEY section 8f.3): BFS from vertex 0, one PageRank push
+                nv = int(stt["n"])
+                lv, bms = eng.bfs(0, with_ms=True)
+                lv, bms = eng.bfs(0, with_ms=True)
+                reached = int((lv != 0xFFFFFFFF).sum())
+                pr, pms = eng.pagerank(np.ones(nv, np.float32), with_ms=True)
+                pr, pms = eng.pagerank(np.ones(nv, np.float32), with_ms=True)
+                extra["consumers"] = {"bfs_ms": bms, "bfs_levels": int(lv[lv != 0xFFFFFFFF].max()), "bfs_reached": reached,
+                                      "bfs_edges_per_s": tot / (bms * 1e-3), "pagerank_ms": pms,
+                                      "pagerank_edges_per_s": tot / (pms * 1e-3),
+                                      "note": "device time; pagerank = bulk scan + stable radix sort by dest (rocPRIM, a library op) + "
+                                              "in-order segment sums (bit-identical to the reference's fp32 loop; the adds into one "
+                                              "destination are sequential by definition)"}
+                # non-parity bulk build of the same core graph on a fresh engine (SURVEY section 8f.2)
+                eb = pkg.PCSR(n_global, device=dev_id)
+                tb0 = time.perf_counter()
+                bb_ms = eb.bulk_build(res["core_blk"], with_ms=True)
+                tb1 = time.perf_counter()
+                extra["bulk_build"] = {"edges": int(len(res["core_blk"])), "device_ms": bb_ms, "wall_ms_incl_h2d": (tb1 - tb0) * 1e3,
+                                       "edges_per_s_device": len(res["core_blk"]) / (bb_ms * 1e-3), "N_slots": int(eb.geometry()[0]),
+                                       "note": "NOT layout-identical to the one-by-one build (history dependent); same edge "
+                                               "set, values, num_neighbors and invariants"}
+                eb.close()
         except Exception as e:  # never let a secondary measurement kill the headline
             extra["secondary_error"] = str(e)
+    # release the headline engines before further workloads are built
+    headline = {k: res[k] for k in ("value", "ms_per_step", "engine", "N_slots", "logN")}
+    roofline = res.get("roofline")
+    for e in es:
+        e.close() if single else None
+    if res["pp"] is not None:
+        res["pp"].close()
+    res = None
+
+    def side_leg(key, wl_, steps, warmup, check):
+        try:
+            r = run_workload(wl_, key, steps, warmup, False)
+            out = {"workload": wl_.name(P, N), "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": steps, "engine": r["engine"]}
+            if check and not args.no_check:
+                ok, against, osecs, nops = parity_check(wl_, r)
+                out["parity_checked"] = ok
+                if not ok:
+                    raise SystemExit(f"PARITY FAILURE in {key}")
+            for e in r["es"]:
+                e.close() if single else None
+            if r["pp"] is not None:
+                r["pp"].close()
+            extra[key] = out
+        except SystemExit:
+            raise
+        except Exception as e:
+            extra[key + "_error"] = str(e)
+
+    if not args.no_secondary and cfg == 4 and not args.zipf:
+        # the same graph with raw labels (the faithful input: partition 0 holds 44 % of the edges), and config #5's stream
+        if permute:
+            side_leg("raw_labels", Workload(streams, 4, n_global, scale, core_edges, batch, False), max(1, min(args.steps, 2)), 1, False)
+        side_leg("config5_zipf", Workload(streams, 5, n_global, scale, core_edges, batch, permute), 1, 1, True)
+    if not args.no_secondary and cfg == 2 and N == 1 and not args.zipf:
+        # config #3 and the config #5 stream shape on this one-GPU graph
+        side_leg("config3_mixed", Workload(streams, 3, n_global, scale, core_edges, batch, permute), max(1, min(args.steps, 3)), 1, True)
+        side_leg("config5_shape_zipf", Workload(streams, 5, n_global, scale, core_edges, batch, permute), max(1, min(args.steps, 2)), 1, True)
 
     if rank == 0:
         out = {
-            "metric": "edge-updates/sec", "value": value, "unit": "edge-updates/s", "n_gpus": P, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": (f"config#3 {args.batch} mixed 50/50 insert+delete" if args.mixed else
-                                    (f"config#5 {args.batch} Zipf(1.2)-source inserts" if args.zipf else f"config#2 {args.batch} random inserts"))
-                       + f" on RMAT scale-{args.scale} / {args.core_edges}-edge core per GPU"
-                       + (f", {P} vertex-range partitions, labels {'permuted' if permute else 'raw'}, {'RCCL' if args.backend == 'nccl' else args.backend} all-to-all" if P > 1 else ", 1 partition"),
-                       "vertices": n_global, "core_edges": args.core_edges * P, "updates_per_step": args.batch * P,
-                       "parallelism": f"partition-per-gpu x{P}", "N_slots": int(s1["N"]), "logN": int(s1["logN"]),
+            "metric": "edge-updates/sec", "value": headline["value"], "unit": "edge-updates/s", "n_gpus": N, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": headline["ms_per_step"], "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": wl.name(P, N), "vertices": n_global, "core_edges": core_edges, "updates_per_step": batch,
+                       "parallelism": f"{P} partition(s), {ppr} per GPU x {N} GPU(s)"
+                                      + ("" if N == 1 else f", {'RCCL' if args.backend == 'nccl' else args.backend} all-to-all"),
+                       "N_slots": headline["N_slots"], "logN": headline["logN"],
+                       "distinct_update_batches": max(1, min(args.distinct_batches, args.warmup + args.steps)),
                        "semantics": "sequential stream order (bit-exact vs reference -threads=1)"},
-            "roofline": roofline, "cpu_baseline": cpu, "engine": dstat, **extra,
+            "roofline": roofline, "cpu_baseline": cpu, "engine": headline["engine"], **extra,
         }
         print(json.dumps(out), flush=True)
-    if P > 1:
+    if N > 1:
         dist.barrier()
         dist.destroy_process_group()
 

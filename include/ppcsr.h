@@ -57,6 +57,7 @@ typedef struct {
   /* option "profile"=1: HIP-event time spent in each round kernel, measured on the engine's own stream */
   double prof_plan_ms, prof_check_ms, prof_apply_ms, prof_compact_ms;
   uint64_t prof_launches; /* launches of each of the three round kernels */
+  uint64_t wasted_rounds; /* rounds of speculative epochs that were rolled back (not counted in `rounds`) */
 } ppcsr_stats_t;
 
 /* PCSR::PCSR(init_n, src_n, lock_search, domain)  — PCSR.cpp:775-838; `device` replaces the NUMA domain */

@@ -490,6 +490,18 @@ po_pcsr *po_create(uint32_t init_n, uint32_t src_n, int lock_search) {
   return p;
 }
 
+/* test convenience (no reference equivalent): an independent copy of the whole state, so that several update batches can
+ * be replayed from one loaded core graph */
+po_pcsr *po_clone(const po_pcsr *p) {
+  po_pcsr *q = (po_pcsr *)malloc(sizeof(po_pcsr));
+  *q = *p;
+  q->items = (po_edge *)malloc(p->N * sizeof(po_edge));
+  memcpy(q->items, p->items, p->N * sizeof(po_edge));
+  q->nodes = (po_node *)calloc(p->ncap, sizeof(po_node));
+  memcpy(q->nodes, p->nodes, p->n * sizeof(po_node));
+  return q;
+}
+
 void po_destroy(po_pcsr *p) {
   if (!p) return;
   free(p->items);

@@ -41,6 +41,7 @@ typedef struct {
 typedef struct po_pcsr po_pcsr;
 
 po_pcsr *po_create(uint32_t init_n, uint32_t src_n, int lock_search);
+po_pcsr *po_clone(const po_pcsr *p); /* test convenience: independent copy of the state */
 void po_destroy(po_pcsr *p);
 void po_add_edge(po_pcsr *p, uint32_t src, uint32_t dest, uint32_t value);
 void po_remove_edge(po_pcsr *p, uint32_t src, uint32_t dest);

@@ -29,7 +29,8 @@ class Stats(ctypes.Structure):
                 ("double_calls", c_u64), ("half_calls", c_u64), ("big_redistributes", c_u64), ("rollbacks", c_u64),
                 ("not_found", c_u64), ("duplicates", c_u64), ("noops", c_u64), ("slide_slots", c_u64),
                 ("ops_applied", c_u64), ("last_batch_ms", c_dbl), ("last_batch_h2d_ms", c_dbl),
-                ("prof_plan_ms", c_dbl), ("prof_check_ms", c_dbl), ("prof_apply_ms", c_dbl), ("prof_compact_ms", c_dbl), ("prof_launches", c_u64)]
+                ("prof_plan_ms", c_dbl), ("prof_check_ms", c_dbl), ("prof_apply_ms", c_dbl), ("prof_compact_ms", c_dbl), ("prof_launches", c_u64),
+                ("wasted_rounds", c_u64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -146,6 +146,7 @@ int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out) {
   out->ops_applied = s.ops_applied; out->last_batch_ms = s.last_batch_ms; out->last_batch_h2d_ms = s.last_batch_h2d_ms;
   out->prof_plan_ms = s.prof_plan_ms; out->prof_check_ms = s.prof_check_ms; out->prof_apply_ms = s.prof_apply_ms; out->prof_compact_ms = s.prof_compact_ms;
   out->prof_launches = s.prof_launches;
+  out->wasted_rounds = s.wasted_rounds;
   return 0;
 }
 int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value) { H_CHECK(); return ret(h->e, h->e->set_option(key, value)); }

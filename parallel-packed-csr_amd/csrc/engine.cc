@@ -743,7 +743,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
                   c.viol_info[1], c.viol_info[2], c.viol_info[3], c.viol_info[4], c.viol_info[5], c.viol_info[6], c.viol_info[7]);
         GCHK(snap_load(p, p.esnap));
         GCHK(gpu::d2d(p.d_stats, p.d_stats_snap, kStatShards * sizeof(StatShard), p.stream));
-        p.st.rounds += c.rounds;
+        p.st.wasted_rounds += c.rounds;  // (kept apart: `rounds` / `committed` / `planned` describe committed work only)
         const uint64_t cut = (uint64_t)c.viol_idx + 1;
         if (retries < 3 && c.viol_idx != kMax && cut > e0 && cut < e1) {
           retries++;

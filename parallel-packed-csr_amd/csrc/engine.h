@@ -26,6 +26,7 @@ struct EngineStats {
   // profile mode (option "profile"=1): HIP-event time of each round kernel on the engine's stream
   double prof_plan_ms, prof_check_ms, prof_apply_ms, prof_compact_ms;
   uint64_t prof_launches;  // launches of EACH of the three kernels
+  uint64_t wasted_rounds;  // rounds of speculative epochs that were rolled back (not part of `rounds`)
 };
 
 class Engine {

@@ -74,6 +74,59 @@ def bucket_ops_device(ops, init_n, n_parts):
     return out, counts
 
 
+def _bucket(ops, init_n, n_parts):
+    if ops.is_cuda and n_parts <= 64 and _hip_lib() is not None:
+        return bucket_ops_device(ops.contiguous(), init_n, n_parts)
+    return bucket_ops(ops, init_n, n_parts)
+
+
+def exchange_parts(ops, init_n, n_parts, world, group=None, cap=None):
+    """Strong-scaling form: `n_parts` partitions of the global layout over `world` ranks, rank r holding the contiguous
+    partitions [r * ppr, (r + 1) * ppr), ppr = n_parts / world (the reference's partitions_per_domain).  ONE collective per
+    batch and no host synchronisation before it: every rank sends every peer a fixed-capacity chunk
+        [header rows: the ppr bucket sizes | payload: the peer's ppr buckets, back to back | padding]
+    (capacity `cap`: the largest block any rank holds — the worst case; default: this rank's block size, which is right
+    whenever all ranks hold equal blocks, as bench.py's do), so the split sizes are static.  Returns (per-partition tensors in
+    stream order with partition-local src, counts) for this rank's partitions; the only host sync is the read of the
+    world x ppr received header words that the per-partition apply calls need anyway."""
+    assert n_parts % world == 0
+    ppr = n_parts // world
+    m = ops.shape[0]
+    cap = m if cap is None else cap
+    assert m <= cap
+    hrows = (ppr + 2) // 3
+    dev = ops.device
+    b, counts = _bucket(ops, init_n, n_parts)
+    counts = counts.to(torch.int64)
+    if world == 1:
+        cnt = counts.cpu().tolist()
+        offs = np.concatenate([[0], np.cumsum(cnt)])
+        return [b[int(offs[q]):int(offs[q + 1])] for q in range(n_parts)], cnt
+    rows = cap + hrows
+    send = torch.zeros((world, rows, 3), dtype=ops.dtype, device=dev)
+    hdr = torch.zeros((world, hrows * 3), dtype=ops.dtype, device=dev)
+    hdr[:, :ppr] = counts.view(world, ppr).to(ops.dtype)
+    send[:, :hrows, :] = hdr.view(world, hrows, 3)
+    if m:
+        offs = torch.cumsum(counts, 0) - counts                                             # first bucketed row of each partition
+        part_of = torch.repeat_interleave(torch.arange(n_parts, device=dev), counts, output_size=m)
+        peer = part_of // ppr
+        base = offs.index_select(0, peer * ppr)                                              # first row of the peer's buckets
+        row = peer * rows + hrows + (torch.arange(m, device=dev) - base)
+        send.view(-1, 3).index_copy_(0, row, b)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    got = recv[:, :hrows, :].reshape(world, hrows * 3)[:, :ppr].to(torch.int64).cpu().numpy()  # [source rank][local partition]
+    out, cnts = [], []
+    starts = np.concatenate([np.zeros((world, 1), np.int64), np.cumsum(got, 1)], 1)
+    for q in range(ppr):
+        segs = [recv[r, hrows + int(starts[r, q]): hrows + int(starts[r, q]) + int(got[r, q])] for r in range(world)]
+        t = torch.cat(segs) if world > 1 else segs[0]
+        out.append(t.contiguous())
+        cnts.append(int(got[:, q].sum()))
+    return out, cnts
+
+
 def exchange_ops(ops, init_n, n_parts, group=None):
     """all-to-all of owner buckets; returns this rank's partition subsequence (stream order, local src)"""
     if ops.is_cuda and n_parts <= 64 and _hip_lib() is not None:

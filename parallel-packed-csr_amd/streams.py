@@ -55,6 +55,12 @@ def rmat_edges(scale, count, seed, a=0.57, b=0.19, c=0.19, offset=0, chunk=1 << 
     return src, dst
 
 
+def rmat_edges_folded(n, scale, count, seed, offset=0):
+    """config #4/#5 graph: RMAT ids of 2**scale >= n vertices folded into [0, n) by `% n`"""
+    s, d = rmat_edges(scale, count, seed=seed, offset=offset)
+    return (s % np.uint32(n)).astype(np.uint32), (d % np.uint32(n)).astype(np.uint32)
+
+
 def adds(src, dst, value=1):
     return np.stack([src, dst, np.full(len(src), value, np.uint32)], 1).astype(np.uint32)
 
@@ -80,11 +86,18 @@ def mixed_existing_stream(core, fresh, seed):
     return out
 
 
+_ZIPF_CDF = {}
+
+
 def zipf_sources(n, count, seed, alpha=1.2, offset=0):
     """Zipf(alpha) ranks in [0,n) by inverse CDF on a precomputed table (config #5); counters offset..offset+count-1."""
-    w = 1.0 / np.power(np.arange(1, n + 1, dtype=np.float64), alpha)
-    cdf = np.cumsum(w)
-    cdf /= cdf[-1]
+    cdf = _ZIPF_CDF.get((n, alpha))
+    if cdf is None:
+        w = 1.0 / np.power(np.arange(1, n + 1, dtype=np.float64), alpha)
+        cdf = np.cumsum(w)
+        cdf /= cdf[-1]
+        _ZIPF_CDF.clear()  # (one table at a time: 80 MB at n = 10 M)
+        _ZIPF_CDF[(n, alpha)] = cdf
     u = _u01(seed, np.arange(offset, offset + count, dtype=np.uint64))
     return np.minimum(np.searchsorted(cdf, u, side="right"), n - 1).astype(np.uint32)
 

@@ -33,6 +33,8 @@ def _load_oracle():
     L.po_create.restype = c_vp
     L.po_create.argtypes = [c_u32, c_u32, c_int]
     L.po_destroy.argtypes = [c_vp]
+    L.po_clone.restype = c_vp
+    L.po_clone.argtypes = [c_vp]
     L.po_add_edge.argtypes = [c_vp, c_u32, c_u32, c_u32]
     L.po_remove_edge.argtypes = [c_vp, c_u32, c_u32]
     L.po_add_node.argtypes = [c_vp]
@@ -114,6 +116,12 @@ class Oracle(_State):
         if self.own and self.h:
             self.L.po_destroy(self.h)
         self.h = None
+
+    def clone(self):
+        """independent copy of the whole state (several batches can be replayed from one loaded core graph)"""
+        o = Oracle(0, handle=self.L.po_clone(self.h))
+        o.own = True
+        return o
 
     def __del__(self):
         try:

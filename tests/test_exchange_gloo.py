@@ -68,3 +68,52 @@ def test_exchange_world2(n_global):
     for r in range(world):
         a, b = parts[r], pp.partition(r)
         assert digest(*a.state(), a.geometry()) == digest(*b.state(), b.geometry())
+
+
+def _worker_parts(rank, world, port, n_global, n_parts, blocks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = _load_exchange()
+    outs = []
+    for blk in blocks[rank]:
+        t = torch.from_numpy(blk.view(np.int32))
+        parts, cnts = ex.exchange_parts(t, n_global, n_parts, world, cap=3000)  # blocks are ragged: agree on the capacity
+        assert [p.shape[0] for p in parts] == cnts
+        outs.append([p.numpy().view(np.uint32).copy() for p in parts])
+    q.put((rank, outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_global,n_parts", [(1000, 4), (1003, 8), (1000, 2)])
+def test_exchange_parts_world2(n_global, n_parts):
+    """strong-scaling form (config #4/#5): n_parts partitions over 2 ranks, ONE padded all-to-all per batch; every local
+    partition receives exactly its subsequence of the global stream (block 0 then block 1), partition-local sources"""
+    from oracle_lib import OraclePPPCSR
+    streams = load_streams()
+    world, steps = 2, 2
+    sizes = [3000, 1]  # ragged: an almost empty block on one rank
+    blocks = [[streams.random_stream(n_global, sizes[(r + k) % 2] if k else 2500, seed=90 + 5 * k + r, p_delete=0.25) for k in range(steps)]
+              for r in range(world)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_parts, args=(r, world, port, n_global, n_parts, blocks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pp = OraclePPPCSR(n_global, True, world, n_parts // world)
+    ppr = n_parts // world
+    for k in range(steps):
+        glob = np.concatenate([blocks[r][k] for r in range(world)])
+        owner = np.array([pp.get_partition(int(s)) for s in glob[:, 0]])
+        for r in range(world):
+            for ql in range(ppr):
+                part = r * ppr + ql
+                exp = glob[owner == part].copy()
+                exp[:, 0] -= np.uint32(pp.partition_start(part))
+                np.testing.assert_array_equal(got[r][k][ql], exp, err_msg=f"step {k} partition {part}")

@@ -1,0 +1,138 @@
+"""GPU (MI355X): the BASELINE.json configurations at FULL size, slot by slot against the oracle.
+
+* configs #2 / #3 (and config #5's stream shape) on the RMAT scale-20 / 10 M-edge graph: the state after the core load
+  (the regime with exclusive updates, doublings and rollbacks), after 1 M inserts, after 1 M mixed updates, after 1 M
+  Zipf(1.2)-source inserts — each from the same core snapshot;
+* configs #4 / #5 (n = 10 000 000, 100 M-edge core, P = 8, partitionSize = 1 250 000): ONE partition at a time, fed with
+  its subsequence of the global stream exactly as PPPCSR routes it (PPPCSR.cpp:46-66) — partition 0 with raw labels (the
+  one that holds 44 % of the edges) and partition 3 with permuted labels (it owns the second-hottest Zipf vertex), the
+  latter also under config #5's 10 M-update Zipf stream.
+The partitions of a PPPCSR are independent PCSRs, so one partition against the oracle at full size is the full-size
+check of that partition in the 8-GPU run; bench.py checks all resident partitions after its timed region as well."""
+import time
+
+import numpy as np
+import pytest
+
+from helpers import load_pkg
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_pkg()
+    p.load_library()
+    return p
+
+
+def _same(eng, o, label):
+    assert tuple(eng.geometry()) == tuple(o.geometry()), f"{label}: geometry {eng.geometry()} vs {o.geometry()}"
+    ei, en = eng.state()
+    oi, on = o.state()
+    if not np.array_equal(en, on):
+        bad = np.nonzero((en != on).any(1))[0]
+        raise AssertionError(f"{label}: nodes[] differ at {len(bad)} vertices, first {bad[:8]}")
+    if not np.array_equal(ei, oi):
+        bad = np.nonzero((ei != oi).any(1))[0]
+        raise AssertionError(f"{label}: edges[] differ at {len(bad)} slots, first {bad[:8]}")
+
+
+def _branch(eng, core_oracle, ops, label):
+    """from the core snapshot: apply `ops` to the engine and to a copy of the core oracle, compare, report the rates"""
+    eng.restore()
+    s0 = eng.stats()
+    eng.apply(ops)
+    s1 = eng.stats()
+    o = core_oracle.clone()
+    t0 = time.time()
+    o.apply(ops)
+    dt = time.time() - t0
+    _same(eng, o, label)
+    o.close()
+    print(f"{label}: {len(ops)} updates, device {s1['last_batch_ms']:.1f} ms = {len(ops) / s1['last_batch_ms'] / 1e3:.1f} M/s, "
+          f"rounds {s1['rounds'] - s0['rounds']}, exclusive {s1['exclusive_ops'] - s0['exclusive_ops']}, "
+          f"rollbacks {s1['rollbacks'] - s0['rollbacks']}; oracle {dt:.1f} s = {len(ops) / dt / 1e6:.2f} M/s on one host thread")
+
+
+def test_configs_2_3_and_zipf_shape_full_size(pkg, streams):
+    scale, n = 20, 1 << 20
+    s, d = streams.rmat_edges(scale, 10_000_000, seed=1)
+    core = streams.adds(s, d)
+    eng, o = pkg.PCSR(n), Oracle(n)
+    eng.apply(core)
+    t0 = time.time()
+    o.apply(core)
+    print(f"core: oracle {time.time() - t0:.1f} s; engine {eng.stats()}")
+    _same(eng, o, "after the 10 M-edge core load")
+    st = eng.stats()
+    assert st["N"] == 1 << 24 and st["logN"] == 32
+    assert st["exclusive_ops"] > 0 and st["double_calls"] >= 2  # the load is where the scheduler is stressed most
+    eng.snapshot()
+    s2, d2 = streams.rmat_edges(scale, 1_000_000, seed=2)
+    fresh = streams.adds(s2, d2)
+    _branch(eng, o, fresh, "config #2: 1 M inserts")
+    _branch(eng, o, streams.mixed_existing_stream(core, fresh[:500_000], seed=3), "config #3: 1 M mixed 50/50")
+    zs = streams.zipf_sources(n, 1_000_000, seed=4, alpha=1.2)
+    zd = streams.uniform_ints(11, 1_000_000, n)
+    _branch(eng, o, streams.adds(zs, zd), "config #5 stream shape on the config #2 graph: 1 M Zipf(1.2)-source inserts")
+    o.close()
+    eng.close()
+
+
+# ---- configs #4 / #5 -------------------------------------------------------------------------------------------------
+N4, SCALE4, CORE4, UPD4, P4 = 10_000_000, 24, 100_000_000, 10_000_000, 8
+
+
+@pytest.fixture(scope="module")
+def graph4(streams):
+    """raw (folded) ids of the 100 M-edge core and of the 10 M-insert stream, generated once for the module"""
+    t0 = time.time()
+    cs, cd = streams.rmat_edges_folded(N4, SCALE4, CORE4, seed=1)
+    us, ud = streams.rmat_edges_folded(N4, SCALE4, UPD4, seed=2)
+    print(f"config #4 streams generated in {time.time() - t0:.1f} s")
+    return cs, cd, us, ud
+
+
+def _partition_subsequence(streams, s, d, part, permute):
+    """PPPCSR routing (PPPCSR.cpp:20-29, 46-66): owner = src / floor(n / P) (last partition takes the remainder); the
+    partition sees its updates in stream order with src made local and dest left global"""
+    if permute:
+        s = streams.permute_labels(s, N4)
+        d = streams.permute_labels(d, N4)
+    ps = N4 // P4
+    own = np.minimum(s // np.uint32(ps), P4 - 1)
+    m = own == part
+    return streams.adds(s[m] - np.uint32(part * ps), d[m])
+
+
+@pytest.mark.parametrize("labels,part", [("raw", 0), ("permuted", 3)])
+def test_config4_one_partition_full_size(pkg, streams, graph4, labels, part):
+    cs, cd, us, ud = graph4
+    permute = labels == "permuted"
+    ps = N4 // P4
+    size = ps if part < P4 - 1 else N4 - part * ps
+    assert size == 1_250_000
+    core = _partition_subsequence(streams, cs, cd, part, permute)
+    upd = _partition_subsequence(streams, us, ud, part, permute)
+    print(f"config #4 partition {part} ({labels}): {len(core)} core edges ({100.0 * len(core) / CORE4:.1f} % of the graph), {len(upd)} inserts")
+    eng, o = pkg.PCSR(size), Oracle(size)
+    eng.apply(core)
+    t0 = time.time()
+    o.apply(core)
+    print(f"core: oracle {time.time() - t0:.1f} s")
+    _same(eng, o, f"partition {part} ({labels}) after its core subsequence")
+    eng.snapshot()
+    _branch(eng, o, upd, f"config #4 partition {part} ({labels}): its share of the 10 M inserts")
+    if permute:
+        # config #5 on the same partition: 10 M updates, src = Zipf(1.2) rank through the same permutation (rank 2 lands in
+        # this partition: permute(1) = 4 435 761), dst uniform
+        zs = streams.zipf_sources(N4, UPD4, seed=4, alpha=1.2)
+        zd = streams.uniform_ints(11, UPD4, N4)
+        zupd = _partition_subsequence(streams, zs, zd, part, True)
+        hot = np.bincount(zupd[:, 0]).max()
+        print(f"config #5 partition {part}: {len(zupd)} updates, {hot} of them into one vertex")
+        _branch(eng, o, zupd, f"config #5 partition {part} (permuted): its share of the 10 M Zipf(1.2) updates")
+    o.close()
+    eng.close()
