@@ -102,6 +102,9 @@ struct Engine::Impl {
   uint32_t adaptive = 0;
   uint32_t scatter_blocks = 8192;
   uint32_t small_batch = 256;    // batches up to this size take the strict rounds even in speculative mode
+  // windows up to this size are rebalanced by the exclusive executor's own wave (64 slots at a time: ~2 us per dependent
+  // chunk, i.e. milliseconds at 64 K slots); larger ones by the multi-workgroup kernels (three launches whatever the size)
+  uint32_t excl_in_wave = 4096;
   uint32_t rb_tile = 0;          // leaves per rebalance tile (power of two <= 256); 0 = pick per window
   uint32_t rb_min_tiles = 4096;  // auto tile: shrink the tile until the window has at least this many
   uint32_t rb_prefetch = 1;  // 1: four chunks in flight per wave, 0: one
@@ -402,6 +405,10 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "small_batch") {
     p.small_batch = value < 0 ? 0u : (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "excl_in_wave") {
+    p.excl_in_wave = (uint32_t)std::max<int64_t>(64, value);
     return PPCSR_OK;
   }
   if (k == "rb_tile") {
@@ -820,7 +827,7 @@ int Engine::run_exclusive(Op op, uint32_t flags) {
   Impl &p = *p_;
   p.st.exclusive_ops++;
   for (int attempt = 0; attempt < 8; attempt++) {
-    GPU_LAUNCH(p.stream, k_exclusive, 1, 64, p.v, op, flags, p.d_xout, p.d_stats);
+    GPU_LAUNCH(p.stream, k_exclusive, 1, 64, p.v, op, flags, p.d_xout, p.d_stats, p.excl_in_wave);
     GCHK(gpu::d2h(p.h_xout, p.d_xout, sizeof(ExclOut), p.stream));
     GCHK(gpu::sync(p.stream));
     GCHK(gpu::last_error());

@@ -169,9 +169,10 @@ constexpr uint32_t XF_FORCE_NOINFO = 1u;  // insert(..., nullptr): climb on post
 constexpr uint32_t XF_SKIP_COUNT = 2u;    // num_neighbors already adjusted by a previous attempt
 constexpr uint32_t XF_ADD_NODE = 4u;      // op.src = new vertex id, op.dst = slot to insert the sentinel at, op.op = sentinel value
 constexpr uint32_t XF_RESEARCH = 8u;      // add_node retry after double_list: search again (PCSR.cpp:539)
-constexpr uint32_t kExclInWave = 1u << 16;
 
-PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatShard *st) {
+
+// in_wave_max: largest window the executor's own wave rebalances; larger ones go back to the host (multi-workgroup kernels)
+PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatShard *st, uint32_t in_wave_max) {
   PMA_SHARED uint32_t lds[3 * kLdsWindow];
   const int lane = wv::lane();
   const Geometry &g = v.g;
@@ -321,7 +322,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
         if (result == X_DONE) {
           if (ws + wn > g.N) {
             result = X_WINDOW_BEYOND_ARRAY;
-          } else if (wn <= kExclInWave) {
+          } else if (wn <= in_wave_max) {
             dev::redistribute_wave(v, ws, wn, lds);
           } else {
             result = X_NEED_REDIST;
@@ -363,7 +364,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
             wv::atomic_add_u64(&st->redistribute_calls, 2ull);
             wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)logN + rp.wlen);
           }
-          if (rp.wlen <= kExclInWave) {
+          if (rp.wlen <= in_wave_max) {
             dev::redistribute_wave(v, rp.wstart, rp.wlen, lds);
           } else {
             result = X_NEED_REDIST;
