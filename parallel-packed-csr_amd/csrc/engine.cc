@@ -112,6 +112,7 @@ struct Engine::Impl {
   bool carry_dumped = false;
   bool partial = false;
   bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
+  uint32_t diag = 0;     // count, per epoch, why planned updates did not commit (printed to stderr at the end of the epoch)
   std::vector<gpu::Event> events;  // init failed half-way: destructor frees only what exists
 };
 
@@ -438,6 +439,10 @@ int Engine::set_option(const char *key, int64_t value) {
     p.start_horizon = (uint32_t)value;
     return PPCSR_OK;
   }
+  if (k == "diag") {
+    p.diag = value != 0;
+    return PPCSR_OK;
+  }
   if (k == "profile") {
     p.profile = value != 0;
     p.st.prof_plan_ms = p.st.prof_check_ms = p.st.prof_apply_ms = p.st.prof_compact_ms = 0;
@@ -684,6 +689,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       a.vws = p.d_vws;
       a.vrs = p.d_vrs;
       a.regshift = rs;
+      a.diag = p.diag;
       // grid sized for the horizon the device last reported (it can only shrink within a chunk when fresh
       // updates run out; it never exceeds opt_horizon)
       uint32_t gh = p.opt_horizon;
@@ -732,6 +738,12 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       }
       p.st.round_syncs++;
       if (c.error) return fail(PPCSR_EINTERNAL, "device-side error " + std::to_string(c.error));
+      if (p.diag && (c.violation || c.excl || c.done))
+        fprintf(stderr, "[ppcsr diag] epoch [%llu,%llu) %s after %llu rounds: committed %llu planned %llu | not committed because: excl-kind %llu, "
+                "behind-barrier %llu, dup %llu, W-W %llu, W-after-R %llu, R-after-W %llu, sentinel-read %llu, sentinel-move %llu, region %llu, "
+                "growth-zone %llu, stamp %llu\n",
+                (unsigned long long)e0, (unsigned long long)e1, c.violation ? "ROLLBACK" : (c.excl ? "exclusive" : "done"), c.rounds, c.committed,
+                c.planned, c.why[0], c.why[1], c.why[2], c.why[3], c.why[4], c.why[5], c.why[6], c.why[7], c.why[8], c.why[9], c.why[10]);
       const uint32_t npar = (p.round + 1) & 1u;
       // an exclusive update rewrites an unbounded part of the array; if anything LATER has already been
       // committed (it turned exclusive only after being deferred) the epoch is not serialisable: roll back

@@ -74,6 +74,9 @@ struct RangeRec {  // read-leaf ranges collected by lane 0 into the plan record
   uint32_t nlong = 0;
   // register copy, lane r holding range r (r < 64): the planning kernel reserves from it without reading the record back
   uint32_t my_lo = 1, my_hi = 0;
+  // which sentinel positions the search result depends on: bit 0 = nodes[src].beginning (the final bracket still starts
+  // at the first slot of the range), bit 1 = nodes[src].end (it still ends at the end of the range)
+  uint32_t sdep = 0;
 };
 PMA_DEV void rec_range(RangeRec &rr, const View &v, uint32_t slot_lo, uint32_t slot_hi) {
   if (!rr.plan) return;
@@ -108,12 +111,29 @@ PMA_DEV void rec_range(RangeRec &rr, const View &v, uint32_t slot_lo, uint32_t s
 struct SearchHit {
   uint32_t known, value, dest;
 };
+// What is recorded as READ is the search's CERTIFICATE, not its path.  In a sorted neighbourhood the slot the reference's
+// walk returns is a function of the final tight bracket alone (tests/test_search_model.py): a live slot a with dest < key
+// (or the first slot of the range), a live slot b with dest > key (or the end of the range), and nothing live in between —
+// or the slot that holds the key itself.  Whatever an earlier update does to the leaves the walk merely passed through
+// (the 64-ary samples, the probes of earlier iterations) cannot change the outcome as long as those bracket leaves are
+// untouched, so only [a, b] is recorded; and the result depends on the POSITION of sentinel src / src + 1 only when the
+// bracket still starts / ends at the range's own boundary (rr.sdep).  Path reads used to order every update of a hub vertex
+// behind every write to the few leaves its coarse samples sit on.
 PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32_t end, RangeRec &rr, SearchHit *hit) {
   hit->known = 0;
   hit->value = 0;
   hit->dest = 0;
   const int lane = wv::lane();
   const Edge *items = v.items;
+  const uint32_t range_start = start, range_end = end;
+#define PMA_CERT_BRACKET()                                                                  \
+  do {                                                                                      \
+    if (start == range_start) rr.sdep |= 1u;                                                \
+    if (end == range_end) rr.sdep |= 2u;                                                    \
+    const uint32_t _hi = (end == range_end && end > start) ? end - 1u : end;                \
+    rec_range(rr, v, start < _hi ? start : _hi, start < _hi ? _hi : start);                 \
+  } while (0)
+  if (!v.g.narrow || end <= start) rr.sdep |= 3u;  // unsorted / inverted ranges (add_node after a doubling): no theorem
   // Once the interval fits one wave (<= 64 slots) it is loaded ONCE, lane l holding slot cbase + l, and the remaining
   // levels probe that register copy through shuffles: same probes, same decisions, no further memory round trips.
   bool cached = false;
@@ -123,14 +143,11 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
   // whose dest > key" leads to the same answer (the walk only ever tightens such a bracket, and every exit fires on
   // the tight one; tests/test_search_model.py checks this against the scalar walk).  So the bracket is first tightened
   // 64 samples at a time — one round trip per factor of ~64 instead of one per factor of 2 — and the reference's walk
-  // then finishes it from registers.  Only the two samples that become the new bracket are recorded as reads: with a
-  // sorted neighbourhood the others cannot change the outcome.
+  // then finishes it from registers.
   while (v.g.narrow && end > start && end - start > 64) {  // (end < start happens: add_node after a doubling can leave a vertex whose
                                              // recorded range is inverted, PCSR.cpp:533-540 + 681-703; the walk below copes)
     const uint32_t len = end - start;
-    // samples sit on an ABSOLUTE power-of-two grid (multiples of 2^sshift), not at offsets from `start`: a deferred
-    // update that is planned again after its vertex's range has shifted by a slot or two then reads the same sample
-    // leaves as before, which is what the per-round reservations of the other updates were checked against
+    // samples sit on an ABSOLUTE power-of-two grid (multiples of 2^sshift), not at offsets from `start`
     uint32_t sshift = 0;
     while ((len >> sshift) >= 64u) sshift++;
     const uint32_t first = ((start + (1u << sshift) - 1u) >> sshift) << sshift;
@@ -157,8 +174,6 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
       nend = bslot;
     }
     if (mlt) nstart = wv::shfl(sl, 63 - __builtin_clzll(mlt));
-    if (nstart != start) rec_range(rr, v, nstart, nstart);
-    if (nend != end) rec_range(rr, v, nend, nend);
     const bool progress = (nend - nstart) <= len / 2u;
     start = nstart;
     end = nend;
@@ -177,7 +192,7 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
     }
     const uint32_t mid = (start + end) / 2;
     bool found = false;
-    uint32_t check = mid, idest = 0, ival = 0, dist = 0;
+    uint32_t check = mid, idest = 0, ival = 0;
     for (uint32_t pbase = 0;; pbase += 64) {
       const uint32_t p = pbase + (uint32_t)lane;
       const uint32_t d = (p + 1) >> 1;
@@ -208,27 +223,22 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
         check = wv::shfl(slot, pl);
         idest = wv::shfl(dst, pl);
         ival = wv::shfl(val, pl);
-        dist = (pbase + (uint32_t)pl + 1) >> 1;
         found = true;
         break;
       }
       if (wv::ballot(valid) == 0) break;  // both sides exhausted: the whole range is null
     }
-    if (found) {
-      uint32_t lo = (dist <= mid - start) ? mid - dist : start;
-      uint32_t hi = (dist < end - mid) ? mid + dist : end - 1;
-      rec_range(rr, v, lo, hi);
-    } else {
-      rec_range(rr, v, start, end - 1);
-    }
     if (!found || check == start) {
+      // nothing live in (start, end): the bracket is tight
       if (found && dest <= idest) {
+        if (dest == idest) rec_range(rr, v, check, check); else PMA_CERT_BRACKET();
         hit->known = 1;
         hit->value = ival;
         hit->dest = idest;
         return check;
       }
       // mid itself: the nearest live slot to it is `check` (or there is none), so unless mid == check it is null
+      PMA_CERT_BRACKET();
       hit->known = 1;
       if (found && check == mid) {
         hit->value = ival;
@@ -237,6 +247,7 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
       return mid;
     }
     if (dest == idest) {
+      rec_range(rr, v, check, check);
       hit->known = 1;
       hit->value = ival;
       hit->dest = idest;
@@ -253,7 +264,11 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
     ev = items[start].value;
     ed = items[start].dest;
   }
-  rec_range(rr, v, start, start);
+  if (ev != 0 && dest == ed) {
+    rec_range(rr, v, start, start);
+  } else {
+    PMA_CERT_BRACKET();
+  }
   if (ev != 0 && dest <= ed) {
     hit->known = 1;
     hit->value = ev;
@@ -266,6 +281,7 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
     hit->dest = wv::shfl(cdst, (int)(end - cbase));
   }
   return end;
+#undef PMA_CERT_BRACKET
 }
 
 // first null slot in [from, N); returns N if none.  Stops (returns kMax) after `limit` slots.
@@ -709,7 +725,7 @@ PMA_DEV void slide_left_wave(const View &v, uint32_t gap, uint32_t last) {
 // ---- full per-op planning (search + window plan) -------------------------------------------------------
 // What the planning kernels need from the plan right away (the full record goes to memory for the later kernels)
 struct PlanRegs {
-  uint32_t kind, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, nr, nlong;
+  uint32_t kind, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, nr, nlong, sdep;
   uint32_t my_lo, my_hi;  // lane r: read range r (r < 64)
 };
 PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
@@ -877,8 +893,10 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
     plan->alg_slots = aslots;
     plan->nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
     plan->nlong = rr.nlong;
+    plan->sdep = rr.sdep;
   }
   PlanRegs pr;
+  pr.sdep = rr.sdep;
   pr.kind = kind;
   pr.wlen = wlen;
   pr.wleaf_lo = wl;

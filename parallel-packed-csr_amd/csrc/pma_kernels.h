@@ -106,12 +106,12 @@ PMA_KERNEL void k_check(RoundArgs a) {
     const unsigned long long k = a.v.wres[leaf];
     if ((uint32_t)(k >> 32) == tag && (uint32_t)k < idx) fail = true;  // an earlier update writes what we read
   });
-  if (kind != K_NOOP) {  // nodes[src].beginning / .end: an earlier update moves sentinel src or src+1
+  if (kind != K_NOOP && pl->sdep) {  // the result depends on nodes[src].beginning / .end: an earlier update moves that sentinel
     const uint32_t src = a.ops[idx].src;
     if (src < a.v.g.n) {
       const unsigned long long k0 = a.v.vw[src];
-      if ((uint32_t)(k0 >> 32) == tag && (uint32_t)k0 < idx) fail = true;
-      if (src + 1u < a.v.g.n) {
+      if ((pl->sdep & 1u) && (uint32_t)(k0 >> 32) == tag && (uint32_t)k0 < idx) fail = true;
+      if ((pl->sdep & 2u) && src + 1u < a.v.g.n) {
         const unsigned long long k1 = a.v.vw[src + 1u];
         if ((uint32_t)(k1 >> 32) == tag && (uint32_t)k1 < idx) fail = true;
       }
@@ -1235,6 +1235,11 @@ struct OptCtl {
   unsigned long long rounds, committed, planned, blocked, failed;
   uint32_t viol_info[8];  // debug: kind, leaf, stamp, what(1=wstamp on W,2=rstamp on W,3=wstamp on R), wleaf_lo, wleaf_hi, index, round
   uint32_t hist[192];  // debug: (horizon << 16 | committed) >> of the first rounds of the epoch
+  // diagnostics (option "diag"): why planned updates did not commit, first reason found per update
+  // 0 exclusive kind, 1 behind a barrier (gbar), 2 duplicate-slot conflicts, 3 write leaf reserved by an earlier writer,
+  // 4 write leaf read by an earlier update, 5 read leaf written by an earlier update, 6 sentinel located by is moved earlier,
+  // 7 sentinel we move is needed earlier, 8 region prefix, 9 growth zone of a deferred reader/writer (pfail), 10 stamp violation
+  unsigned long long why[12];
 };
 struct OptArgs {
   View v;
@@ -1250,6 +1255,7 @@ struct OptArgs {
   uint32_t *vws, *vrs;  // per vertex: 1 + latest committed update that moved / read the position of its sentinel
   uint32_t round;
   int regshift;
+  uint32_t diag;
 };
 constexpr uint32_t kRegionPadLeaves = 2u;
 constexpr uint32_t kGrowLeaves = 8u;
@@ -1262,7 +1268,7 @@ PMA_DEV bool key_earlier(unsigned long long k, uint32_t tag, uint32_t idx) { ret
 // the per-wave arrays are padded to the launch grid, so the loads are always in bounds).  The round kernels are chains
 // of dependent loads; what can be asked for together is asked for together.
 struct PlanHead {
-  uint32_t kind, index, wstart, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, sleaf_b, sleaf_e, nr, nlong;
+  uint32_t kind, index, wstart, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, sleaf_b, sleaf_e, nr, nlong, sdep;
   uint32_t my_lo, my_hi;  // lane r: read range r (r < 64)
 };
 PMA_DEV PlanHead load_plan_head(const Plan *pl, int lane) {
@@ -1279,6 +1285,7 @@ PMA_DEV PlanHead load_plan_head(const Plan *pl, int lane) {
   h.sleaf_e = pl->sleaf_e;
   h.nr = pl->nr;
   h.nlong = pl->nlong;
+  h.sdep = pl->sdep;
   h.my_lo = pl->rlo[lane];
   h.my_hi = pl->rhi[lane];
   return h;
@@ -1335,9 +1342,9 @@ PMA_KERNEL void o_plan(OptArgs a) {
     wv::fence();  // (rare) more ranges than lanes, or long ranges: walk the record this wave has just written
     PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, wv::atomic_min_u64(&a.v.rres[leaf], key));
   }
-  if (kind != K_NOOP && op.src < a.v.g.n) {  // readers of the positions of sentinels src and src+1
-    if (lane == 0) wv::atomic_min_u64(&a.v.vr[op.src], key);
-    if (lane == 1 && op.src + 1u < a.v.g.n) wv::atomic_min_u64(&a.v.vr[op.src + 1u], key);
+  if (kind != K_NOOP && op.src < a.v.g.n) {  // readers of the positions of sentinels src and src+1 (only when the result depends on them)
+    if (lane == 0 && (pr.sdep & 1u)) wv::atomic_min_u64(&a.v.vr[op.src], key);
+    if (lane == 1 && (pr.sdep & 2u) && op.src + 1u < a.v.g.n) wv::atomic_min_u64(&a.v.vr[op.src + 1u], key);
   }
 }
 
@@ -1358,21 +1365,23 @@ PMA_KERNEL void o_check(OptArgs a) {
   const unsigned long long key = make_key(a.round, idx);
   const uint32_t tag = (uint32_t)(key >> 32);
   bool fail = (kind == K_EXCL) || key_earlier(gbar, tag, idx);
+  uint32_t why = (kind == K_EXCL) ? 0u : (fail ? 1u : 99u);  // diagnostics: first reason (lowest code wins below)
+#define PMA_WHY(code) do { if (a.diag && (code) < why) why = (code); } while (0)
   bool stamp_bad = false;
   const uint32_t me1 = idx + 1u;  // stamps hold (index + 1) of the latest committed toucher
   const bool writes = kind_writes(kind);
   const bool strong = kind_strong(kind);
   if (kind == K_DUP) {
     const uint32_t leaf = h.wleaf_lo;
-    if (key_earlier(a.v.wres[leaf], tag, idx)) fail = true;  // an earlier pending update moves slots of this leaf
-    if (a.v.dres[leaf] != key) fail = true;                   // an earlier pending duplicate on this leaf
+    if (key_earlier(a.v.wres[leaf], tag, idx)) { fail = true; PMA_WHY(2u); }  // an earlier pending update moves slots of this leaf
+    if (a.v.dres[leaf] != key) { fail = true; PMA_WHY(2u); }                   // an earlier pending duplicate on this leaf
   }
   if (strong) {
     const uint32_t wl = h.wleaf_lo, wh = h.wleaf_hi;
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) {
-      if (a.v.wres[leaf] != key) fail = true;                   // an earlier pending update writes it
-      if (key_earlier(a.v.dres[leaf], tag, idx)) fail = true;   // an earlier pending duplicate overwrites a slot here
-      if (key_earlier(a.v.rres[leaf], tag, idx)) fail = true;   // an earlier pending update reads it
+      if (a.v.wres[leaf] != key) { fail = true; PMA_WHY(3u); }                   // an earlier pending update writes it
+      if (key_earlier(a.v.dres[leaf], tag, idx)) { fail = true; PMA_WHY(2u); }   // an earlier pending duplicate overwrites a slot here
+      if (key_earlier(a.v.rres[leaf], tag, idx)) { fail = true; PMA_WHY(4u); }   // an earlier pending update reads it
       if (a.wstamp[leaf] > me1 || a.rstamp[leaf] > me1) {  // a LATER update already touched it
         stamp_bad = true;
         a.vdbg[4 * wid + 0] = leaf;
@@ -1382,7 +1391,7 @@ PMA_KERNEL void o_check(OptArgs a) {
     }
   }
   PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, {
-    if (key_earlier(a.v.wres[leaf], tag, idx)) fail = true;  // an earlier pending update writes what we read
+    if (key_earlier(a.v.wres[leaf], tag, idx)) { fail = true; PMA_WHY(5u); }  // an earlier pending update writes what we read
     if (a.wstamp[leaf] > me1) {                               // a LATER update already wrote what we read
       stamp_bad = true;
       a.vdbg[4 * wid + 0] = leaf;
@@ -1392,9 +1401,9 @@ PMA_KERNEL void o_check(OptArgs a) {
   });
   if (kind != K_NOOP) {
     const uint32_t src = a.ops[idx].src;
-    if (src < a.v.g.n && lane < 2 && src + (uint32_t)lane < a.v.g.n) {  // lane 0: sentinel src, lane 1: sentinel src+1
+    if (src < a.v.g.n && lane < 2 && ((h.sdep >> lane) & 1u) && src + (uint32_t)lane < a.v.g.n) {  // lane 0: sentinel src, lane 1: sentinel src+1
       const uint32_t u = src + (uint32_t)lane;
-      if (key_earlier(a.v.vw[u], tag, idx)) fail = true;  // an earlier pending update moves a sentinel we located by
+      if (key_earlier(a.v.vw[u], tag, idx)) { fail = true; PMA_WHY(6u); }  // an earlier pending update moves a sentinel we located by
       if (a.vws[u] > me1) {                                // a LATER update already moved it
         stamp_bad = true;
         a.vdbg[4 * wid + 0] = u;
@@ -1405,7 +1414,7 @@ PMA_KERNEL void o_check(OptArgs a) {
     if (strong) {
       const uint32_t ml = h.mv_lo, mh = h.mv_hi;
       for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) {
-        if (key_earlier(a.v.vr[u], tag, idx)) fail = true;  // an earlier pending update still needs the old position
+        if (key_earlier(a.v.vr[u], tag, idx)) { fail = true; PMA_WHY(7u); }  // an earlier pending update still needs the old position
         if (a.vrs[u] > me1 || a.vws[u] > me1) {              // a LATER update already used / moved it
           stamp_bad = true;
           a.vdbg[4 * wid + 0] = (uint32_t)u;
@@ -1417,6 +1426,14 @@ PMA_KERNEL void o_check(OptArgs a) {
   }
   const bool anyfail = wv::ballot(fail) != 0;
   const bool anybad = wv::ballot(stamp_bad) != 0;
+  if (a.diag && anyfail) {
+    uint32_t w = why;
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t y = wv::shfl(w, lane ^ o);
+      w = y < w ? y : w;
+    }
+    if (lane == 0 && w < 12u) wv::atomic_add_u64(&c->why[w], 1ull);
+  }
   if (anyfail && kind != K_NOOP) {
     // a deferred update keeps later updates out of its region(s); its footprint may still creep over a region edge
     // by a slide, so the mark is padded by kRegionPadLeaves leaves on both sides
@@ -1468,17 +1485,20 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
     } else {
       glo = ghi = (h.index >> a.v.g.sh) >> a.regshift;
     }
-    bool blocked = false;
+    bool blocked = false, blocked_r = false;
     for (uint32_t g = glo + (uint32_t)lane; g <= ghi; g += 64)
-      if (key_earlier(a.regfail[g], tag, idx)) blocked = true;
+      if (key_earlier(a.regfail[g], tag, idx)) blocked_r = true;
     // ... nor may we have READ a leaf an earlier deferred update may still grow over
     PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, { if (key_earlier(a.pfail[leaf], tag, idx)) blocked = true; });
     // ... nor located our range by a sentinel inside the block a deferred earlier update may still grow over
-    if (lane == 0 && key_earlier(a.pfail[h.sleaf_b], tag, idx)) blocked = true;
-    if (lane == 1 && key_earlier(a.pfail[h.sleaf_e], tag, idx)) blocked = true;
-    if (wv::ballot(blocked) != 0) return;  // an earlier update of this region was deferred: keep stream order inside it
+    if (lane == 0 && (h.sdep & 1u) && key_earlier(a.pfail[h.sleaf_b], tag, idx)) blocked = true;
+    if (lane == 1 && (h.sdep & 2u) && key_earlier(a.pfail[h.sleaf_e], tag, idx)) blocked = true;
+    const bool any_r = wv::ballot(blocked_r) != 0, any_p = wv::ballot(blocked) != 0;
+    if (a.diag && (any_r || any_p) && lane == 0) wv::atomic_add_u64(&c->why[any_r ? 8 : 9], 1ull);
+    if (any_r || any_p) return;  // an earlier update of this region was deferred: keep stream order inside it
   }
   if (st & OS_STAMP_BAD) {
+    if (a.diag && lane == 0) wv::atomic_add_u64(&c->why[10], 1ull);
     if (lane == 0) {
       const uint32_t prev = wv::atomic_min_u32(&c->viol_idx, idx);
       wv::atomic_exch_u32(&c->violation, 1u);
@@ -1509,7 +1529,7 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
   }
   PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, wv::atomic_max_u32(&a.rstamp[leaf], me1));
   if (kind != K_NOOP && op.src < a.v.g.n) {
-    if (lane < 2 && op.src + (uint32_t)lane < a.v.g.n) wv::atomic_max_u32(&a.vrs[op.src + (uint32_t)lane], me1);
+    if (lane < 2 && ((h.sdep >> lane) & 1u) && op.src + (uint32_t)lane < a.v.g.n) wv::atomic_max_u32(&a.vrs[op.src + (uint32_t)lane], me1);
     if (kind_strong(kind)) {
       const uint32_t ml = h.mv_lo, mh = h.mv_hi;
       for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_max_u32(&a.vws[u], me1);

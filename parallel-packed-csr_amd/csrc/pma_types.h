@@ -82,6 +82,7 @@ struct Plan {
   uint32_t alg_calls, alg_slots;  // redistribute() calls / slots the reference performs for this op
   uint32_t nr;
   uint32_t nlong;  // number of read ranges spanning >= kLongRange leaves (0 for almost every update)
+  uint32_t sdep;   // bit 0 / 1: the search result depends on the position of sentinel src / src + 1 (pma_search)
   uint32_t rlo[kMaxR], rhi[kMaxR];  // inclusive leaf ranges read by the search / vertex range lookup
 };
 
