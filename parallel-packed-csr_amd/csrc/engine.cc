@@ -105,6 +105,12 @@ struct Engine::Impl {
   // windows up to this size are rebalanced by the exclusive executor's own wave (64 slots at a time: ~2 us per dependent
   // chunk, i.e. milliseconds at 64 K slots); larger ones by the multi-workgroup kernels (three launches whatever the size)
   uint32_t excl_in_wave = 4096;
+  // speculative rounds: windows up to big_window slots stay inside the round; those above big_min are rebalanced by a
+  // workgroup each (o_big, big_grid workgroups, one scratch stretch of big_window slots per workgroup)
+  uint32_t big_window = 131072, big_min = 512, big_grid = 64;
+  dev::BigJob *d_jobs = nullptr;
+  Edge *d_bigscratch = nullptr;
+  uint64_t bigscratch_cap = 0;
   uint32_t rb_tile = 0;          // leaves per rebalance tile (power of two <= 256); 0 = pick per window
   uint32_t rb_min_tiles = 4096;  // auto tile: shrink the tile until the window has at least this many
   uint32_t rb_prefetch = 1;  // 1: four chunks in flight per wave, 0: one
@@ -253,6 +259,7 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   Geometry g;
   compute_geometry(N, src_n, lock_search, &g);
   p.v.g = g;
+  p.v.big_window = kBigWindow;
   p.n_cap = std::max<uint64_t>(src_n, 16);
   p.leaves_cap = N >> g.sh;
   GCHK(gpu::dmalloc((void **)&p.v.items, N * sizeof(Edge)));
@@ -339,6 +346,8 @@ Engine::~Engine() {
   if (p.d_nbr) GPU_DFREE(p.d_nbr);
   if (p.d_scratch) GPU_DFREE(p.d_scratch);
   if (p.d_scan_state) GPU_DFREE(p.d_scan_state);
+  if (p.d_jobs) GPU_DFREE(p.d_jobs);
+  if (p.d_bigscratch) GPU_DFREE(p.d_bigscratch);
   for (Impl::Snap *sp : {&p.snap, &p.esnap}) {
     if (sp->v.items) GPU_DFREE(sp->v.items);
     if (sp->v.nodes) GPU_DFREE(sp->v.nodes);
@@ -410,6 +419,19 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "excl_in_wave") {
     p.excl_in_wave = (uint32_t)std::max<int64_t>(64, value);
+    return PPCSR_OK;
+  }
+  if (k == "big_window") {  // <= kBigWindow: o_big is not launched at all (every window of a round is rebalanced by its own wave)
+    if (value < 64 || (value & (value - 1))) return fail(PPCSR_EINVAL, "big_window must be a power of two >= 64");
+    p.big_window = (uint32_t)std::min<int64_t>(value, 1 << 20);
+    return PPCSR_OK;
+  }
+  if (k == "big_min") {
+    p.big_min = (uint32_t)std::max<int64_t>(64, std::min<int64_t>(value, kBigWindow));
+    return PPCSR_OK;
+  }
+  if (k == "big_grid") {
+    p.big_grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 256));
     return PPCSR_OK;
   }
   if (k == "rb_tile") {
@@ -632,6 +654,21 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     GCHK(gpu::dmalloc((void **)&p.d_carry1, carry_need * sizeof(uint32_t)));
     p.carry_cap = carry_need;
   }
+  // big-window path: windows of up to kBigLeaves leaves (and big_window slots) stay inside the round
+  uint32_t bigw = p.big_window;
+  while (bigw > kBigWindow && (bigw >> p.v.g.sh) > dev::kBigLeaves) bigw >>= 1;
+  const bool use_big = bigw > p.big_min;
+  if (use_big) {
+    if (!p.d_jobs) GCHK(gpu::dmalloc((void **)&p.d_jobs, kBigJobs * sizeof(dev::BigJob)));
+    const uint64_t need = (uint64_t)p.big_grid * bigw;
+    if (p.bigscratch_cap < need) {
+      if (p.d_bigscratch) GPU_DFREE(p.d_bigscratch);
+      p.d_bigscratch = nullptr;
+      p.bigscratch_cap = 0;
+      GCHK(gpu::dmalloc((void **)&p.d_bigscratch, need * sizeof(Edge)));
+      p.bigscratch_cap = need;
+    }
+  }
   uint64_t e0 = 0;
   uint64_t forced_e1 = 0;  // after a rollback: end the retried epoch right after the update that failed validation
   int retries = 0;
@@ -673,6 +710,11 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     while (epoch_open) {
       OptArgs a;
       a.v = p.v;
+      a.v.big_window = use_big ? bigw : kBigWindow;
+      a.big_min = p.big_min;
+      a.jobs = use_big ? p.d_jobs : (dev::BigJob *)nullptr;
+      a.bigscratch = p.d_bigscratch;
+      a.bigscratch_stride = bigw;
       a.ops = d_ops;
       a.plans = p.d_plans;
       a.opidx = p.d_opidx;
@@ -720,6 +762,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         GPU_LAUNCH(p.stream, o_check, blocks, 256, a);
         if (p.profile) p.events[5 * r + 2].record(p.stream);
         GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
+        if (use_big) GPU_LAUNCH(p.stream, o_big, p.big_grid, dev::kBigThreads, a);
         if (p.profile) p.events[5 * r + 3].record(p.stream);
         GPU_LAUNCH(p.stream, o_compact, 1, 1024, a);
         if (p.profile) p.events[5 * r + 4].record(p.stream);

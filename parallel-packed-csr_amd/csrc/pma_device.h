@@ -28,9 +28,12 @@ struct View {
   unsigned long long *vw;    // per-vertex: earliest pending update that may MOVE this vertex's sentinel
   unsigned long long *vr;    // per-vertex: earliest pending update that READS this sentinel's position
   Geometry g;
+  // largest rebalance window a round accepts (larger ones make the update exclusive).  Strict rounds: kBigWindow (one
+  // wave rebalances it); speculative rounds: up to kBigLeaves leaves, rebalanced by a workgroup (o_big)
+  uint32_t big_window;
 };
 
-constexpr uint32_t kBigWindow = 4096;  // windows larger than this run through the exclusive executor
+constexpr uint32_t kBigWindow = 4096;  // default of View::big_window: the largest window ONE wave rebalances inside a round
 constexpr uint32_t kMaxSlide = 4096;   // slides longer than this too
 constexpr int kStatShards = 256;
 constexpr uint32_t kLdsWindow = 512;   // windows up to this many slots are rebalanced inside one wave's LDS tile (12 KB)
@@ -47,7 +50,8 @@ PMA_DEV uint32_t lanemask_lt_count(uint64_t m, int lane) { return (uint32_t)wv::
 PMA_DEV uint32_t count_leaves(const View &v, uint32_t leaf_lo, uint32_t nleaves) {
   if (nleaves == 1) return v.leafcnt[leaf_lo];
   uint32_t s = 0;
-  for (uint32_t i = (uint32_t)wv::lane(); i < nleaves; i += 64) s += v.leafcnt[leaf_lo + i];
+#pragma unroll 8
+  for (uint32_t i = (uint32_t)wv::lane(); i < nleaves; i += 64) s += v.leafcnt[leaf_lo + i];  // (independent loads: batched by the unroll)
   return wv::reduce_add(s);
 }
 PMA_DEV uint32_t count_window(const View &v, uint64_t start, uint64_t len) {
@@ -670,6 +674,117 @@ PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, ui
   wv::fence();
 }
 
+// ---- workgroup window rebalance (redistribute, PCSR.cpp:222-249, for windows of up to kBigLeaves leaves) --------------
+// One workgroup, out of place through a scratch stretch of its own, two streaming passes with no dependency between
+// chunks: (1) every wave takes 64-slot chunks, ranks their live elements (leaf prefix from the exact leaf counts, kept in
+// LDS, + ballot/popcount inside the leaf), places each at its exact position and fills the null run up to the next
+// element's position — every scratch slot is written exactly once; (2) the scratch stretch is copied back and the leaf
+// counts are rewritten from ballots.  Sentinels are fixed up in pass 1 (fix_sentinel).
+constexpr uint32_t kBigLeaves = 4096;    // leaves per job at most (131072 slots at logN = 32)
+constexpr uint32_t kBigThreads = 1024;
+struct BigShared {
+  uint32_t pref[kBigLeaves + 1];
+  uint32_t wsum[kBigThreads / 64];
+  ChainTable tb;
+};
+PMA_DEV void redistribute_block(const View &v, uint64_t wstart, uint64_t wlen, Edge *scratch, BigShared &sh) {
+  const int lane = wv::lane(), w = wv::wave_in_block();
+  const uint32_t tid = wv::thread_idx(), nthreads = wv::block_dim(), nwaves = nthreads >> 6;
+  const int s = v.g.sh;
+  const uint32_t logN = (uint32_t)v.g.logN;
+  const uint32_t nleaf = (uint32_t)(wlen >> s);
+  const uint32_t lf0 = (uint32_t)(wstart >> s);
+  Edge *items = v.items;
+  // exclusive prefix of the leaf counts: every thread owns a run of `per` consecutive leaves
+  const uint32_t per = (nleaf + nthreads - 1) / nthreads;
+  uint32_t mine = 0;
+  for (uint32_t q = 0; q < per; q++) {
+    const uint32_t i = tid * per + q;
+    if (i < nleaf) mine += v.leafcnt[lf0 + i];
+  }
+  uint32_t incl = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) sh.wsum[w] = incl;
+  wv::block_sync();
+  uint32_t woff = 0, j = 0;
+  for (uint32_t q = 0; q < nwaves; q++) {
+    const uint32_t x = sh.wsum[q];
+    if (q < (uint32_t)w) woff += x;
+    j += x;
+  }
+  {
+    uint32_t run = woff + incl - mine;
+    for (uint32_t q = 0; q < per; q++) {
+      const uint32_t i = tid * per + q;
+      if (i < nleaf) {
+        sh.pref[i] = run;
+        run += v.leafcnt[lf0 + i];
+      }
+    }
+  }
+  ChainSeg sg;
+  const bool single = chain_single(wstart, wlen, j, &sg);  // every aligned window that does not start at slot 0
+  if (!single && j >= 2 && tid == 0) build_chain_table(wstart, wlen, j, &sh.tb);
+  wv::block_sync();
+  const uint64_t wend = wstart + wlen;
+  const uint32_t nchunks = (uint32_t)(wlen >> 6);
+  if (j == 0) {
+    for (uint64_t o = tid; o < wlen; o += nthreads) scratch[o] = null_edge();
+  } else {
+    int hint = 0, hint2 = 0;
+    constexpr int kB = 4;  // chunks requested back to back per wave
+    for (uint32_t c0 = (uint32_t)w * kB; c0 < nchunks; c0 += nwaves * kB) {
+      Edge e[kB];
+#pragma unroll
+      for (int b = 0; b < kB; b++) {
+        e[b] = null_edge();
+        if (c0 + b < nchunks) e[b] = items[wstart + (uint64_t)(c0 + b) * 64 + lane];
+      }
+#pragma unroll
+      for (int b = 0; b < kB; b++) {
+        if (c0 + b >= nchunks) break;
+        const uint32_t off = (c0 + b) * 64u + (uint32_t)lane;
+        const bool nn = e[b].value != 0;
+        const uint64_t m = wv::ballot(nn);
+        if (m == 0) continue;
+        if (nn) {
+          const uint32_t first = (logN >= 64) ? 0u : ((uint32_t)lane & ~(logN - 1u));
+          const uint64_t lmask = (logN >= 64) ? ~0ull : (((1ull << logN) - 1ull) << first);
+          const uint64_t k = (uint64_t)sh.pref[off >> s] + (uint64_t)wv::popc64(m & lmask & ((1ull << lane) - 1ull));
+          uint64_t pos, nxt;
+          if (single) {
+            pos = chain_single_pos(sg, wstart, j, k);
+            nxt = (k + 1 < j) ? chain_single_pos(sg, wstart, j, k + 1) : wend;
+          } else if (j >= 2) {
+            pos = chain_pos(&sh.tb, k, &hint);
+            nxt = (k + 1 < j) ? chain_pos(&sh.tb, k + 1, &hint2) : wend;
+          } else {
+            pos = wstart;
+            nxt = wend;
+          }
+          scratch[pos - wstart] = e[b];
+          for (uint64_t q = pos + 1; q < nxt; q++) scratch[q - wstart] = null_edge();
+          fix_sentinel(v, e[b], (uint32_t)pos);
+        }
+      }
+    }
+  }
+  wv::block_sync();  // (workgroup-scope release/acquire: every wave sees the others' scratch stores)
+  const uint32_t lpc = (logN >= 64) ? 1u : (64u >> s);  // leaves per 64-slot chunk
+  for (uint32_t c = (uint32_t)w; c < nchunks; c += nwaves) {
+    const Edge e = scratch[(uint64_t)c * 64 + lane];
+    items[wstart + (uint64_t)c * 64 + lane] = e;
+    const uint64_t occ = wv::ballot(e.value != 0);
+    if ((uint32_t)lane < lpc) {
+      const uint64_t sub = (logN >= 64) ? occ : ((occ >> ((uint32_t)lane * logN)) & ((1ull << logN) - 1ull));
+      v.leafcnt[((wstart + (uint64_t)c * 64) >> s) + lane] = (uint32_t)wv::popc64(sub);
+    }
+  }
+}
+
 // shift items[index .. gap-1] one slot to the right (slide_right, PCSR.cpp:326-355); gap is null.
 PMA_DEV void slide_right_wave(const View &v, uint32_t index, uint32_t gap) {
   const int lane = wv::lane();
@@ -769,7 +884,21 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
         wl = wh = leaf;
       } else {
         const uint32_t gap_right = occupied ? find_gap_right(v, index + 1, kMaxSlide, true, nul0) : index;
-        const InsertPlan ip = plan_insert(v, index, occupied, c_leaf, gap_right, rr);
+        InsertPlan ip = plan_insert(v, index, occupied, c_leaf, gap_right, rr);
+        // tries > 3 (PCSR.cpp:952-955): the reference gives up on leaf locks, takes the global write lock and runs
+        // insert(..., nullptr) — same slide, same write, but the window comes from POST-insert densities (PCSR.cpp:578-590).
+        // That climb is a function of the leaf counts and of where the slide's gap is, so it is planned here like any
+        // other window instead of sending the update to the exclusive executor (in a structure whose every level sits
+        // close to its density bound almost every multi-level climb ends this way).  Slot N-1 occupied
+        // (PCSR.cpp:992-997: double, re-search) stays exclusive.
+        bool noinfo = false;
+        if (ip.status == PS_GLOBAL_NOINFO && !((uint64_t)index == g.N - 1 && occupied) && g.logN <= 32 &&
+            !(occupied && (gap_right == kMax || (uint64_t)gap_right == g.N))) {
+          noinfo = true;
+          ip.status = PS_OK;
+          ip.gap = occupied ? gap_right : index;
+          ip.max_len = (uint64_t)g.logN;
+        }
         if (ip.status != PS_OK) {
           kind = K_EXCL;
         } else {
@@ -786,13 +915,68 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
           }
           acalls = 1;
           aslots = (uint32_t)wn;
-          if (ip.max_len > (uint64_t)g.logN) {  // PCSR.cpp:592-594
+          bool need_double = false;
+          if (noinfo && ws + wn <= g.N) {
+            // the first density the reference looks at is that of (node_index, logN) AFTER the leaf / 2-leaf pass
+            // (PCSR.cpp:555-564): with a 2-leaf pass that is the evened-out LEFT leaf
+            rec_range(rr, v, (uint32_t)ws, (uint32_t)(ws + wn - 1));
+            uint32_t c = cpost, j2 = 0;
+            if (wn != (uint64_t)g.logN) {
+              const uint32_t l0 = (uint32_t)(ws >> g.sh);
+              j2 = v.leafcnt[l0] + v.leafcnt[l0 + 1u] + ((gleaf == l0 || gleaf == l0 + 1u) ? 1u : 0u);
+              // elements of the evened window that land in its left leaf: exact positions, as redistribute_wave places them
+              uint64_t mypos = ws;
+              const uint32_t k = (uint32_t)lane;
+              if (j2 >= 2) {
+                ChainSeg sg;
+                if (chain_single(ws, wn, j2, &sg)) {
+                  if (k < j2) mypos = chain_single_pos(sg, ws, j2, k);
+                } else {
+                  const double step = chain_step(wn, j2);
+                  double x = chain_top(ws, j2, step);
+                  for (uint32_t t = 0; t + 1 < j2; t++) {
+                    if (k == j2 - 1 - t) mypos = (uint64_t)x;
+                    x = chain_sub(x, step);
+                  }
+                }
+              }
+              c = (uint32_t)wv::popc64(wv::ballot(k < j2 && mypos < ws + (uint64_t)g.logN));
+            }
+            uint64_t node_index = ws, len = (uint64_t)g.logN;
+            int level = g.H;
+            while ((uint64_t)c >= (uint64_t)g.t_up[level]) {
+              len *= 2;
+              if (len > g.N) {
+                need_double = true;
+                break;
+              }
+              level--;
+              const uint64_t new_idx = node_index & ~(len - 1);
+              if (len == wn) {
+                c = j2;  // the 2-leaf window itself (its right leaf was evened by the same pass)
+              } else {
+                const uint64_t half = (new_idx < node_index) ? new_idx : new_idx + len / 2;
+                c += count_window(v, half, len / 2) + (((uint64_t)gleaf >= (half >> g.sh) && (uint64_t)gleaf < ((half + len / 2) >> g.sh)) ? 1u : 0u);
+                rec_range(rr, v, (uint32_t)half, (uint32_t)(half + len / 2 - 1));
+              }
+              node_index = new_idx;
+            }
+            if (!need_double && len > wn) {  // PCSR.cpp:592-594
+              ws = node_index;
+              wn = len;
+              acalls = 2;
+              aslots += (uint32_t)wn;
+            } else if (!need_double && len > (uint64_t)g.logN) {
+              acalls = 2;  // (the climb stopped at the 2-leaf window: the reference rebalances it a second time)
+              aslots += (uint32_t)len;
+            }
+          } else if (ip.max_len > (uint64_t)g.logN) {  // PCSR.cpp:592-594
             ws = ip.node_index_final;
             wn = ip.max_len;
             acalls = 2;
             aslots += (uint32_t)wn;
           }
-          if (wn > kBigWindow || ws + wn > g.N) {
+          if (need_double || wn > v.big_window || ws + wn > g.N) {
             kind = K_EXCL;
           } else {
             kind = K_INSERT;
@@ -810,7 +994,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
         kind = K_NOTFOUND;
       } else {
         const RemovePlan rp = plan_remove(v, index, rr);
-        if (rp.half || rp.wlen > kBigWindow) {
+        if (rp.half || rp.wlen > v.big_window) {
           kind = K_EXCL;
         } else {
           kind = K_REMOVE;
@@ -910,8 +1094,13 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
   return pr;
 }
 
-// apply a planned op whose reservations were validated
-PMA_DEV void apply_op(const View &v, const Op op, const Plan *plan, uint32_t *lds, StatShard *st) {
+// A window too large for one wave is handed to a workgroup (o_big) through the round's job queue: the update's own wave
+// does everything up to the final rebalance (slide, write, counters) and leaves the leaf counts exact.
+struct BigJob {
+  uint32_t wstart, wlen;
+};
+// apply a planned op whose reservations were validated.  defer != nullptr: queue the rebalance instead of running it here.
+PMA_DEV void apply_op(const View &v, const Op op, const Plan *plan, uint32_t *lds, StatShard *st, BigJob *defer = nullptr) {
   const int lane = wv::lane();
   const Geometry &g = v.g;
   const uint32_t kind = plan->kind;
@@ -940,31 +1129,33 @@ PMA_DEV void apply_op(const View &v, const Op op, const Plan *plan, uint32_t *ld
     if (gap != index) slide_right_wave(v, index, gap);
     // the rebalance below recounts every leaf of its window; only a gap that lies beyond the window needs its leaf's
     // count bumped here (a read-modify-write the following fence would otherwise have to wait for)
-    const bool gap_outside = ((uint64_t)gap < (uint64_t)plan->wstart) || ((uint64_t)gap >= (uint64_t)plan->wstart + plan->wlen);
+    const bool gap_outside = defer || ((uint64_t)gap < (uint64_t)plan->wstart) || ((uint64_t)gap >= (uint64_t)plan->wstart + plan->wlen);
     if (lane == 0) {
       v.items[index] = Edge{op.src, op.dst, op.op};
-      if (gap_outside) v.leafcnt[gap >> g.sh] += 1u;
+      if (gap_outside) v.leafcnt[gap >> g.sh] += 1u;  // (a slide moves one element over every leaf boundary it crosses: only the gap's leaf gains)
       wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 1u);
       wv::atomic_add_u64(&st->redistribute_calls, (unsigned long long)plan->alg_calls);
       wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)plan->alg_slots);
       wv::atomic_add_u64(&st->slide_slots, (unsigned long long)(gap - index));
+      if (defer) *defer = BigJob{plan->wstart, plan->wlen};
     }
     wv::fence();
-    redistribute_wave(v, plan->wstart, plan->wlen, lds);
+    if (!defer) redistribute_wave(v, plan->wstart, plan->wlen, lds);
     return;
   }
   if (kind == K_REMOVE) {
     if (lane == 0) {
       v.items[index].value = 0;
       v.items[index].dest = 0;
-      if ((uint64_t)index < (uint64_t)plan->wstart || (uint64_t)index >= (uint64_t)plan->wstart + plan->wlen)
-        v.leafcnt[index >> g.sh] -= 1u;  // (never: the window contains the slot; its leaves are recounted below)
+      if (defer || (uint64_t)index < (uint64_t)plan->wstart || (uint64_t)index >= (uint64_t)plan->wstart + plan->wlen)
+        v.leafcnt[index >> g.sh] -= 1u;  // (in-wave: never — the window contains the slot and its leaves are recounted below)
       wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
       wv::atomic_add_u64(&st->redistribute_calls, (unsigned long long)plan->alg_calls);
       wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)plan->alg_slots);
+      if (defer) *defer = BigJob{plan->wstart, plan->wlen};
     }
     wv::fence();
-    redistribute_wave(v, plan->wstart, plan->wlen, lds);
+    if (!defer) redistribute_wave(v, plan->wstart, plan->wlen, lds);
     return;
   }
 }

@@ -1240,6 +1240,7 @@ struct OptCtl {
   // 4 write leaf read by an earlier update, 5 read leaf written by an earlier update, 6 sentinel located by is moved earlier,
   // 7 sentinel we move is needed earlier, 8 region prefix, 9 growth zone of a deferred reader/writer (pfail), 10 stamp violation
   unsigned long long why[12];
+  uint32_t njobs;  // big-window rebalances queued by this round's o_apply for o_big (reset by o_compact)
 };
 struct OptArgs {
   View v;
@@ -1256,7 +1257,13 @@ struct OptArgs {
   uint32_t round;
   int regshift;
   uint32_t diag;
+  // windows above big_min slots are rebalanced by a workgroup of o_big (job queue + one scratch stretch per workgroup)
+  uint32_t big_min;
+  dev::BigJob *jobs;
+  Edge *bigscratch;
+  uint32_t bigscratch_stride;  // slots per workgroup
 };
+constexpr uint32_t kBigJobs = 256;  // capacity of the round's job queue
 constexpr uint32_t kRegionPadLeaves = 2u;
 constexpr uint32_t kGrowLeaves = 8u;
 constexpr uint32_t OS_PASS = 1u, OS_STAMP_BAD = 2u, OS_COMMITTED = 4u;
@@ -1331,7 +1338,7 @@ PMA_KERNEL void o_plan(OptArgs a) {
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_min_u64(&a.v.wres[leaf], key);
     // an update whose window is already within two levels of the exclusive threshold is likely to turn exclusive
     // once the earlier updates have landed: nothing later may overtake it (soft barrier)
-    if (pr.wlen >= kBigWindow / 4 && lane == 0) wv::atomic_min_u64(&c->gbar[par], key + 1ull);
+    if (pr.wlen >= a.v.big_window / 4 && lane == 0) wv::atomic_min_u64(&c->gbar[par], key + 1ull);
     const uint32_t ml = pr.mv_lo, mh = pr.mv_hi;
     for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_min_u64(&a.v.vw[u], key);
   }
@@ -1378,16 +1385,34 @@ PMA_KERNEL void o_check(OptArgs a) {
   }
   if (strong) {
     const uint32_t wl = h.wleaf_lo, wh = h.wleaf_hi;
-    for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) {
-      if (a.v.wres[leaf] != key) { fail = true; PMA_WHY(3u); }                   // an earlier pending update writes it
-      if (key_earlier(a.v.dres[leaf], tag, idx)) { fail = true; PMA_WHY(2u); }   // an earlier pending duplicate overwrites a slot here
-      if (key_earlier(a.v.rres[leaf], tag, idx)) { fail = true; PMA_WHY(4u); }   // an earlier pending update reads it
-      if (a.wstamp[leaf] > me1 || a.rstamp[leaf] > me1) {  // a LATER update already touched it
-        stamp_bad = true;
-        a.vdbg[4 * wid + 0] = leaf;
-        a.vdbg[4 * wid + 1] = a.wstamp[leaf] > me1 ? a.wstamp[leaf] : a.rstamp[leaf];
-        a.vdbg[4 * wid + 2] = a.wstamp[leaf] > me1 ? 1u : 2u;
+    // (a big window spans thousands of leaves: four leaves per lane are requested together, 20 loads per trip)
+    for (uint32_t base = wl; base <= wh; base += 256u) {
+      unsigned long long kw[4], kd[4], kr[4];
+      uint32_t sw[4], sr[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t leaf = base + (uint32_t)q * 64u + (uint32_t)lane;
+        const bool in = leaf <= wh && leaf >= base;
+        kw[q] = in ? a.v.wres[leaf] : key;
+        kd[q] = in ? a.v.dres[leaf] : ~0ull;
+        kr[q] = in ? a.v.rres[leaf] : ~0ull;
+        sw[q] = in ? a.wstamp[leaf] : 0u;
+        sr[q] = in ? a.rstamp[leaf] : 0u;
       }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t leaf = base + (uint32_t)q * 64u + (uint32_t)lane;
+        if (kw[q] != key) { fail = true; PMA_WHY(3u); }                   // an earlier pending update writes it
+        if (key_earlier(kd[q], tag, idx)) { fail = true; PMA_WHY(2u); }   // an earlier pending duplicate overwrites a slot here
+        if (key_earlier(kr[q], tag, idx)) { fail = true; PMA_WHY(4u); }   // an earlier pending update reads it
+        if (sw[q] > me1 || sr[q] > me1) {  // a LATER update already touched it
+          stamp_bad = true;
+          a.vdbg[4 * wid + 0] = leaf;
+          a.vdbg[4 * wid + 1] = sw[q] > me1 ? sw[q] : sr[q];
+          a.vdbg[4 * wid + 2] = sw[q] > me1 ? 1u : 2u;
+        }
+      }
+      if (wh - base < 256u) break;  // (no wrap-around at the top of the leaf range)
     }
   }
   PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, {
@@ -1516,12 +1541,22 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
     return;
   }
   const Op op = a.ops[idx];
+  // a window too large for one wave goes to a workgroup of o_big: take a queue slot BEFORE touching the state (a full queue
+  // leaves the update pending for the next round)
+  dev::BigJob *job = nullptr;
+  if (kind_strong(kind) && h.wlen > a.big_min && a.jobs) {
+    uint32_t slot = 0;
+    if (lane == 0) slot = wv::atomic_add_u32(&c->njobs, 1u);
+    slot = wv::first(slot);
+    if (slot >= kBigJobs) return;
+    job = &a.jobs[slot];
+  }
 #if defined(PPCSR_SIM)
   if (lane == 0 && getenv("PPCSR_TRACE"))
     fprintf(stderr, "R%u commit idx=%u op=(%u,%u,%u) kind=%u index=%u gap=%u win=(%u,%u) wleaf=[%u,%u] nr=%u\n", a.round, idx, op.src,
             op.dst, op.op, kind, h.index, pl->gap, h.wstart, h.wlen, h.wleaf_lo, h.wleaf_hi, h.nr);
 #endif
-  dev::apply_op(a.v, op, pl, lds_wave, &a.stats[wv::block_idx() & (kStatShards - 1)]);
+  dev::apply_op(a.v, op, pl, lds_wave, &a.stats[wv::block_idx() & (kStatShards - 1)], job);
   const uint32_t me1 = idx + 1u;
   if (kind_strong(kind)) {  // (a duplicate's value overwrite commutes with everything it can be reordered with: no stamp)
     const uint32_t wl = h.wleaf_lo, wh = h.wleaf_hi;
@@ -1657,6 +1692,7 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
     c->hor[par ^ 1u] = nh;
     c->gbar[par ^ 1u] = ~0ull;
     c->gbar[par] = ~0ull;
+    c->njobs = 0;
     const bool done = (new_cn == 0 && new_nf == e1);
     if (done) c->done = 1;
     const uint32_t lowest = new_cn ? *s_first_p : new_nf;
@@ -1678,6 +1714,22 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
 PMA_KERNEL void o_apply(OptArgs a) {
   PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
   o_apply_wave(a, lds[wv::wave_in_block()]);
+}
+
+// the round's queued big-window rebalances, one workgroup each (dev::redistribute_block); launched between o_apply and
+// o_compact with a small fixed grid — a launch that finds the queue empty costs one kernel boundary
+PMA_KERNEL void o_big(OptArgs a) {
+  PMA_SHARED dev::BigShared sh;
+  OptCtl *c = a.ctl;
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  uint32_t nj = c->njobs;
+  if (f_done || f_viol || f_excl || f_err || nj == 0) return;  // (a violation rolls the epoch back anyway)
+  if (nj > kBigJobs) nj = kBigJobs;
+  for (uint32_t jb = wv::block_idx(); jb < nj; jb += wv::grid_dim()) {
+    const dev::BigJob job = a.jobs[jb];
+    dev::redistribute_block(a.v, job.wstart, job.wlen, a.bigscratch + (uint64_t)wv::block_idx() * a.bigscratch_stride, sh);
+    wv::block_sync();  // the shared prefix / table are reused by the next job
+  }
 }
 
 // (Folding the compaction into o_apply's last-finishing workgroup was measured and dropped: the device-scope fences the

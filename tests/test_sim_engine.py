@@ -43,6 +43,9 @@ def sim():
         e.set_option("init_horizon", opts.get("init_horizon", 8))
         e.set_option("rounds_per_sync", opts.get("rounds_per_sync", 2))
         e.set_option("small_batch", opts.get("small_batch", 0))  # keep small streams on the scheduler under test
+        e.set_option("big_grid", opts.get("big_grid", 2))        # (every emulated workgroup of o_big is 1024 fibers)
+        e.set_option("big_min", opts.get("big_min", 512))
+        e.set_option("big_window", opts.get("big_window", 131072))
         return e
     return make
 
@@ -92,6 +95,15 @@ def test_sim_speculative_rounds(sim, name, region):
     st = eng.stats()
     assert eng.check_invariants() == 0
     assert st["rollbacks"] > 0  # the small regions / doublings of these fixtures must exercise the rollback path
+
+
+@pytest.mark.parametrize("big_min,big_window", [(64, 131072), (128, 1024), (512, 4096)])
+def test_sim_big_windows_inside_the_round(sim, big_min, big_window):
+    """windows above big_min slots are rebalanced by a workgroup (o_big) instead of the update's own wave; the hub
+    fixture drives windows up to the whole array, its delete phase shrinks them again"""
+    eng = replay_golden(lambda n, lock: sim(n, lock, mode=1, opt_horizon=128, epoch_ops=4096, region_slots=64, big_min=big_min,
+                                            big_window=big_window), "hub_1e4_insert_then_delete")
+    assert eng.check_invariants() == 0
 
 
 def test_sim_speculative_stats_survive_rollback(sim, streams):
