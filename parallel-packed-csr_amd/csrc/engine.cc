@@ -94,12 +94,17 @@ struct Engine::Impl {
   uint32_t *d_vws = nullptr, *d_vrs = nullptr;  // per-vertex sentinel stamps (capacity n_cap + 1)
   uint32_t *d_wstamp = nullptr, *d_rstamp = nullptr;
   uint32_t mode = 1;             // 0 = strict prefix rounds, 1 = speculative rounds with validated rollback
-  uint32_t epoch_ops = 1u << 20;  // rollback granularity
+  uint32_t epoch_ops = 1u << 20;  // rollback granularity (upper bound)
+  // adaptive epoch length: a rollback throws away everything since the epoch's snapshot, so a stream that provokes
+  // rollbacks (hot vertices whose windows balloon while they wait) is cut into short epochs — kEpochShort updates after a
+  // rollback, doubling again with every epoch that ends cleanly — while a stream that never rolls back keeps one
+  // snapshot per epoch_ops updates
+  uint32_t cur_epoch = 0;
   uint32_t region_slots = 4096;  // per-region prefix rule (>= kBigWindow so a window never leaves its region)
   uint32_t opt_horizon = 6144;  // round width (upper bound when `adaptive` is on); dependency chains bound the number
                                 // of rounds, so a wider horizon mostly re-plans more: 6144 measured best on config #2
   uint32_t start_horizon = 6144;
-  uint32_t adaptive = 0;
+  uint32_t adaptive = 1;
   uint32_t scatter_blocks = 8192;
   uint32_t small_batch = 256;    // batches up to this size take the strict rounds even in speculative mode
   // windows up to this size are rebalanced by the exclusive executor's own wave (64 slots at a time: ~2 us per dependent
@@ -107,7 +112,8 @@ struct Engine::Impl {
   uint32_t excl_in_wave = 4096;
   // speculative rounds: windows up to big_window slots stay inside the round; those above big_min are rebalanced by a
   // workgroup each (o_big, big_grid workgroups, one scratch stretch of big_window slots per workgroup)
-  uint32_t big_window = 131072, big_min = 512, big_grid = 64;
+  uint32_t big_window = 32768, big_min = 512, big_grid = 64;
+  Plan *d_xplan = nullptr;  // read ranges of an exclusive update inside a speculative epoch (validation)
   dev::BigJob *d_jobs = nullptr;
   Edge *d_bigscratch = nullptr;
   uint64_t bigscratch_cap = 0;
@@ -347,6 +353,7 @@ Engine::~Engine() {
   if (p.d_scratch) GPU_DFREE(p.d_scratch);
   if (p.d_scan_state) GPU_DFREE(p.d_scan_state);
   if (p.d_jobs) GPU_DFREE(p.d_jobs);
+  if (p.d_xplan) GPU_DFREE(p.d_xplan);
   if (p.d_bigscratch) GPU_DFREE(p.d_bigscratch);
   for (Impl::Snap *sp : {&p.snap, &p.esnap}) {
     if (sp->v.items) GPU_DFREE(sp->v.items);
@@ -672,8 +679,10 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
   uint64_t e0 = 0;
   uint64_t forced_e1 = 0;  // after a rollback: end the retried epoch right after the update that failed validation
   int retries = 0;
+  constexpr uint32_t kEpochShort = 8192;
+  if (p.cur_epoch == 0 || p.cur_epoch > p.epoch_ops) p.cur_epoch = p.epoch_ops;
   while (e0 < n) {
-    uint64_t e1 = std::min<uint64_t>(e0 + p.epoch_ops, n);
+    uint64_t e1 = std::min<uint64_t>(e0 + p.cur_epoch, n);
     if (forced_e1 > e0 && forced_e1 < e1) e1 = forced_e1;
     if (p.round > 0xFFFF0000u) GCHK(reset_tags(p));
     p.carry_dumped = false;
@@ -696,8 +705,10 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     c.hor[par] = (uint32_t)std::min<uint64_t>(c.cur_horizon, e1 - e0);
     c.e1 = (uint32_t)e1;
     c.max_horizon = p.opt_horizon;
+    c.width_cap = p.opt_horizon;
     c.gbar[0] = c.gbar[1] = ~0ull;
     c.viol_idx = kMax;
+    c.skip = kMax;
     GCHK(gpu::h2d(p.d_octl, p.h_octl, sizeof(OptCtl), p.stream));
     int rs = 0;
     while ((p.region_slots >> rs) > (uint32_t)p.v.g.logN) rs++;
@@ -707,6 +718,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     uint64_t chunk_pending = e1 - e0;
     double chunk_cpr = 0.9 * (double)c.hor[par];
     unsigned long long prev_rounds = 0, prev_committed = 0;
+    uint32_t excl_cooldown = 0;  // chunks to keep short after an exclusive update (the launches behind it in its chunk are wasted)
     while (epoch_open) {
       OptArgs a;
       a.v = p.v;
@@ -734,8 +746,14 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       a.diag = p.diag;
       // grid sized for the horizon the device last reported (it can only shrink within a chunk when fresh
       // updates run out; it never exceeds opt_horizon)
+      // grid: wide enough for the adapted width to grow during the chunk (x1.25 per full-width round), narrow at the tail
       uint32_t gh = p.opt_horizon;
-      if (hint_hor * 2u < gh) gh = std::max<uint32_t>(hint_hor * 2u, 256u);
+      {
+        const uint64_t want = std::max<uint64_t>(1024, 4ull * (c.cur_horizon ? c.cur_horizon : p.opt_horizon));
+        if (want < gh) gh = (uint32_t)want;
+        const uint64_t pend = (chunk_pending + 255) & ~255ull;
+        if (pend < gh) gh = (uint32_t)std::max<uint64_t>(pend, 256);
+      }
       const uint32_t blocks = (gh + 3) / 4;
       if (gh != c.max_horizon) {  // the device must never choose a horizon larger than the launched grid
         GCHK(gpu::h2d(&p.d_octl->max_horizon, &gh, sizeof(uint32_t), p.stream));
@@ -748,6 +766,10 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         const double per_round = std::max(1.0, 0.85 * chunk_cpr);
         const double est = (double)chunk_pending / per_round + 2.0;
         if (est < (double)rounds) rounds = (uint32_t)std::max(2.0, est);
+      }
+      if (excl_cooldown) {
+        rounds = std::min<uint32_t>(rounds, 8u);
+        excl_cooldown--;
       }
       if (p.profile && p.events.size() < 5ull * rounds) {
         const size_t oldn = p.events.size();
@@ -762,9 +784,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         GPU_LAUNCH(p.stream, o_check, blocks, 256, a);
         if (p.profile) p.events[5 * r + 2].record(p.stream);
         GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
-        if (use_big) GPU_LAUNCH(p.stream, o_big, p.big_grid, dev::kBigThreads, a);
         if (p.profile) p.events[5 * r + 3].record(p.stream);
-        GPU_LAUNCH(p.stream, o_compact, 1, 1024, a);
+        GPU_LAUNCH(p.stream, o_compact, 1u + (use_big ? p.big_grid : 0u), 1024, a);  // workgroup 0 compacts, the others rebalance big windows
         if (p.profile) p.events[5 * r + 4].record(p.stream);
       }
       GCHK(gpu::d2h(p.h_octl, p.d_octl, sizeof(OptCtl), p.stream));
@@ -788,11 +809,21 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
                 (unsigned long long)e0, (unsigned long long)e1, c.violation ? "ROLLBACK" : (c.excl ? "exclusive" : "done"), c.rounds, c.committed,
                 c.planned, c.why[0], c.why[1], c.why[2], c.why[3], c.why[4], c.why[5], c.why[6], c.why[7], c.why[8], c.why[9], c.why[10]);
       const uint32_t npar = (p.round + 1) & 1u;
-      // an exclusive update rewrites an unbounded part of the array; if anything LATER has already been
-      // committed (it turned exclusive only after being deferred) the epoch is not serialisable: roll back
-      if (c.excl && !c.violation && c.maxc > c.excl_idx + 1u) {
-        c.violation = 1;
-        c.viol_idx = c.excl_idx;
+      // An exclusive update runs now, alone, in the middle of the epoch: it is the lowest pending update, so it sees exactly
+      // the state sequential execution gives it unless a LATER update was committed earlier on something it reads or
+      // writes — validated with the stamps like every other update (k_exclusive, XValid).  Only a resize (double_list /
+      // half_list rewrite the whole array and its geometry) keeps the blanket rule "nothing later may have been committed"
+      // and ends the epoch; everything else continues it: the update's slot commits as nothing in the next round (K_SKIP).
+      bool excl_resized = false;
+      if (c.excl && !c.violation) {
+        const uint64_t g = c.excl_idx;
+        bool viol = false;
+        int rc = run_exclusive(Op{0, 0, 0}, 0, d_ops, (uint32_t)g, &viol, &excl_resized, c.maxc > c.excl_idx + 1u);
+        if (rc != PPCSR_OK) return rc;
+        if (viol) {
+          c.violation = 1;
+          c.viol_idx = c.excl_idx;
+        }
       }
       if (c.violation) {
         // a later update was committed before an earlier one whose footprint then reached it: roll the epoch back
@@ -806,6 +837,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         GCHK(snap_load(p, p.esnap));
         GCHK(gpu::d2d(p.d_stats, p.d_stats_snap, kStatShards * sizeof(StatShard), p.stream));
         p.st.wasted_rounds += c.rounds;  // (kept apart: `rounds` / `committed` / `planned` describe committed work only)
+        p.cur_epoch = std::min<uint32_t>(p.cur_epoch, std::max<uint32_t>(kEpochShort, std::min<uint32_t>(p.epoch_ops, kEpochShort)));
+        if (p.epoch_ops < kEpochShort) p.cur_epoch = p.epoch_ops;
         const uint64_t cut = (uint64_t)c.viol_idx + 1;
         if (retries < 3 && c.viol_idx != kMax && cut > e0 && cut < e1) {
           retries++;
@@ -818,18 +851,26 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
           forced_e1 = 0;
         }
         epoch_open = false;
-      } else if (c.excl) {
+      } else if (c.excl && excl_resized) {
         p.st.rounds += c.rounds;
-        p.st.committed += c.committed;
+        p.st.committed += c.committed + 1;
         p.st.planned += c.planned;
-        const uint64_t g = c.excl_idx;
-        GCHK(gpu::d2h(p.h_op1, d_ops + g, sizeof(Op), p.stream));
-        GCHK(gpu::sync(p.stream));
-        int rc = run_exclusive(*p.h_op1, 0);
-        if (rc != PPCSR_OK) return rc;
-        e0 = g + 1;
+        e0 = (uint64_t)c.excl_idx + 1;
         retries = 0;
         epoch_open = false;
+      } else if (c.excl) {
+        // the epoch goes on: clear the flag and tell the next round which slot is already done
+        p.h_octl->excl = 0;
+        p.h_octl->skip = c.excl_idx;
+        GCHK(gpu::h2d(&p.d_octl->excl, &p.h_octl->excl, sizeof(uint32_t), p.stream));
+        GCHK(gpu::h2d(&p.d_octl->skip, &p.h_octl->skip, sizeof(uint32_t), p.stream));
+        GCHK(gpu::sync(p.stream));  // (h_octl is the landing buffer of the next chunk's control block)
+        // the launches that were queued behind the exclusive update returned at once: the next round must carry the parity
+        // whose entries the last real round filled in
+        if (((p.round + 1) & 1u) != c.resume_par) p.round++;
+        hint_hor = c.hor[c.resume_par];
+        chunk_pending = (uint64_t)c.carry_n[c.resume_par] + (uint64_t)(c.e1 - c.next_fresh[c.resume_par]);
+        excl_cooldown = 4;
       } else if (c.done) {
         if (getenv("PPCSR_TRACE_EPOCH")) {
           fprintf(stderr, "[ppcsr] epoch [%llu,%llu) rounds=%llu planned=%llu:", (unsigned long long)e0, (unsigned long long)e1,
@@ -843,6 +884,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         e0 = e1;
         retries = 0;
         epoch_open = false;
+        p.cur_epoch = (uint32_t)std::min<uint64_t>(p.epoch_ops, 2ull * p.cur_epoch);
         if (c.cur_horizon) p.start_horizon = c.cur_horizon;  // keep the adapted width for the next epoch
       } else {
         if (const char *tc = getenv("PPCSR_TRACE_CARRY")) {  // debug: who is stuck?  histogram of src over the carry list
@@ -878,21 +920,47 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
   return PPCSR_OK;
 }
 
-int Engine::run_exclusive(Op op, uint32_t flags) {
+int Engine::run_exclusive(Op op, uint32_t flags, const Op *d_ops, uint32_t spec_index, bool *violation, bool *resized, bool later_committed) {
   Impl &p = *p_;
   p.st.exclusive_ops++;
+  if (violation) *violation = false;
+  if (resized) *resized = false;
+  const bool spec = spec_index != kMax;
+  if (spec && !p.d_xplan) GCHK(gpu::dmalloc((void **)&p.d_xplan, sizeof(Plan)));
   for (int attempt = 0; attempt < 8; attempt++) {
-    GPU_LAUNCH(p.stream, k_exclusive, 1, 64, p.v, op, flags, p.d_xout, p.d_stats, p.excl_in_wave);
+    XValid xv;
+    xv.wstamp = p.d_wstamp;
+    xv.rstamp = p.d_rstamp;
+    xv.vws = p.d_vws;
+    xv.scratch_plan = p.d_xplan;
+    xv.me1 = (spec && attempt == 0) ? spec_index + 1u : 0u;  // (a retry follows a doubling: whole-array rule, see the caller)
+    GPU_LAUNCH(p.stream, k_exclusive, 1, 64, p.v, op, d_ops, spec ? spec_index : kMax, flags, p.d_xout, p.d_stats, p.excl_in_wave, xv);
     GCHK(gpu::d2h(p.h_xout, p.d_xout, sizeof(ExclOut), p.stream));
     GCHK(gpu::sync(p.stream));
     GCHK(gpu::last_error());
     const ExclOut x = *p.h_xout;
     switch (x.result) {
       case X_DONE: return PPCSR_OK;
-      case X_NEED_DOUBLE: return resize(p.v.g.N * 2);
-      case X_NEED_HALF: return resize(p.v.g.N / 2);
-      case X_NEED_REDIST: return big_redistribute(x.wstart, x.wlen);
+      case X_VIOLATION:
+        if (violation) *violation = true;
+        return PPCSR_OK;
+      case X_NEED_DOUBLE:
+      case X_NEED_HALF:
+        // double_list / half_list rewrite the whole array and its geometry: inside a speculative epoch they are only
+        // serialisable when nothing later has been committed yet (otherwise: roll back, the retry ends the epoch here)
+        if (spec && later_committed) {
+          if (violation) *violation = true;
+          return PPCSR_OK;
+        }
+        if (resized) *resized = true;
+        return resize(x.result == X_NEED_DOUBLE ? p.v.g.N * 2 : p.v.g.N / 2);
+      case X_NEED_REDIST: return big_redistribute(x.wstart, x.wlen, false);
       case X_DOUBLE_THEN_RETRY: {
+        if (spec && later_committed) {
+          if (violation) *violation = true;
+          return PPCSR_OK;
+        }
+        if (resized) *resized = true;
         int rc = resize(p.v.g.N * 2);
         if (rc != PPCSR_OK) return rc;
         flags |= XF_FORCE_NOINFO | XF_SKIP_COUNT;

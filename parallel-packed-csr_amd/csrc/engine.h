@@ -68,7 +68,10 @@ class Engine {
   Engine();
   int init(uint32_t init_n, uint32_t src_n, int lock_search, int device);
   int run_rounds(const Op *d_ops, uint64_t n);
-  int run_exclusive(Op op, uint32_t flags);
+  // spec_index != kMax: the update sits at that index of d_ops and runs inside a speculative epoch (stamp-validated);
+  // *violation / *resized report what happened
+  int run_exclusive(Op op, uint32_t flags, const Op *d_ops = nullptr, uint32_t spec_index = 0xFFFFFFFFu, bool *violation = nullptr,
+                    bool *resized = nullptr, bool later_committed = false);
   int resize(uint64_t newN);
   int big_redistribute(uint64_t wstart, uint64_t wlen, bool sync = true);
   int rank_scan(const uint32_t *d_cnt, uint64_t nleaves, bool table = false, uint64_t tb_index = 0, uint64_t tb_len = 0);

@@ -50,8 +50,8 @@ PMA_DEV uint32_t lanemask_lt_count(uint64_t m, int lane) { return (uint32_t)wv::
 PMA_DEV uint32_t count_leaves(const View &v, uint32_t leaf_lo, uint32_t nleaves) {
   if (nleaves == 1) return v.leafcnt[leaf_lo];
   uint32_t s = 0;
-#pragma unroll 8
-  for (uint32_t i = (uint32_t)wv::lane(); i < nleaves; i += 64) s += v.leafcnt[leaf_lo + i];  // (independent loads: batched by the unroll)
+#pragma unroll 1  // (batching these loads by unrolling costs the planning kernel 6 -> 4 waves per SIMD: 76 -> 104 VGPRs)
+  for (uint32_t i = (uint32_t)wv::lane(); i < nleaves; i += 64) s += v.leafcnt[leaf_lo + i];
   return wv::reduce_add(s);
 }
 PMA_DEV uint32_t count_window(const View &v, uint64_t start, uint64_t len) {
@@ -924,23 +924,19 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
             if (wn != (uint64_t)g.logN) {
               const uint32_t l0 = (uint32_t)(ws >> g.sh);
               j2 = v.leafcnt[l0] + v.leafcnt[l0 + 1u] + ((gleaf == l0 || gleaf == l0 + 1u) ? 1u : 0u);
-              // elements of the evened window that land in its left leaf: exact positions, as redistribute_wave places them
-              uint64_t mypos = ws;
-              const uint32_t k = (uint32_t)lane;
+              // elements of the evened window that land in its left leaf: the literal position chain (PCSR.cpp:237-247),
+              // at most 63 dependent subtractions, every lane the same (cheap in registers: this path is rare and must
+              // not cost the planning kernel its occupancy)
+              c = (j2 >= 1) ? 1u : 0u;  // element 0 stays on the window's first slot
               if (j2 >= 2) {
-                ChainSeg sg;
-                if (chain_single(ws, wn, j2, &sg)) {
-                  if (k < j2) mypos = chain_single_pos(sg, ws, j2, k);
-                } else {
-                  const double step = chain_step(wn, j2);
-                  double x = chain_top(ws, j2, step);
-                  for (uint32_t t = 0; t + 1 < j2; t++) {
-                    if (k == j2 - 1 - t) mypos = (uint64_t)x;
-                    x = chain_sub(x, step);
-                  }
+                const double step = chain_step(wn, j2);
+                double x = chain_top(ws, j2, step);
+                const uint64_t mid = ws + (uint64_t)g.logN;
+                for (uint32_t t = 0; t + 1 < j2; t++) {
+                  c += ((uint64_t)x < mid) ? 1u : 0u;
+                  x = chain_sub(x, step);
                 }
               }
-              c = (uint32_t)wv::popc64(wv::ballot(k < j2 && mypos < ws + (uint64_t)g.logN));
             }
             uint64_t node_index = ws, len = (uint64_t)g.logN;
             int level = g.H;

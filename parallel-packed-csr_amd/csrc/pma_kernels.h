@@ -51,6 +51,7 @@ PMA_DEV bool kind_writes(uint32_t k) { return k == K_INSERT || k == K_DUP || k =
 // value != 0 and compare `dest`, neither of which changes, so it conflicts with updates that MOVE or rewrite slots of
 // that leaf (same round only; across rounds they commute) but never with readers.  Strong writers move slots.
 PMA_DEV bool kind_strong(uint32_t k) { return k == K_INSERT || k == K_REMOVE; }
+PMA_DEV bool kind_real(uint32_t k) { return k != K_NOOP && k != K_SKIP; }  // has a source vertex and a place in the array
 
 PMA_KERNEL void k_plan(RoundArgs a) {
   Control *c = a.ctl;
@@ -171,17 +172,63 @@ constexpr uint32_t XF_ADD_NODE = 4u;      // op.src = new vertex id, op.dst = sl
 constexpr uint32_t XF_RESEARCH = 8u;      // add_node retry after double_list: search again (PCSR.cpp:539)
 
 
+// Validation of an exclusive update inside a speculative epoch (me1 = stream index + 1, 0 = none): it runs when it is the
+// lowest pending update, so the only thing that can make the epoch non-serialisable is a LATER update that was committed
+// earlier on something this one reads or writes.  Checked exactly as for every other update — the stamps of the leaves it
+// writes (padded by one leaf on both sides: an update that located its range by a sentinel this one moves has read the
+// slot next to it), of the leaves its search and climb read, and of the sentinels it locates its range by.
+struct XValid {
+  const uint32_t *wstamp, *rstamp, *vws;
+  Plan *scratch_plan;  // receives the read ranges of the search
+  uint32_t me1;
+};
+PMA_DEV bool xv_bad_writes(const View &v, const XValid &xv, uint64_t leaf_lo, uint64_t leaf_hi) {
+  if (!xv.me1) return false;
+  const uint64_t nleaves = v.g.N >> v.g.sh;
+  if (leaf_lo > 0) leaf_lo--;
+  if (leaf_hi + 1 < nleaves) leaf_hi++;
+  bool bad = false;
+  for (uint64_t l = leaf_lo + (uint64_t)wv::lane(); l <= leaf_hi; l += 64)
+    if (xv.wstamp[l] > xv.me1 || xv.rstamp[l] > xv.me1) bad = true;
+  return wv::ballot(bad) != 0;
+}
+PMA_DEV bool xv_bad_reads(const View &v, const XValid &xv, const dev::RangeRec &rr, uint32_t src) {
+  if (!xv.me1) return false;
+  bool bad = false;
+  const uint32_t nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
+  for (uint32_t r = 0; r < nr; r++) {
+    const uint32_t lo = xv.scratch_plan->rlo[r], hi = xv.scratch_plan->rhi[r];
+    for (uint32_t l = lo + (uint32_t)wv::lane(); l <= hi; l += 64)
+      if (xv.wstamp[l] > xv.me1) bad = true;
+  }
+  if (wv::lane() == 0 && (rr.sdep & 1u) && xv.vws[src] > xv.me1) bad = true;
+  if (wv::lane() == 1 && (rr.sdep & 2u) && src + 1u < v.g.n && xv.vws[src + 1u] > xv.me1) bad = true;
+  return wv::ballot(bad) != 0;
+}
+
 // in_wave_max: largest window the executor's own wave rebalances; larger ones go back to the host (multi-workgroup kernels)
-PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatShard *st, uint32_t in_wave_max) {
+// ops / op_index: op_index != kMax takes the update from the device-resident stream instead of `op`
+PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uint32_t flags, ExclOut *out, StatShard *st, uint32_t in_wave_max, XValid xv) {
   PMA_SHARED uint32_t lds[3 * kLdsWindow];
   const int lane = wv::lane();
   const Geometry &g = v.g;
   const int sh = g.sh;
   const uint32_t logN = (uint32_t)g.logN;
   uint32_t result = X_DONE, rws = 0, rwl = 0, found = 0;
+  if (op_index != kMax) op = ops[op_index];
   dev::RangeRec rr;
-  rr.plan = nullptr;
+  rr.plan = xv.me1 ? xv.scratch_plan : (Plan *)nullptr;
   rr.nr = 0;
+#define PMA_X_VIOLATION()            \
+  do {                               \
+    if (lane == 0) {                 \
+      out->result = X_VIOLATION;     \
+      out->wstart = 0;               \
+      out->wlen = 0;                 \
+      out->found = 0;                \
+    }                                \
+    return;                          \
+  } while (0)
   const bool add_node = (flags & XF_ADD_NODE) != 0;
   if (op.op != 0 || add_node) {
     Edge elem{op.src, op.dst, op.op};
@@ -205,6 +252,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
     wv::fence();  // every lane has read the slot before lane 0 may overwrite it
     const bool occupied = !is_null(at);
     if (occupied && !is_sentinel(elem) && at.dest == elem.dest) {  // PCSR.cpp:529-532
+      if (xv_bad_reads(v, xv, rr, op.src) || xv_bad_writes(v, xv, index >> sh, index >> sh)) PMA_X_VIOLATION();
       if (lane == 0) {
         v.items[index].value = elem.value;
         wv::atomic_add_u64(&st->duplicates, 1ull);
@@ -234,6 +282,22 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
       if (off_end && gleft == kMax) {
         result = X_UNSUPPORTED;  // no null slot on either side: the reference doubles and slides from slot 0 (PCSR.cpp:378-383)
       } else {
+        {  // validation: search / climb reads, the slide range and the window known so far
+          uint64_t lo = index, hi = off_end ? g.N - 1 : gap;
+          if (off_end && gleft < lo) lo = gleft;
+          uint64_t pws = ((uint64_t)index >> sh) << sh, pwn = logN;
+          if (status == dev::PS_OK && ip.max_len > logN) {
+            pws = ip.node_index_final;
+            pwn = ip.max_len;
+          }
+          if (pws < lo) lo = pws;
+          if (pws + pwn - 1 > hi) hi = pws + pwn - 1;
+          const uint64_t two = ((uint64_t)index) & ~(2ull * logN - 1);  // (the 2-leaf pass of a leaf that becomes full)
+          if (two < lo) lo = two;
+          if (two + 2ull * logN - 1 > hi) hi = two + 2ull * logN - 1;
+          if (hi > g.N - 1) hi = g.N - 1;
+          if (xv_bad_reads(v, xv, rr, op.src) || xv_bad_writes(v, xv, lo >> sh, hi >> sh)) PMA_X_VIOLATION();
+        }
         wv::fence();  // planning reads are complete in every lane before the state is modified
         if (off_end) {
           // The slide ran off the end of the array (PCSR.cpp:347-351).  The reference slides everything back (its
@@ -313,6 +377,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
             wn = len;
             acalls = 2;
             aslots += wn;
+            if (xv_bad_writes(v, xv, ws >> sh, (ws + wn - 1) >> sh)) PMA_X_VIOLATION();  // (the rollback restores what was done so far)
           }
         }
         if (lane == 0) {
@@ -346,6 +411,9 @@ PMA_KERNEL void k_exclusive(View v, Op op, uint32_t flags, ExclOut *out, StatSha
       } else {
         found = 1;
         const dev::RemovePlan rp = dev::plan_remove(v, index, rr);
+        if (xv_bad_reads(v, xv, rr, op.src) ||
+            (!rp.half && xv_bad_writes(v, xv, rp.wstart >> sh, (rp.wstart + rp.wlen - 1) >> sh)))
+          PMA_X_VIOLATION();
         wv::fence();  // planning reads are complete in every lane before the state is modified
         if (lane == 0) {
           v.items[index].value = 0;
@@ -1226,7 +1294,8 @@ struct OptCtl {
   uint32_t carry_n[2], next_fresh[2], hor[2];
   uint32_t e1;  // end of the epoch (exclusive stream index)
   uint32_t violation, excl, done, error;
-  uint32_t max_horizon, excl_idx;
+  uint32_t max_horizon, excl_idx;  // max_horizon: width of the launched grid (the next round's horizon never exceeds it)
+  uint32_t width_cap;              // upper bound of the adaptive width (the engine's opt_horizon)
   uint32_t maxc;  // 1 + largest stream index committed in this epoch
   uint32_t viol_idx;  // smallest stream index whose commit-time validation failed
   uint32_t adaptive;     // 1: adapt cur_horizon (experimental; a fixed width of 6144 measured best on config #2)
@@ -1240,7 +1309,10 @@ struct OptCtl {
   // 4 write leaf read by an earlier update, 5 read leaf written by an earlier update, 6 sentinel located by is moved earlier,
   // 7 sentinel we move is needed earlier, 8 region prefix, 9 growth zone of a deferred reader/writer (pfail), 10 stamp violation
   unsigned long long why[12];
-  uint32_t njobs;  // big-window rebalances queued by this round's o_apply for o_big (reset by o_compact)
+  uint32_t njobs[2];  // big-window rebalances queued by this round's o_apply (by round parity; the next round's entry is reset by o_compact)
+  uint32_t skip;   // stream index the exclusive executor has just run inside this epoch (kMax: none); its slot commits as nothing
+  uint32_t resume_par;  // round parity whose double-buffered entries (hor / carry_n / next_fresh / carry list) are current: the
+                        // launches queued behind an exclusive update return at once and do not flip them
 };
 struct OptArgs {
   View v;
@@ -1312,7 +1384,7 @@ PMA_KERNEL void o_plan(OptArgs a) {
   const uint32_t par = a.round & 1u;
   const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
   const uint32_t *carry = par ? a.carry1 : a.carry0;
-  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error, f_skip = c->skip;
   const uint32_t hor = c->hor[par], cn = c->carry_n[par], nf = c->next_fresh[par];
   const uint32_t cw = carry[wid];  // (requested with the control block; the carry lists are padded to the launch grid)
   if (f_done || f_viol || f_excl || f_err) return;
@@ -1321,9 +1393,22 @@ PMA_KERNEL void o_plan(OptArgs a) {
   const uint32_t idx = (wid < used) ? cw : nf + (wid - used);
   const Op op = a.ops[idx];
   Plan *pl = &a.plans[wid];
+  const int lane = wv::lane();
+  if (idx == f_skip) {  // executed by the exclusive executor in the middle of this epoch: nothing left to do, commits at once
+    if (lane == 0) {
+      a.opidx[wid] = idx;
+      pl->kind = K_SKIP;
+      pl->index = pl->wstart = pl->wlen = pl->nr = pl->nlong = pl->sdep = 0;
+      pl->wleaf_lo = 1;
+      pl->wleaf_hi = 0;
+      pl->mv_lo = 1;
+      pl->mv_hi = 0;
+      pl->sleaf_b = pl->sleaf_e = 0;
+    }
+    return;
+  }
   // the plan record goes to memory for o_check / o_apply; this kernel reserves straight from the registers
   const dev::PlanRegs pr = dev::plan_op(a.v, op, pl);
-  const int lane = wv::lane();
   if (lane == 0) a.opidx[wid] = idx;
   const unsigned long long key = make_key(a.round, idx);
   const uint32_t kind = pr.kind;
@@ -1349,7 +1434,7 @@ PMA_KERNEL void o_plan(OptArgs a) {
     wv::fence();  // (rare) more ranges than lanes, or long ranges: walk the record this wave has just written
     PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, wv::atomic_min_u64(&a.v.rres[leaf], key));
   }
-  if (kind != K_NOOP && op.src < a.v.g.n) {  // readers of the positions of sentinels src and src+1 (only when the result depends on them)
+  if (kind_real(kind) && op.src < a.v.g.n) {  // readers of the positions of sentinels src and src+1 (only when the result depends on them)
     if (lane == 0 && (pr.sdep & 1u)) wv::atomic_min_u64(&a.v.vr[op.src], key);
     if (lane == 1 && (pr.sdep & 2u) && op.src + 1u < a.v.g.n) wv::atomic_min_u64(&a.v.vr[op.src + 1u], key);
   }
@@ -1424,7 +1509,7 @@ PMA_KERNEL void o_check(OptArgs a) {
       a.vdbg[4 * wid + 2] = 3u;
     }
   });
-  if (kind != K_NOOP) {
+  if (kind_real(kind)) {
     const uint32_t src = a.ops[idx].src;
     if (src < a.v.g.n && lane < 2 && ((h.sdep >> lane) & 1u) && src + (uint32_t)lane < a.v.g.n) {  // lane 0: sentinel src, lane 1: sentinel src+1
       const uint32_t u = src + (uint32_t)lane;
@@ -1459,7 +1544,7 @@ PMA_KERNEL void o_check(OptArgs a) {
     }
     if (lane == 0 && w < 12u) wv::atomic_add_u64(&c->why[w], 1ull);
   }
-  if (anyfail && kind != K_NOOP) {
+  if (anyfail && kind_real(kind)) {
     // a deferred update keeps later updates out of its region(s); its footprint may still creep over a region edge
     // by a slide, so the mark is padded by kRegionPadLeaves leaves on both sides
     const uint32_t nleaves = (uint32_t)(a.v.g.N >> a.v.g.sh);
@@ -1502,7 +1587,7 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
   const unsigned long long key = make_key(a.round, idx);
   const uint32_t tag = (uint32_t)(key >> 32);
   const bool writes = kind_writes(kind);
-  if (kind != K_NOOP) {
+  if (kind_real(kind)) {
     uint32_t glo, ghi;
     if (writes) {
       glo = h.wleaf_lo >> a.regshift;
@@ -1546,7 +1631,7 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
   dev::BigJob *job = nullptr;
   if (kind_strong(kind) && h.wlen > a.big_min && a.jobs) {
     uint32_t slot = 0;
-    if (lane == 0) slot = wv::atomic_add_u32(&c->njobs, 1u);
+    if (lane == 0) slot = wv::atomic_add_u32(&c->njobs[par], 1u);
     slot = wv::first(slot);
     if (slot >= kBigJobs) return;
     job = &a.jobs[slot];
@@ -1563,7 +1648,7 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_max_u32(&a.wstamp[leaf], me1);
   }
   PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, wv::atomic_max_u32(&a.rstamp[leaf], me1));
-  if (kind != K_NOOP && op.src < a.v.g.n) {
+  if (kind_real(kind) && op.src < a.v.g.n) {
     if (lane < 2 && ((h.sdep >> lane) & 1u) && op.src + (uint32_t)lane < a.v.g.n) wv::atomic_max_u32(&a.vrs[op.src + (uint32_t)lane], me1);
     if (kind_strong(kind)) {
       const uint32_t ml = h.mv_lo, mh = h.mv_hi;
@@ -1584,7 +1669,7 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
   const uint32_t par = a.round & 1u;
   const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
   const uint32_t hor = c->hor[par], cn = c->carry_n[par], nf = c->next_fresh[par];
-  const uint32_t cur_h = c->cur_horizon, max_h = c->max_horizon, adaptive = c->adaptive, e1 = c->e1;
+  const uint32_t cur_h = c->cur_horizon, max_h = c->max_horizon, wcap = c->width_cap, adaptive = c->adaptive, e1 = c->e1;
   const unsigned long long gb = c->gbar[par];
   const unsigned long long n_rounds = c->rounds, n_committed = c->committed, n_planned = c->planned;
   if (f_done || f_viol || f_excl || f_err) return;
@@ -1675,28 +1760,35 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
   if (tid == 0) {
     const uint32_t new_cn = kept + (cn - used);
     const uint32_t new_nf = nf + (hor - used);
-    // adaptive width: dependency chains bound the number of rounds, so planning far more updates than can commit only
-    // makes every round slower; widen by 1/8 when > 85 % of the round committed, narrow by 1/8 when < 65 % did
-    uint32_t ch = cur_h ? cur_h : max_h;
+    // adaptive width: dependency chains bound the number of commits per round (a hot vertex whose range sits at its
+    // density bounds yields a few hundred disjoint windows per round however many updates are planned), so planning far
+    // more than can commit only makes every round slower — but a round's time grows far slower than its width (~30 us
+    // + ~2.5 us per 1024 updates), so width is only given up when almost nothing of it commits.  Narrow by 1/4 when less
+    // than 10 % of a full-width round committed, widen by 1/4 when more than 30 % did.
+    uint32_t ch = cur_h ? cur_h : wcap;
     if (adaptive && hor >= ch) {  // only full-width rounds carry information about the width
-      if (ncommitted * 100u > hor * 92u) ch += ch / 16u;
-      else if (ncommitted * 100u < hor * 80u) ch -= ch / 16u;
+      if (ncommitted * 100u > hor * 30u) ch += ch / 4u;
+      else if (ncommitted * 100u < hor * 10u) ch -= ch / 4u;
     }
     if (ch < 1024u) ch = 1024u;
-    if (ch > max_h) ch = max_h;
+    if (ch > wcap) ch = wcap;  // (the launch grid — max_h — bounds the next round below, not the adapted width itself: the
+                               // host narrows the grid at the tail of an epoch)
     c->cur_horizon = ch;
     uint32_t nh = new_cn + (e1 - new_nf);
     if (nh > ch) nh = ch;
+    if (nh > max_h) nh = max_h;
     c->carry_n[par ^ 1u] = new_cn;
     c->next_fresh[par ^ 1u] = new_nf;
     c->hor[par ^ 1u] = nh;
     c->gbar[par ^ 1u] = ~0ull;
     c->gbar[par] = ~0ull;
-    c->njobs = 0;
+    c->njobs[par ^ 1u] = 0;
+    c->skip = kMax;
     const bool done = (new_cn == 0 && new_nf == e1);
     if (done) c->done = 1;
     const uint32_t lowest = new_cn ? *s_first_p : new_nf;
     const uint32_t tag = (uint32_t)(make_key(a.round, 0) >> 32);
+    c->resume_par = par ^ 1u;
     if (!done && (uint32_t)(gb >> 32) == tag && (uint32_t)gb == lowest) {
       c->excl = 1;
       c->excl_idx = lowest;
@@ -1716,28 +1808,31 @@ PMA_KERNEL void o_apply(OptArgs a) {
   o_apply_wave(a, lds[wv::wave_in_block()]);
 }
 
-// the round's queued big-window rebalances, one workgroup each (dev::redistribute_block); launched between o_apply and
-// o_compact with a small fixed grid — a launch that finds the queue empty costs one kernel boundary
-PMA_KERNEL void o_big(OptArgs a) {
-  PMA_SHARED dev::BigShared sh;
-  OptCtl *c = a.ctl;
-  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
-  uint32_t nj = c->njobs;
-  if (f_done || f_viol || f_excl || f_err || nj == 0) return;  // (a violation rolls the epoch back anyway)
-  if (nj > kBigJobs) nj = kBigJobs;
-  for (uint32_t jb = wv::block_idx(); jb < nj; jb += wv::grid_dim()) {
-    const dev::BigJob job = a.jobs[jb];
-    dev::redistribute_block(a.v, job.wstart, job.wlen, a.bigscratch + (uint64_t)wv::block_idx() * a.bigscratch_stride, sh);
-    wv::block_sync();  // the shared prefix / table are reused by the next job
-  }
-}
-
 // (Folding the compaction into o_apply's last-finishing workgroup was measured and dropped: the device-scope fences the
 // ticket needs make every workgroup write back its XCD's L2, and the round got 3x slower than with a separate launch.)
+// Workgroup 0: the compaction.  Workgroups 1 .. : the round's queued big-window rebalances, one workgroup per window
+// (dev::redistribute_block) — independent of the compaction (they only finish the rebalance of updates that have already
+// been committed), so they share its launch instead of paying a kernel boundary of their own.
 PMA_KERNEL void o_compact(OptArgs a) {
   PMA_SHARED uint32_t wsum[16];
   PMA_SHARED uint32_t s_first;
-  compact_block<8>(a, wsum, &s_first);
+  PMA_SHARED dev::BigShared sh;
+  if (wv::block_idx() == 0) {
+    compact_block<8>(a, wsum, &s_first);
+    return;
+  }
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  uint32_t nj = c->njobs[par];
+  if (f_done || f_viol || f_excl || f_err || nj == 0) return;  // (a violation rolls the epoch back anyway)
+  if (nj > kBigJobs) nj = kBigJobs;
+  const uint32_t nwg = wv::grid_dim() - 1u, me = wv::block_idx() - 1u;
+  for (uint32_t jb = me; jb < nj; jb += nwg) {
+    const dev::BigJob job = a.jobs[jb];
+    dev::redistribute_block(a.v, job.wstart, job.wlen, a.bigscratch + (uint64_t)me * a.bigscratch_stride, sh);
+    wv::block_sync();  // the shared prefix / table are reused by the next job
+  }
 }
 
 // ---- owner bucketing for the multi-GPU exchange (PPPCSR routing rule, PPPCSR.cpp:46-66) ----------------------------

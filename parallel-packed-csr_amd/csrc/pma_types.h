@@ -64,6 +64,7 @@ enum Kind : uint32_t {
   K_REMOVE = 3,    // edge found: null the slot, one window rebalance
   K_NOTFOUND = 4,  // delete of a missing edge: only num_neighbors-- (PCSR.cpp:747-754)
   K_EXCL = 5,      // must run alone through the exclusive executor (global path, resize, big window)
+  K_SKIP = 6,      // already executed by the exclusive executor inside this epoch: commits as nothing
 };
 
 constexpr int kMaxR = 72;  // read-leaf ranges recorded per op (<= 32 search iterations + <= 32 climb levels + a few)
@@ -110,6 +111,8 @@ enum ExclResult : uint32_t {
   X_NEED_REDIST = 3,        // host must run the multi-workgroup window rebalance on (wstart,wlen)
   X_DOUBLE_THEN_RETRY = 4,  // slot N-1 occupied: double_list(), re-search, insert(..., nullptr) (PCSR.cpp:533-540)
   X_UNSUPPORTED = 5,        // a slide found no null slot on either side (reference: PCSR.cpp:378-383) — never observed
+  X_VIOLATION = 7,          // speculative epoch only: a LATER update has already been committed on something this update reads
+                            // or writes — the epoch must be rolled back (validation by stamps, as for every other update)
   X_WINDOW_BEYOND_ARRAY = 6,  // the 2-leaf rebalance of a full leaf on a ONE-leaf array (N == logN): the reference reads and
                               // writes past the end of its array there (PCSR.cpp:555-557 with len*2 > N) — undefined behaviour
 };

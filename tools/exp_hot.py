@@ -51,6 +51,10 @@ for name, n, core, upd in workloads():
         for k, v in zip(keys, combo):
             e.set_option(k, v)
         e.apply(core)
+        if os.environ.get("EXP_DIAG"):
+            e.set_option("diag", 1)
+        if os.environ.get("EXP_PROF"):
+            e.set_option("profile", 1)
         s0 = e.stats()
         t0 = time.perf_counter()
         e.apply(upd)
@@ -71,4 +75,8 @@ for name, n, core, upd in workloads():
         print(f"{name} {dict(zip(keys, combo))}: core {len(core)} N={s1['N']} | {len(upd)} updates in {s1['last_batch_ms']:.1f} ms device ({wall:.1f} wall) = "
               f"{len(upd) / s1['last_batch_ms'] / 1e3:.2f} M/s | rounds {d['rounds']} (+{d['wasted_rounds']} wasted) commits/round {d['committed'] / max(d['rounds'], 1):.0f} "
               f"replan {d['planned'] / max(d['committed'], 1):.2f} excl {d['exclusive_ops']} bigrb {d['big_redistributes']} rollbacks {d['rollbacks']} syncs {d['round_syncs']} {ok}", flush=True)
+        if os.environ.get("EXP_PROF") and s1["prof_launches"]:
+            L = s1["prof_launches"]
+            print(f"   per launch (us): plan {s1['prof_plan_ms'] / L * 1e3:.1f} check {s1['prof_check_ms'] / L * 1e3:.1f} apply+big {s1['prof_apply_ms'] / L * 1e3:.1f} "
+                  f"compact {s1['prof_compact_ms'] / L * 1e3:.1f} over {L} launches", flush=True)
         e.close()
