@@ -468,6 +468,18 @@ int Engine::set_option(const char *key, int64_t value) {
     p.start_horizon = (uint32_t)value;
     return PPCSR_OK;
   }
+  if (k == "test_block_rebalance") {  // test hook: value = wstart << 32 | wlen; rebalances that window with the workgroup routine
+    const uint64_t ws = (uint64_t)value >> 32, wl = (uint64_t)value & 0xFFFFFFFFull;
+    if (wl < 64 || (wl & (wl - 1)) || ws % wl || ws + wl > p.v.g.N || (wl >> p.v.g.sh) > dev::kBigLeaves) return fail(PPCSR_EINVAL, "bad window");
+    gpu::set_device(device_);
+    Edge *sc = nullptr;
+    GCHK(gpu::dmalloc((void **)&sc, wl * sizeof(Edge)));
+    GPU_LAUNCH(p.stream, k_block_rebalance, 1, dev::kBigThreads, p.v, ws, wl, sc);
+    GCHK(gpu::sync(p.stream));
+    GCHK(gpu::last_error());
+    gpu::dfree(sc);
+    return PPCSR_OK;
+  }
   if (k == "diag") {
     p.diag = value != 0;
     return PPCSR_OK;

@@ -1310,6 +1310,7 @@ struct OptCtl {
   // 7 sentinel we move is needed earlier, 8 region prefix, 9 growth zone of a deferred reader/writer (pfail), 10 stamp violation
   unsigned long long why[12];
   uint32_t njobs[2];  // big-window rebalances queued by this round's o_apply (by round parity; the next round's entry is reset by o_compact)
+  uint32_t jobs_round[2];  // the round that queued them (launches that follow an exclusive / final round must not run them again)
   uint32_t skip;   // stream index the exclusive executor has just run inside this epoch (kMax: none); its slot commits as nothing
   uint32_t resume_par;  // round parity whose double-buffered entries (hor / carry_n / next_fresh / carry list) are current: the
                         // launches queued behind an exclusive update return at once and do not flip them
@@ -1635,6 +1636,7 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
     slot = wv::first(slot);
     if (slot >= kBigJobs) return;
     job = &a.jobs[slot];
+    if (lane == 0) c->jobs_round[par] = a.round;
   }
 #if defined(PPCSR_SIM)
   if (lane == 0 && getenv("PPCSR_TRACE"))
@@ -1810,6 +1812,12 @@ PMA_KERNEL void o_apply(OptArgs a) {
 
 // (Folding the compaction into o_apply's last-finishing workgroup was measured and dropped: the device-scope fences the
 // ticket needs make every workgroup write back its XCD's L2, and the round got 3x slower than with a separate launch.)
+// test hook: one workgroup rebalances one window with the big-window routine (leaf counts must be exact)
+PMA_KERNEL void k_block_rebalance(View v, uint64_t wstart, uint64_t wlen, Edge *scratch) {
+  PMA_SHARED dev::BigShared sh;
+  dev::redistribute_block(v, wstart, wlen, scratch, sh);
+}
+
 // Workgroup 0: the compaction.  Workgroups 1 .. : the round's queued big-window rebalances, one workgroup per window
 // (dev::redistribute_block) — independent of the compaction (they only finish the rebalance of updates that have already
 // been committed), so they share its launch instead of paying a kernel boundary of their own.
@@ -1823,9 +1831,10 @@ PMA_KERNEL void o_compact(OptArgs a) {
   }
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
-  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  // (NOT c->done / c->excl: workgroup 0 sets them during this very launch.  A violation rolls the epoch back anyway.)
+  const uint32_t f_viol = c->violation, f_err = c->error;
   uint32_t nj = c->njobs[par];
-  if (f_done || f_viol || f_excl || f_err || nj == 0) return;  // (a violation rolls the epoch back anyway)
+  if (f_viol || f_err || nj == 0 || c->jobs_round[par] != a.round) return;
   if (nj > kBigJobs) nj = kBigJobs;
   const uint32_t nwg = wv::grid_dim() - 1u, me = wv::block_idx() - 1u;
   for (uint32_t jb = me; jb < nj; jb += nwg) {
