@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip scan / rebalance / consumers / raw-label / zipf legs")
     ap.add_argument("--mode", type=int, default=-1, help="0 strict prefix rounds, 1 speculative rounds (engine default)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
+    ap.add_argument("--markers", action="store_true", help="launch marker kernels around the timed region / isolated kernels (tools/roofline_profile.sh)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' only for functional tests of the N > 1 path on one GPU")
     args = ap.parse_args()
 
@@ -263,9 +264,14 @@ def main():
         if N > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        mark = args.markers and label.startswith("config#") and single
+        if mark:
+            es[0].set_option("marker", 0)
         t_start = time.perf_counter()
         for k in range(warmup, warmup + steps):
             step(k)
+        if mark:
+            es[0].set_option("marker", 1)
         torch.cuda.synchronize()
         if N > 1:
             dist.barrier()
@@ -479,15 +485,24 @@ def main():
         try:
             eng = es[0]
             ms, tot = eng.bench_scan_all()
+            if args.markers:
+                eng.set_option("marker", 6)
             ms, tot = eng.bench_scan_all()
+            if args.markers:
+                eng.set_option("marker", 7)
             stt = eng.stats()
             scan_bytes = 12.0 * stt["N"] + 12.0 * stt["n"] + 4.0 * tot
             extra["neighbour_scan"] = {"edges_per_s": tot / (ms * 1e-3), "ms": ms, "edges": int(tot),
                                        "alg_GBps": scan_bytes / (ms * 1e-3) / 1e9,
                                        "frac_of_peak": scan_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        "partition": 0 if not single else None}
-            for label, w in (("window_rebalance", int(stt["N"])), ("window_rebalance_half", int(stt["N"]) // 2)):
+            for mk, (label, w) in enumerate((("window_rebalance", int(stt["N"])), ("window_rebalance_half", int(stt["N"]) // 2))):
+                if args.markers:
+                    eng.bench_rebalance(w, 1)  # (sizes the scratch array outside the marked section)
+                    eng.set_option("marker", 2 + 2 * mk)
                 rms = eng.bench_rebalance(w, 5)
+                if args.markers:
+                    eng.set_option("marker", 3 + 2 * mk)
                 extra[label] = {"window_slots": w, "ms_per_call": rms, "alg_GBps": 24.0 * w / (rms * 1e-3) / 1e9,
                                 "frac_of_peak": 24.0 * w / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "note": "device time (HIP events) of tile sums + position table + fused scatter/fill"}

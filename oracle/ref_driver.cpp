@@ -17,6 +17,10 @@
 
 #include "PCSR.h"
 #include "PPPCSR.h"
+// the reference's graph-algorithm clients (src/utility/bfs.h:15-36, src/utility/pagerank.h:15-29): header-only templates,
+// instantiated below on the reference PCSR so that their results can be stored as golden vectors
+#include "bfs.h"
+#include "pagerank.h"
 
 namespace {
 // The reference prints on every resize / missing delete; keep stdout clean for callers.
@@ -91,6 +95,18 @@ uint64_t ref_get_neighbourhood(void *h, int src, int *out, uint64_t cap) {
   uint64_t m = v.size() < cap ? v.size() : cap;
   if (out && m) memcpy(out, v.data(), m * sizeof(int));
   return v.size();
+}
+
+// bfs(graph, start): out[n] levels, UINT32_MAX = unreachable.  pagerank(graph, node_values): one push step in fp32.
+void ref_bfs(void *h, uint32_t start, uint32_t *out) {
+  std::vector<uint32_t> r = bfs(*static_cast<PCSR *>(h), start);
+  if (!r.empty()) memcpy(out, r.data(), r.size() * sizeof(uint32_t));
+}
+void ref_pagerank(void *h, const float *node_values, float *out) {
+  PCSR *p = static_cast<PCSR *>(h);
+  std::vector<float> vals(node_values, node_values + p->get_n());
+  std::vector<float> r = pagerank(*p, vals);
+  if (!r.empty()) memcpy(out, r.data(), r.size() * sizeof(float));
 }
 
 // ---- PPPCSR (vertex-range partitioned) -------------------------------------------------------

@@ -480,6 +480,22 @@ int Engine::set_option(const char *key, int64_t value) {
     gpu::dfree(sc);
     return PPCSR_OK;
   }
+  if (k == "marker") {
+    gpu::set_device(device_);
+    uint32_t *np_ = nullptr;
+    switch (value) {
+      case 0: GPU_LAUNCH(p.stream, k_mark_0, 1, 64, np_); break;
+      case 1: GPU_LAUNCH(p.stream, k_mark_1, 1, 64, np_); break;
+      case 2: GPU_LAUNCH(p.stream, k_mark_2, 1, 64, np_); break;
+      case 3: GPU_LAUNCH(p.stream, k_mark_3, 1, 64, np_); break;
+      case 4: GPU_LAUNCH(p.stream, k_mark_4, 1, 64, np_); break;
+      case 5: GPU_LAUNCH(p.stream, k_mark_5, 1, 64, np_); break;
+      case 6: GPU_LAUNCH(p.stream, k_mark_6, 1, 64, np_); break;
+      case 7: GPU_LAUNCH(p.stream, k_mark_7, 1, 64, np_); break;
+      default: return fail(PPCSR_EINVAL, "marker id must be 0..7");
+    }
+    return PPCSR_OK;
+  }
   if (k == "diag") {
     p.diag = value != 0;
     return PPCSR_OK;

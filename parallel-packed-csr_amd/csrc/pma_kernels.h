@@ -1812,6 +1812,13 @@ PMA_KERNEL void o_apply(OptArgs a) {
 
 // (Folding the compaction into o_apply's last-finishing workgroup was measured and dropped: the device-scope fences the
 // ticket needs make every workgroup write back its XCD's L2, and the round got 3x slower than with a separate launch.)
+// markers: empty kernels with distinct names; `set_option("marker", i)` launches k_mark_<i> on the engine's stream so that
+// tools/roofline_summary.py can cut sections (timed region, one isolated rebalance, one scan) out of a rocprofv3 kernel
+// trace / counter collection of bench.py
+#define PMA_MARK(i) PMA_KERNEL void k_mark_##i(uint32_t *p) { if (p && wv::thread_idx() == 0xFFFFFFFFu) *p = i; }
+PMA_MARK(0) PMA_MARK(1) PMA_MARK(2) PMA_MARK(3) PMA_MARK(4) PMA_MARK(5) PMA_MARK(6) PMA_MARK(7)
+#undef PMA_MARK
+
 // test hook: one workgroup rebalances one window with the big-window routine (leaf counts must be exact)
 PMA_KERNEL void k_block_rebalance(View v, uint64_t wstart, uint64_t wlen, Edge *scratch) {
   PMA_SHARED dev::BigShared sh;

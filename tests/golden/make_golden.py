@@ -55,7 +55,35 @@ def run_case(name, n, ops, lock_search=True, checkpoints=8, raw=True, pre=None):
     r.close()
 
 
+def consumers_case():
+    """bfs.h / pagerank.h of the reference run on the reference PCSR: RMAT scale-12 graph with deletes (gapped array),
+    a vertex without neighbours and one whose num_neighbors wrapped below zero (delete of a missing edge: the division by
+    4294967295 is part of the contract).  All dests < n (the reference indexes out[dest] unchecked)."""
+    scale, m = 12, 60000
+    n = 1 << scale
+    s, d = streams.rmat_edges(scale, m, seed=41)
+    ops = streams.adds(s, d)
+    dele = ops[::5].copy()
+    dele[:, 2] = 0
+    extra = np.array([[9, 1, 0], [9, 1, 0]], np.uint32)
+    ops = np.concatenate([ops, dele, extra]).astype(np.uint32)
+    r = RefPCSR(n)
+    r.apply(ops)
+    starts = np.array([0, 1, int(s[777]), n - 1], np.uint32)
+    levels = np.stack([r.bfs(int(x)) for x in starts])
+    vals = (streams.uniform_ints(42, n, 1000).astype(np.float32) / np.float32(7.0)).astype(np.float32)
+    pr = r.pagerank(vals)
+    ones = r.pagerank(np.ones(n, np.float32))
+    path = os.path.join(HERE, "consumers_rmat12.npz")
+    np.savez_compressed(path, n=np.int64(n), ops=ops, starts=starts, levels=levels, node_values=vals, pagerank=pr, pagerank_ones=ones)
+    print(f"consumers_rmat12: n={n} ops={len(ops)} reached from 0: {(levels[0] != 0xFFFFFFFF).sum()} -> {os.path.getsize(path)/1024:.0f} KiB")
+    r.close()
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "consumers":  # only the consumer fixture (the others are unchanged)
+        consumers_case()
+        return
     # (1) DataStructureTest add_remove_edge_1E4_seq: 1e4 inserts on vertex 0 then 1e4 deletes
     m = 10000
     ins = np.stack([np.zeros(m), np.arange(1, m + 1), np.arange(1, m + 1)], 1).astype(np.uint32)

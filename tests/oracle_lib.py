@@ -199,6 +199,9 @@ def ref_lib():
         L.ref_export.argtypes = [c_vp, c_vp, c_vp]
         L.ref_get_neighbourhood.restype = c_u64
         L.ref_get_neighbourhood.argtypes = [c_vp, c_int, c_vp, c_u64]
+        if hasattr(L, "ref_bfs"):
+            L.ref_bfs.argtypes = [c_vp, c_u32, c_vp]
+            L.ref_pagerank.argtypes = [c_vp, c_vp, c_vp]
         L.refp_create.restype = c_vp
         L.refp_create.argtypes = [c_u32, c_u32, c_int, c_int, c_int]
         L.refp_destroy.argtypes = [c_vp]
@@ -235,6 +238,20 @@ class RefPCSR(_State):
     def add_node(self): self.L.ref_add_node(self.h)
     def edge_exists(self, s, d): return bool(self.L.ref_edge_exists(self.h, s, d))
     def get_n(self): return self.L.ref_get_n(self.h)
+
+    def bfs(self, start):
+        """the reference's own template bfs(graph, start) (src/utility/bfs.h:15-36) on the reference PCSR"""
+        out = np.empty(self.get_n(), np.uint32)
+        self.L.ref_bfs(self.h, start, out.ctypes.data)
+        return out
+
+    def pagerank(self, node_values):
+        """the reference's own template pagerank(graph, node_values) (src/utility/pagerank.h:15-29), weight_t = float"""
+        vals = np.ascontiguousarray(node_values, np.float32)
+        assert len(vals) == self.get_n()
+        out = np.empty(len(vals), np.float32)
+        self.L.ref_pagerank(self.h, vals.ctypes.data, out.ctypes.data)
+        return out
     def apply(self, ops):
         a = as_ops(ops)
         self.L.ref_apply(self.h, a.ctypes.data, len(a))

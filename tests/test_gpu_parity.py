@@ -382,6 +382,18 @@ def test_consumers_bfs_pagerank(pkg, streams):
         eng.bfs(n)
 
 
+def test_consumers_golden_from_reference_templates(pkg):
+    """ppcsr_bfs / ppcsr_pagerank against golden vectors produced by the reference's own bfs.h / pagerank.h templates on
+    the reference PCSR (tests/golden/consumers_rmat12.npz): identical levels, PageRank identical bit for bit"""
+    g = golden("consumers_rmat12")
+    eng = pkg.PCSR(int(g["n"]))
+    eng.apply(g["ops"])
+    for i, start in enumerate(g["starts"]):
+        np.testing.assert_array_equal(eng.bfs(int(start)), g["levels"][i])
+    assert eng.pagerank(g["node_values"]).tobytes() == g["pagerank"].tobytes()
+    assert eng.pagerank(np.ones(int(g["n"]), np.float32)).tobytes() == g["pagerank_ones"].tobytes()
+
+
 def test_bucket_ops_device_matches_host_routing(pkg, streams):
     """HIP counting-sort bucketing (the multi-GPU exchange's device side) == torch stable sort == host routine"""
     import importlib.util

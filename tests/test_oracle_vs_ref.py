@@ -79,3 +79,26 @@ def test_edge_values_and_add_node(streams):
     o.apply(ops2)
     r.apply(ops2)
     _same(o, r, "add_node interleaved")
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (reference tree absent)")
+def test_consumer_restatement_vs_reference_templates_rmat(streams):
+    """the reference's bfs.h / pagerank.h templates on the reference PCSR vs tests/helpers.py:reference_consumers on the
+    oracle, on a larger graph than the committed fixture (RMAT scale 14, 200 K edges, deletes)"""
+    from helpers import reference_consumers
+    scale, m = 14, 200_000
+    n = 1 << scale
+    s, d = streams.rmat_edges(scale, m, seed=51)
+    ops = streams.adds(s, d)
+    dele = ops[::6].copy()
+    dele[:, 2] = 0
+    ops = np.concatenate([ops, dele])
+    r, o = RefPCSR(n), Oracle(n)
+    r.apply(ops)
+    o.apply(ops)
+    vals = (streams.uniform_ints(52, n, 1000).astype(np.float32) / np.float32(3.0)).astype(np.float32)
+    for start in (0, 5, int(s[4321])):
+        lv, pr = reference_consumers(o, start, vals)
+        np.testing.assert_array_equal(lv, r.bfs(start))
+    assert pr.tobytes() == r.pagerank(vals).tobytes()
