@@ -312,6 +312,10 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   GPU_LAUNCH(p.stream, k_recount, grid_for((N + 63) / 64, 4), 256, p.v, (uint64_t)0, N);
   GCHK(gpu::sync(p.stream));
   GCHK(gpu::last_error());
+  if (getenv("PPCSR_DEBUG_PTRS"))
+    fprintf(stderr, "[ppcsr] items %p..%p nodes %p..%p leafcnt %p..%p wres %p rres %p dres %p plans %p ctl %p\n", (void *)p.v.items,
+            (void *)(p.v.items + N), (void *)p.v.nodes, (void *)(p.v.nodes + p.n_cap), (void *)p.v.leafcnt, (void *)(p.v.leafcnt + p.leaves_cap),
+            (void *)p.v.wres, (void *)p.v.rres, (void *)p.v.dres, (void *)p.d_plans, (void *)p.d_ctl);
   return PPCSR_OK;
 }
 
@@ -615,11 +619,16 @@ int Engine::run_rounds(const Op *d_ops, uint64_t n) {
       for (uint32_t r = 0; r < chunk_rounds; r++) {
         a.round = ++p.round;
         if (p.profile) p.events[4 * r + 0].record(p.stream);
+        static const bool dbg_sync = getenv("PPCSR_SYNC_DEBUG") != nullptr;
+        if (dbg_sync) fprintf(stderr, "[ppcsr] round %u k_plan\n", a.round);
         GPU_LAUNCH(p.stream, k_plan, blocks, 256, a);
+        if (dbg_sync) { gpu::sync(p.stream); fprintf(stderr, "[ppcsr] round %u k_check\n", a.round); }
         if (p.profile) p.events[4 * r + 1].record(p.stream);
         GPU_LAUNCH(p.stream, k_check, blocks, 256, a);
+        if (dbg_sync) { gpu::sync(p.stream); fprintf(stderr, "[ppcsr] round %u k_apply\n", a.round); }
         if (p.profile) p.events[4 * r + 2].record(p.stream);
         GPU_LAUNCH(p.stream, k_apply, blocks, 256, a);
+        if (dbg_sync) { gpu::sync(p.stream); fprintf(stderr, "[ppcsr] round %u done\n", a.round); }
         if (p.profile) p.events[4 * r + 3].record(p.stream);
       }
       GCHK(gpu::d2h(p.h_ctl, p.d_ctl, sizeof(Control), p.stream));
@@ -962,6 +971,7 @@ int Engine::run_exclusive(Op op, uint32_t flags, const Op *d_ops, uint32_t spec_
     xv.vws = p.d_vws;
     xv.scratch_plan = p.d_xplan;
     xv.me1 = (spec && attempt == 0) ? spec_index + 1u : 0u;  // (a retry follows a doubling: whole-array rule, see the caller)
+    if (getenv("PPCSR_SYNC_DEBUG")) fprintf(stderr, "[ppcsr] k_exclusive op (%u,%u,%u) flags %u attempt %d\n", op.src, op.dst, op.op, flags, attempt);
     GPU_LAUNCH(p.stream, k_exclusive, 1, 64, p.v, op, d_ops, spec ? spec_index : kMax, flags, p.d_xout, p.d_stats, p.excl_in_wave, xv);
     GCHK(gpu::d2h(p.h_xout, p.d_xout, sizeof(ExclOut), p.stream));
     GCHK(gpu::sync(p.stream));

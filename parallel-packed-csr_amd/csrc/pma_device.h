@@ -289,15 +289,15 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
 }
 
 // first null slot in [from, N); returns N if none.  Stops (returns kMax) after `limit` slots.
-// pre / pre_nul: the caller has already loaded the first 64 slots (lane l: slot from + l is null)
-PMA_DEV uint32_t find_gap_right(const View &v, uint32_t from, uint32_t limit, bool pre = false, bool pre_nul = false) {
+// pre / pre_nul / pre_w: the caller has already loaded the first pre_w slots (lane l < pre_w: slot from + l is null)
+PMA_DEV uint32_t find_gap_right(const View &v, uint32_t from, uint32_t limit, bool pre = false, bool pre_nul = false, uint32_t pre_w = 64) {
   const int lane = wv::lane();
   const uint64_t N = v.g.N;
   for (uint64_t base = from; base < N; base += 64) {
     if (base - from > limit) return kMax;
     const uint64_t s = base + (uint64_t)lane;
     bool nul = false;
-    if (pre && base == from) nul = pre_nul;
+    if (pre && base == from && (uint32_t)lane < pre_w) nul = pre_nul;
     else if (s < N) nul = (v.items[s].value == 0);
     const uint64_t m = wv::ballot(nul);
     if (m) return (uint32_t)(base + (uint64_t)wv::ctz64(m));
@@ -872,7 +872,12 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
     }
     const uint32_t c_leaf = v.leafcnt[leaf];
     bool nul0 = false;
-    if (op.op != 0) {
+#if defined(PPCSR_BISECT_GAP64)
+    constexpr uint32_t kGapPre = 64;
+#else
+    constexpr uint32_t kGapPre = 16;  // slots of the gap search requested with this batch (a null within 16 slots in 99.7 % of the cases at density 0.7)
+#endif
+    if (op.op != 0 && (uint32_t)lane < kGapPre) {
       const uint64_t g0 = (uint64_t)index + 1ull + (uint64_t)lane;
       if (g0 < g.N) nul0 = (v.items[g0].value == 0);
     }
@@ -883,7 +888,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
         kind = K_DUP;
         wl = wh = leaf;
       } else {
-        const uint32_t gap_right = occupied ? find_gap_right(v, index + 1, kMaxSlide, true, nul0) : index;
+        const uint32_t gap_right = occupied ? find_gap_right(v, index + 1, kMaxSlide, true, nul0, kGapPre) : index;
         InsertPlan ip = plan_insert(v, index, occupied, c_leaf, gap_right, rr);
         // tries > 3 (PCSR.cpp:952-955): the reference gives up on leaf locks, takes the global write lock and runs
         // insert(..., nullptr) — same slide, same write, but the window comes from POST-insert densities (PCSR.cpp:578-590).
@@ -1013,40 +1018,53 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
     const uint32_t whi = wstart + wlen - 1u;
     const uint32_t hi = (kind == K_INSERT && gap > whi) ? gap : whi;
     uint32_t down = 0, up = 0;
-    // both directions' first 64 vertices are requested together (one round trip for almost every update)
-    uint32_t bdn = 0, bup = 0;
-    const bool vdn = (uint32_t)lane <= op.src;
-    const uint64_t u0 = (uint64_t)op.src + 1ull + (uint64_t)lane;
-    const bool vup = u0 < g.n;
-    if (vdn) bdn = v.nodes[op.src - (uint32_t)lane].beginning;
-    if (vup) bup = v.nodes[u0].beginning;
-    uint32_t beg_lowest = 0;  // beginning of the lowest vertex found inside the range (vertex mv_lo)
-    for (uint32_t base = 0;; base += 64) {  // downwards: src, src-1, ...
-      const uint32_t k = base + (uint32_t)lane;
-      uint32_t bg = bdn;
-      bool in = false;
-      if (base == 0) {
-        in = vdn && bg >= lo;
-      } else if (k <= op.src) {
-        bg = v.nodes[op.src - k].beginning;
-        in = bg >= lo;
-      }
-      const uint64_t m = wv::ballot(in);
-      if (m) beg_lowest = wv::shfl(bg, 63 - __builtin_clzll(m));  // (the in-range vertices are a prefix of the lanes)
-      down += (uint32_t)wv::popc64(m);
-      if (m != ~0ull) break;
+    // both directions' first kW vertices are requested together, kW lanes each (one round trip for almost every update:
+    // a one-leaf window holds a handful of sentinels at most; 64 node records per direction cost 3 KB of fetches per update)
+#if defined(PPCSR_BISECT_W32)
+    constexpr uint32_t kW = 32;
+#else
+    constexpr uint32_t kW = 8;
+#endif
+    uint32_t b0 = 0;
+    bool v0 = false;
+    if ((uint32_t)lane < kW) {
+      v0 = (uint32_t)lane <= op.src;
+      if (v0) b0 = v.nodes[op.src - (uint32_t)lane].beginning;
+    } else if ((uint32_t)lane < 2u * kW) {
+      const uint64_t u = (uint64_t)op.src + 1ull + ((uint64_t)lane - kW);
+      v0 = u < g.n;
+      if (v0) b0 = v.nodes[u].beginning;
     }
-    for (uint32_t base = 0;; base += 64) {  // upwards: src+1, src+2, ...
-      const uint64_t u = (uint64_t)op.src + 1ull + base + (uint64_t)lane;
-      bool in = false;
-      if (base == 0) {
-        in = vup && bup <= hi;
-      } else if (u < g.n) {
-        in = v.nodes[u].beginning <= hi;
+    const uint64_t mdn = wv::ballot((uint32_t)lane < kW && v0 && b0 >= lo);
+    const uint64_t mup = wv::ballot((uint32_t)lane >= kW && (uint32_t)lane < 2u * kW && v0 && b0 <= hi) >> kW;
+    uint32_t beg_lowest = 0;  // beginning of the lowest vertex found inside the range (vertex mv_lo)
+    down = (uint32_t)wv::popc64(mdn);
+    up = (uint32_t)wv::popc64(mup);
+    if (mdn) beg_lowest = wv::shfl(b0, 63 - __builtin_clzll(mdn));  // (the in-range vertices are a prefix of the lanes)
+    if (mdn == ((1ull << kW) - 1ull)) {
+      for (uint32_t base = kW;; base += 64) {  // downwards: src - kW, ...
+        const uint32_t k = base + (uint32_t)lane;
+        uint32_t bg = 0;
+        bool in = false;
+        if (k <= op.src) {
+          bg = v.nodes[op.src - k].beginning;
+          in = bg >= lo;
+        }
+        const uint64_t m = wv::ballot(in);
+        if (m) beg_lowest = wv::shfl(bg, 63 - __builtin_clzll(m));
+        down += (uint32_t)wv::popc64(m);
+        if (m != ~0ull) break;
       }
-      const uint64_t m = wv::ballot(in);
-      up += (uint32_t)wv::popc64(m);
-      if (m != ~0ull) break;
+    }
+    if (mup == ((1ull << kW) - 1ull)) {
+      for (uint32_t base = kW;; base += 64) {  // upwards: src + 1 + kW, ...
+        const uint64_t u = (uint64_t)op.src + 1ull + base + (uint64_t)lane;
+        bool in = false;
+        if (u < g.n) in = v.nodes[u].beginning <= hi;
+        const uint64_t m = wv::ballot(in);
+        up += (uint32_t)wv::popc64(m);
+        if (m != ~0ull) break;
+      }
     }
     mv_lo = op.src + 1u - down;
     mv_hi = op.src + up;

@@ -1347,6 +1347,7 @@ PMA_DEV bool key_earlier(unsigned long long k, uint32_t tag, uint32_t idx) { ret
 // The plan record's header and this lane's read range, requested in ONE batch (and before the kernel's early-exit tests:
 // the per-wave arrays are padded to the launch grid, so the loads are always in bounds).  The round kernels are chains
 // of dependent loads; what can be asked for together is asked for together.
+constexpr int kHeadRanges = 8;
 struct PlanHead {
   uint32_t kind, index, wstart, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, sleaf_b, sleaf_e, nr, nlong, sdep;
   uint32_t my_lo, my_hi;  // lane r: read range r (r < 64)
@@ -1366,13 +1367,15 @@ PMA_DEV PlanHead load_plan_head(const Plan *pl, int lane) {
   h.nr = pl->nr;
   h.nlong = pl->nlong;
   h.sdep = pl->sdep;
-  h.my_lo = pl->rlo[lane];
-  h.my_hi = pl->rhi[lane];
+  // (the first kHeadRanges ranges only: an update records two or three — its search certificate and the leaves of a short
+  // climb — and 64 lanes x 2 words fetched 512 B of a 640-B record for nothing; longer lists are walked from the record)
+  h.my_lo = lane < kHeadRanges ? pl->rlo[lane] : 1u;
+  h.my_hi = lane < kHeadRanges ? pl->rhi[lane] : 0u;
   return h;
 }
 #define PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, LEAFVAR, BODY)                                  \
   do {                                                                                        \
-    if ((h).nr <= 64u && (h).nlong == 0u) {                                                   \
+    if ((h).nr <= (uint32_t)kHeadRanges && (h).nlong == 0u) {                                 \
       if ((uint32_t)(lane) < (h).nr)                                                          \
         for (uint32_t LEAFVAR = (h).my_lo; LEAFVAR <= (h).my_hi; LEAFVAR++) { BODY; }         \
     } else {                                                                                  \

@@ -67,7 +67,7 @@ enum Kind : uint32_t {
   K_SKIP = 6,      // already executed by the exclusive executor inside this epoch: commits as nothing
 };
 
-constexpr int kMaxR = 72;  // read-leaf ranges recorded per op (<= 32 search iterations + <= 32 climb levels + a few)
+constexpr int kMaxR = 72;  // read-leaf ranges recorded per op (search certificate + one or two per level of the density climb + a few)
 
 struct Plan {
   uint32_t kind;

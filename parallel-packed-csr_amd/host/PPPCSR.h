@@ -6,7 +6,9 @@
 // (thread_pool_pppcsr.cpp:121-156).  Thread safety as in PCSR.h.
 #ifndef PPCSR_HOST_PPPCSR_H
 #define PPCSR_HOST_PPPCSR_H
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <iostream>
 #include <memory>
 #include <mutex>
@@ -117,8 +119,14 @@ class PPPCSR {
       if (pending_.empty()) return;
       batch.swap(pending_);
     }
+    const bool timing = std::getenv("PPCSR_CLI_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     check(pppcsr_apply_batch(h_, batch.data(), batch.size()));
+    const auto t1 = std::chrono::steady_clock::now();
     for (auto &p : partitions) p->sync_geometry();
+    if (timing)
+      std::cerr << "[ppcsr_cli] pppcsr_apply_batch(" << batch.size() << ") " << std::chrono::duration<double, std::milli>(t1 - t0).count()
+                << " ms, geometry refresh " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count() << " ms" << std::endl;
   }
   static void check(int rc) {
     if (rc != 0) {  // the reference exits on failure (PCSR.cpp:49-54)
