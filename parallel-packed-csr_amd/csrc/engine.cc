@@ -100,6 +100,8 @@ struct Engine::Impl {
   // rollback, doubling again with every epoch that ends cleanly — while a stream that never rolls back keeps one
   // snapshot per epoch_ops updates
   uint32_t cur_epoch = 0;
+  uint32_t epoch_short = 8192;  // epoch length after a rollback
+  uint32_t epoch_clean = 0, epoch_grow_after = 8;  // clean epochs in a row / how many of them double the length again
   uint32_t region_slots = 4096;  // per-region prefix rule (>= kBigWindow so a window never leaves its region)
   uint32_t opt_horizon = 6144;  // round width (upper bound when `adaptive` is on); dependency chains bound the number
                                 // of rounds, so a wider horizon mostly re-plans more: 6144 measured best on config #2
@@ -124,6 +126,7 @@ struct Engine::Impl {
   bool carry_dumped = false;
   bool partial = false;
   bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
+  uint32_t defer_barrier = 0;  // slots; a deferred update with a window at least this big lets nothing later overtake it (0: off)
   uint32_t diag = 0;     // count, per epoch, why planned updates did not commit (printed to stderr at the end of the epoch)
   std::vector<gpu::Event> events;  // init failed half-way: destructor frees only what exists
 };
@@ -500,6 +503,18 @@ int Engine::set_option(const char *key, int64_t value) {
     }
     return PPCSR_OK;
   }
+  if (k == "epoch_short") {
+    p.epoch_short = (uint32_t)std::max<int64_t>(64, value);
+    return PPCSR_OK;
+  }
+  if (k == "epoch_grow_after") {
+    p.epoch_grow_after = (uint32_t)std::max<int64_t>(1, value);
+    return PPCSR_OK;
+  }
+  if (k == "defer_barrier") {
+    p.defer_barrier = (uint32_t)std::max<int64_t>(0, value);
+    return PPCSR_OK;
+  }
   if (k == "diag") {
     p.diag = value != 0;
     return PPCSR_OK;
@@ -716,7 +731,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
   uint64_t e0 = 0;
   uint64_t forced_e1 = 0;  // after a rollback: end the retried epoch right after the update that failed validation
   int retries = 0;
-  constexpr uint32_t kEpochShort = 8192;
+  const uint32_t kEpochShort = p.epoch_short;
   if (p.cur_epoch == 0 || p.cur_epoch > p.epoch_ops) p.cur_epoch = p.epoch_ops;
   while (e0 < n) {
     uint64_t e1 = std::min<uint64_t>(e0 + p.cur_epoch, n);
@@ -781,6 +796,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       a.vrs = p.d_vrs;
       a.regshift = rs;
       a.diag = p.diag;
+      a.defer_barrier = p.defer_barrier;
       // grid sized for the horizon the device last reported (it can only shrink within a chunk when fresh
       // updates run out; it never exceeds opt_horizon)
       // grid: wide enough for the adapted width to grow during the chunk (x1.25 per full-width round), narrow at the tail
@@ -874,8 +890,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         GCHK(snap_load(p, p.esnap));
         GCHK(gpu::d2d(p.d_stats, p.d_stats_snap, kStatShards * sizeof(StatShard), p.stream));
         p.st.wasted_rounds += c.rounds;  // (kept apart: `rounds` / `committed` / `planned` describe committed work only)
-        p.cur_epoch = std::min<uint32_t>(p.cur_epoch, std::max<uint32_t>(kEpochShort, std::min<uint32_t>(p.epoch_ops, kEpochShort)));
-        if (p.epoch_ops < kEpochShort) p.cur_epoch = p.epoch_ops;
+        p.cur_epoch = std::min<uint32_t>(p.cur_epoch, std::min<uint32_t>(p.epoch_ops, kEpochShort));
+        p.epoch_clean = 0;
         const uint64_t cut = (uint64_t)c.viol_idx + 1;
         if (retries < 3 && c.viol_idx != kMax && cut > e0 && cut < e1) {
           retries++;
@@ -921,7 +937,10 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         e0 = e1;
         retries = 0;
         epoch_open = false;
-        p.cur_epoch = (uint32_t)std::min<uint64_t>(p.epoch_ops, 2ull * p.cur_epoch);
+        if (++p.epoch_clean >= p.epoch_grow_after) {
+          p.cur_epoch = (uint32_t)std::min<uint64_t>(p.epoch_ops, 2ull * p.cur_epoch);
+          p.epoch_clean = 0;
+        }
         if (c.cur_horizon) p.start_horizon = c.cur_horizon;  // keep the adapted width for the next epoch
       } else {
         if (const char *tc = getenv("PPCSR_TRACE_CARRY")) {  // debug: who is stuck?  histogram of src over the carry list

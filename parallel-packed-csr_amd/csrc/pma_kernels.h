@@ -1330,6 +1330,7 @@ struct OptArgs {
   uint32_t round;
   int regshift;
   uint32_t diag;
+  uint32_t defer_barrier;  // 0: off
   // windows above big_min slots are rebalanced by a workgroup of o_big (job queue + one scratch stretch per workgroup)
   uint32_t big_min;
   dev::BigJob *jobs;
@@ -1427,7 +1428,11 @@ PMA_KERNEL void o_plan(OptArgs a) {
     for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_min_u64(&a.v.wres[leaf], key);
     // an update whose window is already within two levels of the exclusive threshold is likely to turn exclusive
     // once the earlier updates have landed: nothing later may overtake it (soft barrier)
-    if (pr.wlen >= a.v.big_window / 4 && lane == 0) wv::atomic_min_u64(&c->gbar[par], key + 1ull);
+    // ... and so is an update that has ALREADY been deferred at least once and whose window is big (a.defer_barrier
+    // slots): its window keeps growing while it waits behind a hot range, and everything committed around it meanwhile
+    // is a candidate for a rollback
+    if ((pr.wlen >= a.v.big_window / 4 || (a.defer_barrier && wid < used && pr.wlen >= a.defer_barrier)) && lane == 0)
+      wv::atomic_min_u64(&c->gbar[par], key + 1ull);
     const uint32_t ml = pr.mv_lo, mh = pr.mv_hi;
     for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_min_u64(&a.v.vw[u], key);
   }
