@@ -58,6 +58,9 @@ typedef struct {
   double prof_plan_ms, prof_check_ms, prof_apply_ms, prof_compact_ms;
   uint64_t prof_launches; /* launches of each of the three round kernels */
   uint64_t wasted_rounds; /* rounds of speculative epochs that were rolled back (not counted in `rounds`) */
+  uint64_t narrow_lost;   /* how often that add_node path was taken */
+  uint64_t narrow;        /* 1: regular structure (parallel rounds); 0: add_node after a doubling has left overlapping vertex ranges
+                             (PCSR.cpp:533-540, 681-703): updates run one per round until a re-check finds the ranges sane again */
 } ppcsr_stats_t;
 
 /* PCSR::PCSR(init_n, src_n, lock_search, domain)  — PCSR.cpp:775-838; `device` replaces the NUMA domain */

@@ -147,6 +147,8 @@ int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out) {
   out->prof_plan_ms = s.prof_plan_ms; out->prof_check_ms = s.prof_check_ms; out->prof_apply_ms = s.prof_apply_ms; out->prof_compact_ms = s.prof_compact_ms;
   out->prof_launches = s.prof_launches;
   out->wasted_rounds = s.wasted_rounds;
+  out->narrow = s.narrow;
+  out->narrow_lost = s.narrow_lost;
   return 0;
 }
 int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value) { H_CHECK(); return ret(h->e, h->e->set_option(key, value)); }

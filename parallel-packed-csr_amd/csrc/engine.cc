@@ -567,6 +567,10 @@ int Engine::apply_batch_device(const Op *d_ops, uint64_t n) {
     const bool small = m <= p.small_batch;
     int rc;
     if (p.v.g.narrow == 0u) {
+      rc = recheck_ranges();  // (cheap next to one-update-per-round execution)
+      if (rc != PPCSR_OK) return rc;
+    }
+    if (p.v.g.narrow == 0u) {
       // The reference's add_node-after-doubling path has left a structure whose vertex ranges overlap (see
       // run_exclusive): footprints computed from sorted, disjoint ranges no longer describe what an update touches, so
       // nothing may run side by side — one update per round, i.e. plain sequential execution of the exact kernels.
@@ -1028,6 +1032,7 @@ int Engine::run_exclusive(Op op, uint32_t flags, const Op *d_ops, uint32_t spec_
           // walk reproduces — the 64-ary narrowing is switched off for good.
           flags |= XF_RESEARCH;
           p.v.g.narrow = 0u;
+          p.st.narrow_lost++;
         }
         break;
       }
@@ -1038,6 +1043,23 @@ int Engine::run_exclusive(Op op, uint32_t flags, const Op *d_ops, uint32_t spec_
     }
   }
   return fail(PPCSR_EINTERNAL, "exclusive executor did not converge");
+}
+
+// add_node after a doubling can drop the new sentinel into another vertex's range (the reference's own behaviour); from
+// then on only sequential execution follows the reference.  But very often the sentinel lands in a sane place — or a later
+// resize sorts things out — and the structure is as regular as ever: check, and leave the sequential regime again.
+int Engine::recheck_ranges() {
+  Impl &p = *p_;
+  if (p.v.g.narrow != 0u) return PPCSR_OK;
+  const unsigned long long zero = 0;
+  *p.h_total = zero;
+  GCHK(gpu::h2d(p.d_total, p.h_total, sizeof(unsigned long long), p.stream));
+  GPU_LAUNCH(p.stream, k_check_ranges, grid_for(std::max<uint32_t>(p.v.g.n, 1u), 4, 16384), 256, p.v, p.d_total);
+  GCHK(gpu::d2h(p.h_total, p.d_total, sizeof(unsigned long long), p.stream));
+  GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
+  if (*p.h_total == 0) p.v.g.narrow = 1u;
+  return PPCSR_OK;
 }
 
 int Engine::ensure_scratch(uint64_t nleaves) {
@@ -1161,7 +1183,7 @@ int Engine::resize(uint64_t newN) {
   if (newN > oldN) p.st.double_calls++; else p.st.half_calls++;
   p.st.redistribute_calls++;
   p.st.redistribute_slots += newN;
-  return PPCSR_OK;
+  return PPCSR_OK;  // (a structure in the sequential regime is re-checked by add_node / apply_batch, not here: the caller may be in the middle of an update)
 }
 
 // window rebalance too large for one wave: leaf-rank scan + exact position table + ONE fused scatter/fill pass into a
@@ -1253,8 +1275,11 @@ int Engine::add_node() {  // PCSR.cpp:681-703
   p.v.g.n = len + 1;
   Op op{len, nd.beginning, sval};
   const int rc = run_exclusive(op, XF_ADD_NODE | XF_FORCE_NOINFO);
-  if (rc != PPCSR_OK) p.v.g.n = len;  // the vertex was not added
-  return rc;
+  if (rc != PPCSR_OK) {
+    p.v.g.n = len;  // the vertex was not added
+    return rc;
+  }
+  return recheck_ranges();
 }
 
 int Engine::edge_exists(uint32_t s, uint32_t d, int *out) {
@@ -1695,6 +1720,7 @@ int Engine::stats(EngineStats *out) {
   s.n = p.v.g.n;
   s.logN = p.v.g.logN;
   s.H = p.v.g.H;
+  s.narrow = p.v.g.narrow;
   for (int i = 0; i < kStatShards; i++) {
     const StatShard &h = p.h_stats[i];
     s.redistribute_calls += h.redistribute_calls;

@@ -27,6 +27,8 @@ struct EngineStats {
   double prof_plan_ms, prof_check_ms, prof_apply_ms, prof_compact_ms;
   uint64_t prof_launches;  // launches of EACH of the three kernels
   uint64_t wasted_rounds;  // rounds of speculative epochs that were rolled back (not part of `rounds`)
+  uint64_t narrow_lost;    // times add_node-after-doubling switched the structure to the sequential regime
+  uint64_t narrow;         // 1: sorted, disjoint vertex ranges (64-ary search narrowing + parallel rounds); 0: sequential regime
 };
 
 class Engine {
@@ -75,6 +77,7 @@ class Engine {
   int resize(uint64_t newN);
   int big_redistribute(uint64_t wstart, uint64_t wlen, bool sync = true);
   int rank_scan(const uint32_t *d_cnt, uint64_t nleaves, bool table = false, uint64_t tb_index = 0, uint64_t tb_len = 0);
+  int recheck_ranges();  // narrow == 0: look whether the vertex ranges are sane again and re-enable narrowing + parallel rounds
   int ensure_scratch(uint64_t nleaves);
   int ensure_tiles(uint64_t ntiles);
   int fail(int code, const std::string &msg);

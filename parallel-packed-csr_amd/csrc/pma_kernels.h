@@ -881,6 +881,47 @@ PMA_KERNEL void k_copy_slots(const Edge *src, Edge *dst, uint64_t len) {
   for (uint64_t i = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); i < total; i += stride) d[i] = s[i];
 }
 
+// Are the vertex ranges still sorted, disjoint and consistent with nodes[]?  One wave per vertex: the node record
+// (beginning / end chain, the sentinel on `beginning`) and every slot of (beginning, end): live slots carry src == vertex,
+// are no sentinels and have strictly ascending dests.  Run after the one event that can break this (add_node after a
+// doubling, PCSR.cpp:533-540 + 681-703): if nothing is wrong, the 64-ary search narrowing and the parallel rounds are valid again.
+PMA_KERNEL void k_check_ranges(View v, unsigned long long *bad) {
+  const int lane = wv::lane();
+  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
+  const uint32_t n = v.g.n;
+  for (uint64_t u = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); u < n; u += wstride) {
+    const Node nd = v.nodes[u];
+    bool wrong = false;
+    const uint64_t want_end = (u + 1 < n) ? (uint64_t)v.nodes[u + 1].beginning : v.g.N - 1;
+    if ((uint64_t)nd.beginning >= v.g.N || (uint64_t)nd.end != want_end || nd.end <= nd.beginning) wrong = true;
+    if (!wrong) {
+      const Edge sn = v.items[nd.beginning];
+      if (sn.src != (uint32_t)u || sn.dest != kMax || sn.value != (u == 0 ? kMax : (uint32_t)u)) wrong = true;
+    }
+    if (!wrong) {
+      uint32_t prev = 0;
+      bool have_prev = false;
+      for (uint64_t base = (uint64_t)nd.beginning + 1; base < nd.end; base += 64) {
+        const uint64_t s = base + (uint64_t)lane;
+        Edge e = null_edge();
+        if (s < nd.end) e = v.items[s];
+        const bool live = s < nd.end && e.value != 0;
+        const uint64_t m = wv::ballot(live);
+        if (live && (e.src != (uint32_t)u || is_sentinel(e))) wrong = true;
+        const uint64_t below = m & ((1ull << lane) - 1ull);
+        const int pl = below ? 63 - __builtin_clzll(below) : 0;
+        const uint32_t pd = wv::shfl(e.dest, pl);
+        if (live && (below ? !(pd < e.dest) : (have_prev && !(prev < e.dest)))) wrong = true;
+        if (m) {
+          prev = wv::shfl(e.dest, 63 - __builtin_clzll(m));
+          have_prev = true;
+        }
+      }
+    }
+    if (wv::ballot(wrong) != 0 && lane == 0) wv::atomic_add_u64(bad, 1ull);
+  }
+}
+
 // ---- read-side kernels (get_neighbourhood PCSR.cpp:901-912, edge_exists :860-869) --------------------------
 PMA_KERNEL void k_edge_exists(View v, uint32_t src, uint32_t dst, ExclOut *out) {
   dev::RangeRec rr;

@@ -160,6 +160,25 @@ def test_api_sequences_found_by_the_fuzzer(pkg, streams, seed):
     assert ok, desc
 
 
+def test_leaves_the_sequential_regime_when_ranges_are_sane(pkg, streams):
+    """the sequential regime (one update per round) entered when add_node hits the reference's
+    re-search-after-doubling path is left again as soon as the device-side range check finds sorted, disjoint, consistent
+    vertex ranges (here the regime is forced by hand on a regular structure); a structure the reference has really
+    corrupted stays sequential (fuzzer seed 2554 above)"""
+    n = 20000
+    ops = streams.random_stream(n, 120000, seed=23, p_delete=0.2)
+    eng, o = pkg.PCSR(n), Oracle(n)
+    eng.apply(ops[:60000])
+    eng.set_option("search_narrow", 0)
+    assert eng.stats()["narrow"] == 0
+    r0 = eng.stats()["rounds"]
+    eng.apply(ops[60000:])
+    o.apply(ops)
+    _same(eng, o, "after leaving the sequential regime")
+    assert eng.stats()["narrow"] == 1
+    assert eng.stats()["rounds"] - r0 < 2000
+
+
 def test_config1_plumbing_case(mk, streams):
     """BASELINE config #1: scale-14 RMAT, 200 000-edge core (seed 1) + 100 000 inserts (seed 2) — the
     reference's own CPU-runnable case, as a slot-by-slot parity test"""

@@ -146,6 +146,22 @@ def test_sim_horizon_options_changed_between_batches(sim, streams):
     _same(e, o)
 
 
+def test_sim_leaves_the_sequential_regime_when_ranges_are_sane(sim, streams):
+    """narrow == 0 (set by add_node after a doubling, here by hand) makes every batch run one update per round; the range
+    check that precedes such a batch finds sorted, disjoint, consistent vertex ranges and switches back"""
+    ops = streams.random_stream(300, 4000, seed=21, p_delete=0.2)
+    e, o = sim(300, mode=1, opt_horizon=128, epoch_ops=2048, region_slots=64), Oracle(300)
+    e.apply(ops[:2000])
+    e.set_option("search_narrow", 0)
+    assert e.stats()["narrow"] == 0
+    r0 = e.stats()["rounds"]
+    e.apply(ops[2000:])
+    o.apply(ops)
+    _same(e, o)
+    assert e.stats()["narrow"] == 1
+    assert e.stats()["rounds"] - r0 < 1000  # (2000 updates one per round would be 2000 rounds)
+
+
 def test_sim_big_window_rebalance(sim, streams):
     """the multi-workgroup rebalance (rank scan + exact position table + fused scatter/fill) on whole-array and
     partial windows, against the reference's redistribute() run by the oracle on the same window"""

@@ -102,7 +102,9 @@ def run_case(pkg, st, seed):
     ei, en = e.state()
     oi, on = o.state()
     ok = ok and e.geometry() == o.geometry() and e.get_n() == o.get_n() and np.array_equal(ei, oi) and np.array_equal(en, on)
-    desc = f"PCSR n0={n} -> n={o.get_n()} steps={steps} lock={lock}{' (stopped at a one-leaf array)' if undefined else ''}"
+    sst = e.stats()
+    desc = (f"PCSR n0={n} -> n={o.get_n()} steps={steps} lock={lock}{' (stopped at a one-leaf array)' if undefined else ''}"
+            f" sequential-regime events {sst.get('narrow_lost', 0)}, regular again: {bool(sst.get('narrow', 1))}")
     e.close()
     o.close()
     return ok, desc
