@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #define PMA_DEV __device__ __forceinline__
 #define PMA_KERNEL __global__
+#define PMA_LAUNCH_BOUNDS(threads, waves_per_simd) __launch_bounds__(threads, waves_per_simd)
 #define PMA_SHARED __shared__
 
 namespace ppcsr {

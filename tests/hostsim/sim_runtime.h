@@ -13,6 +13,7 @@
 
 #define PMA_DEV inline
 #define PMA_KERNEL
+#define PMA_LAUNCH_BOUNDS(threads, waves_per_simd)
 #define PMA_SHARED static
 
 namespace sim {
