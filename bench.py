@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--mode", type=int, default=-1, help="0 strict prefix rounds, 1 speculative rounds (engine default)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     ap.add_argument("--markers", action="store_true", help="launch marker kernels around the timed region / isolated kernels (tools/roofline_profile.sh)")
+    ap.add_argument("--exchange", choices=["torch", "native"], default="torch",
+                    help="carrier of the owner exchange for N > 1: torch.distributed all_to_all_single (RCCL inside PyTorch; default) or "
+                         "the engine library's own RCCL send/recv (pppcsr_exchange_apply; no torch in the data path)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' only for functional tests of the N > 1 path on one GPU")
     args = ap.parse_args()
 
@@ -197,6 +200,10 @@ def main():
         else:
             pp = pkg.PPPCSR(n_global, numDomain=N, partitionsPerDomain=ppr, local=(rank * ppr, ppr, dev_id))
             es = [pp.partition(rank * ppr + q) for q in range(ppr)]
+            if N > 1 and args.exchange == "native":
+                uid = [pkg.PPPCSR.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)  # (bootstrap only: 128 bytes)
+                pp.comm_create(uid[0], N, rank, dev_id)
         for e in es:
             if args.mode >= 0:
                 e.set_option("mode", args.mode)
@@ -223,6 +230,9 @@ def main():
             return
         if N == 1:
             pp.apply_device(ops_dev.data_ptr(), ops_dev.shape[0])  # device bucketing + all partitions concurrently
+            return
+        if args.exchange == "native":
+            pp.exchange_apply(ops_dev.data_ptr(), ops_dev.shape[0], max(my_core, my_batch))
             return
         parts, cnts = exch.exchange_parts(ops_dev, n_global, P, N, dist.group.WORLD)
         parts = [t.to(dev) for t in parts]
@@ -577,7 +587,8 @@ def main():
             "scaling": scaling, "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": wl.name(P, N), "vertices": n_global, "core_edges": core_edges, "updates_per_step": batch,
                        "parallelism": f"{P} partition(s), {ppr} per GPU x {N} GPU(s)"
-                                      + ("" if N == 1 else f", {'RCCL' if args.backend == 'nccl' else args.backend} all-to-all"),
+                                      + ("" if N == 1 else (", native RCCL send/recv (pppcsr_exchange_apply)" if args.exchange == "native" else
+                                                             f", {'RCCL' if args.backend == 'nccl' else args.backend} all-to-all (torch.distributed)")),
                        "N_slots": headline["N_slots"], "logN": headline["logN"],
                        "distinct_update_batches": max(1, min(args.distinct_batches, args.warmup + args.steps)),
                        "semantics": "sequential stream order (bit-exact vs reference -threads=1)"},

@@ -26,6 +26,7 @@ extern "C" {
 
 typedef struct ppcsr_engine *ppcsr_t;   /* one PCSR instance resident on one GPU            */
 typedef struct pppcsr_engine *pppcsr_t; /* vertex-range partitioned set of PCSRs (PPPCSR)   */
+typedef struct pppcsr_comm *pppcsr_comm_t; /* RCCL communicator + stream + staging of the native exchange */
 
 /* reference edge_t (PCSR.h:30-35) and node_t (PCSR.h:18-23): same field order, same 12-byte layout */
 typedef struct { uint32_t src, dest, value; } ppcsr_edge;
@@ -174,6 +175,19 @@ int pppcsr_bucket_ops(uint32_t init_n, uint64_t n_parts, const ppcsr_op *ops, ui
  * owner on `stream` (a hipStream_t, may be NULL); d_counts[p] (device memory, n_parts <= 64 entries) receives the bucket sizes */
 int pppcsr_bucket_ops_device(uint32_t init_n, uint64_t n_parts, const ppcsr_op *d_ops, uint64_t n, ppcsr_op *d_bucketed,
                              uint64_t *d_counts, void *stream);
+
+/* ---- native multi-GPU exchange: what replaces ThreadPoolPPPCSR::submit_* (thread_pool_pppcsr.cpp:96-118) across processes ----
+ * One process per GPU; each holds the partitions of its domain (pppcsr_create_local) and a contiguous block of the global
+ * stream in HBM.  pppcsr_exchange_apply buckets the block by owner (stable), packs one fixed-capacity chunk per peer,
+ * swaps the chunks with grouped ncclSend / ncclRecv on a HIP stream (RCCL over xGMI; ONE collective step with static
+ * sizes), unpacks what it received in source-rank order (= global stream order per partition) and applies every local
+ * partition's subsequence concurrently.  `capacity` = the largest block any rank passes (agreed beforehand).
+ * The 128-byte unique id comes from rank 0 (pppcsr_comm_unique_id) and is handed to the other ranks by the host program
+ * (any bootstrap: a file, MPI, torch.distributed's store).  RCCL is bound at run time (dlopen of librccl.so). */
+int pppcsr_comm_unique_id(void *id_out_128_bytes);
+int pppcsr_comm_create(const void *id_128_bytes, int n_ranks, int rank, int device, pppcsr_comm_t *out);
+int pppcsr_comm_destroy(pppcsr_comm_t c);
+int pppcsr_exchange_apply(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_ops, uint64_t n, uint64_t capacity);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,7 @@ EXPORTED = [
     "pppcsr_edge_exists", "pppcsr_get_neighbourhood", "pppcsr_get_node", "pppcsr_get_n", "pppcsr_add_node",
     "pppcsr_apply_batch", "pppcsr_bucket_ops", "pppcsr_bucket_ops_device",
     "pppcsr_create_local", "pppcsr_apply_batch_device", "pppcsr_apply_parts_device",
+    "pppcsr_comm_unique_id", "pppcsr_comm_create", "pppcsr_comm_destroy", "pppcsr_exchange_apply",
 ]
 
 _LIBS = {}
@@ -131,6 +132,10 @@ def load_library(path=None):
     L.pppcsr_create_local.argtypes = [c_u32, c_int, c_int, c_int, c_u64, c_u64, c_int, ctypes.POINTER(c_vp)]
     L.pppcsr_apply_batch_device.argtypes = [c_vp, c_vp, c_u64]
     L.pppcsr_apply_parts_device.argtypes = [c_vp, c_u64, c_u64, c_vp, c_vp]
+    L.pppcsr_comm_unique_id.argtypes = [c_vp]
+    L.pppcsr_comm_create.argtypes = [c_vp, c_int, c_int, c_int, ctypes.POINTER(c_vp)]
+    L.pppcsr_comm_destroy.argtypes = [c_vp]
+    L.pppcsr_exchange_apply.argtypes = [c_vp, c_vp, c_vp, c_u64, c_u64]
     _LIBS[path] = L
     return L
 
@@ -305,6 +310,9 @@ class PPPCSR:
             raise PpcsrError(f"ppcsr status {rc}: {self.L.ppcsr_last_error().decode()}")
 
     def close(self):
+        if getattr(self, "comm", None) is not None and self.comm.value:
+            self.L.pppcsr_comm_destroy(self.comm)
+            self.comm = None
         if getattr(self, "h", None) and self.h.value:
             self.L.pppcsr_destroy(self.h)
         self.h = None
@@ -370,6 +378,24 @@ class PPPCSR:
     def apply_device(self, dev_ptr, n):
         """global stream resident in HBM (all partitions on that GPU): device bucketing + concurrent per-partition apply"""
         self._chk(self.L.pppcsr_apply_batch_device(self.h, dev_ptr, n))
+
+    # native exchange (RCCL send/recv from the engine library; no torch in the data path)
+    @staticmethod
+    def comm_unique_id(lib=None):
+        L = lib or load_library()
+        buf = ctypes.create_string_buffer(128)
+        rc = L.pppcsr_comm_unique_id(buf)
+        if rc != 0:
+            raise PpcsrError(f"pppcsr_comm_unique_id: status {rc}: {L.ppcsr_last_error().decode()}")
+        return bytes(buf.raw)
+
+    def comm_create(self, unique_id, n_ranks, rank, device):
+        self.comm = c_vp()
+        self._chk(self.L.pppcsr_comm_create(ctypes.c_char_p(unique_id), n_ranks, rank, device, ctypes.byref(self.comm)))
+
+    def exchange_apply(self, dev_ptr, n, capacity):
+        """this rank's block of the global stream (device pointer, n updates): route through RCCL + apply the local partitions"""
+        self._chk(self.L.pppcsr_exchange_apply(self.h, self.comm, dev_ptr, n, capacity))
 
     def apply_parts_device(self, first_part, dev_ptrs, counts):
         """already routed device-resident subsequences, one per partition of [first_part, first_part + len(counts))"""

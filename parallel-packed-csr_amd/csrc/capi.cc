@@ -18,6 +18,15 @@ int capi_set_device(int d);
 int capi_dev_alloc(void **p, size_t bytes);
 int capi_dev_free(void *p);
 int capi_d2h_sync(void *dst, const void *src, size_t bytes);  // on the NULL stream, after whatever it holds
+#if !defined(PPCSR_SIM)
+struct ppcsr_xchg;
+int capi_xchg_unique_id(void *out128, std::string *err);
+int capi_xchg_create(const void *id128, int nranks, int rank, int device, ppcsr_xchg **out, std::string *err);
+int capi_xchg_destroy(ppcsr_xchg *x);
+int capi_xchg_route(ppcsr_xchg *x, uint32_t init_n, uint32_t n_parts, const ppcsr::Op *d_ops, uint64_t n, uint64_t cap, const ppcsr::Op **out_ptrs,
+                    uint64_t *out_counts);
+const char *capi_xchg_error(ppcsr_xchg *x);
+#endif
 
 static thread_local std::string g_last_error;
 
@@ -439,5 +448,56 @@ int pppcsr_apply_batch_device(pppcsr_t h, const ppcsr_op *d_ops, uint64_t n) {
   }
   return apply_parts(h, 0, P, ptrs.data(), counts.data(), true);
 }
+
+// ---- native exchange: RCCL send/recv on a HIP stream, no torch in the data path (thread_pool_pppcsr.cpp:96-118 replaced) ----
+#if !defined(PPCSR_SIM)
+int pppcsr_comm_unique_id(void *id_out_128_bytes) {
+  if (!id_out_128_bytes) return bad("null output");
+  std::string msg;
+  const int rc = capi_xchg_unique_id(id_out_128_bytes, &msg);
+  if (rc != 0) g_last_error = msg;
+  return rc;
+}
+int pppcsr_comm_create(const void *id_128_bytes, int n_ranks, int rank, int device, pppcsr_comm_t *out) {
+  if (!id_128_bytes || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return bad("bad communicator arguments");
+  *out = nullptr;
+  std::string msg;
+  ppcsr_xchg *x = nullptr;
+  const int rc = capi_xchg_create(id_128_bytes, n_ranks, rank, device, &x, &msg);
+  if (rc != 0) {
+    g_last_error = msg;
+    return rc;
+  }
+  *out = reinterpret_cast<pppcsr_comm_t>(x);
+  return 0;
+}
+int pppcsr_comm_destroy(pppcsr_comm_t c) { return capi_xchg_destroy(reinterpret_cast<ppcsr_xchg *>(c)); }
+int pppcsr_exchange_apply(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_ops, uint64_t n, uint64_t capacity) {
+  PP_CHECK();
+  if (!c) return bad("null communicator");
+  ppcsr_xchg *x = reinterpret_cast<ppcsr_xchg *>(c);
+  const uint64_t P = h->parts.size();
+  uint64_t first = P, nlocal = 0;
+  for (uint64_t k = 0; k < P; k++)
+    if (h->parts[k]) {
+      if (first == P) first = k;
+      nlocal++;
+    }
+  if (nlocal == 0 || nlocal > 64) return bad("no resident partitions");
+  std::vector<const ppcsr::Op *> ptrs(nlocal);
+  std::vector<uint64_t> counts(nlocal);
+  int rc = capi_xchg_route(x, h->init_n, (uint32_t)P, reinterpret_cast<const ppcsr::Op *>(d_ops), n, capacity, ptrs.data(), counts.data());
+  if (rc != 0) {
+    g_last_error = capi_xchg_error(x);
+    return rc;
+  }
+  return apply_parts(h, first, nlocal, reinterpret_cast<const ppcsr_op *const *>(ptrs.data()), counts.data(), true);
+}
+#else
+int pppcsr_comm_unique_id(void *) { return bad("no RCCL in the CPU emulator build"); }
+int pppcsr_comm_create(const void *, int, int, int, pppcsr_comm_t *) { return bad("no RCCL in the CPU emulator build"); }
+int pppcsr_comm_destroy(pppcsr_comm_t) { return 0; }
+int pppcsr_exchange_apply(pppcsr_t, pppcsr_comm_t, const ppcsr_op *, uint64_t, uint64_t) { return bad("no RCCL in the CPU emulator build"); }
+#endif
 
 }  // extern "C"

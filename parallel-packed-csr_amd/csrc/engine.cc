@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <vector>
 #include <chrono>
 
@@ -1848,6 +1849,177 @@ int bucket_ops_device(uint32_t init_n, uint32_t n_parts, const Op *d_ops, uint64
 }
 
 }  // namespace ppcsr
+
+// ---- native RCCL exchange (include/ppcsr.h: pppcsr_comm_*, pppcsr_exchange_apply) --------------------------------------
+// RCCL is bound at run time (dlopen): the engine library itself has no link dependency on it, and a process that already
+// holds an RCCL (PyTorch's) shares that instance through the SONAME.
+#if !defined(PPCSR_SIM)
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct Rccl {
+  void *lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool ok = false;
+};
+Rccl &rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (r.lib) {
+#define PPCSR_SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.lib, "nccl" #f))
+      PPCSR_SYM(GetUniqueId); PPCSR_SYM(CommInitRank); PPCSR_SYM(CommDestroy); PPCSR_SYM(GroupStart); PPCSR_SYM(GroupEnd);
+      PPCSR_SYM(Send); PPCSR_SYM(Recv); PPCSR_SYM(GetErrorString);
+#undef PPCSR_SYM
+      r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv;
+    }
+  }
+  return r;
+}
+}  // namespace
+struct ppcsr_xchg {  // one communicator + its stream and staging buffers
+  ncclComm_t comm = nullptr;
+  int nranks = 0, rank = 0, device = 0;
+  gpu::stream_t stream{};
+  ppcsr::Op *d_bucketed = nullptr, *d_send = nullptr, *d_recv = nullptr, *d_out = nullptr;
+  unsigned long long *d_counts = nullptr, *d_seg = nullptr;
+  uint64_t cap_rows = 0, out_cap = 0, bucket_cap = 0;
+  ppcsr::Op *h_hdr = nullptr;            // pinned: the received headers
+  unsigned long long *h_seg = nullptr;  // pinned: segment table for the unpack kernel
+  std::string err;
+};
+int capi_xchg_unique_id(void *out128, std::string *err) {
+  Rccl &r = rccl();
+  if (!r.ok) { if (err) *err = "RCCL (librccl.so) could not be loaded"; return ppcsr::PPCSR_EHIP; }
+  ncclUniqueId id;
+  const ncclResult_t e = r.GetUniqueId(&id);
+  if (e != ncclSuccess) { if (err) *err = std::string("ncclGetUniqueId: ") + r.GetErrorString(e); return ppcsr::PPCSR_EHIP; }
+  memcpy(out128, &id, sizeof(id));
+  return 0;
+}
+int capi_xchg_create(const void *id128, int nranks, int rank, int device, ppcsr_xchg **out, std::string *err) {
+  Rccl &r = rccl();
+  if (!r.ok) { if (err) *err = "RCCL (librccl.so) could not be loaded"; return ppcsr::PPCSR_EHIP; }
+  if (gpu::set_device(device)) { if (err) *err = "hipSetDevice failed"; return ppcsr::PPCSR_EHIP; }
+  std::unique_ptr<ppcsr_xchg> x(new ppcsr_xchg());
+  x->nranks = nranks;
+  x->rank = rank;
+  x->device = device;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  const ncclResult_t e = r.CommInitRank(&x->comm, nranks, id, rank);
+  if (e != ncclSuccess) { if (err) *err = std::string("ncclCommInitRank: ") + r.GetErrorString(e); return ppcsr::PPCSR_EHIP; }
+  if (gpu::stream_create(&x->stream)) { if (err) *err = "hipStreamCreate failed"; return ppcsr::PPCSR_EHIP; }
+  *out = x.release();
+  return 0;
+}
+int capi_xchg_destroy(ppcsr_xchg *x) {
+  if (!x) return 0;
+  gpu::set_device(x->device);
+  gpu::sync(x->stream);
+  if (x->comm) rccl().CommDestroy(x->comm);
+  for (void *p : {(void *)x->d_bucketed, (void *)x->d_send, (void *)x->d_recv, (void *)x->d_out, (void *)x->d_counts, (void *)x->d_seg})
+    if (p) gpu::dfree(p);
+  if (x->h_hdr) gpu::hfree(x->h_hdr);
+  if (x->h_seg) gpu::hfree(x->h_seg);
+  gpu::stream_destroy(x->stream);
+  delete x;
+  return 0;
+}
+// bucket this rank's block by owner partition, pack one fixed-capacity chunk per peer, swap the chunks with grouped
+// ncclSend / ncclRecv on the exchange stream (ONE collective step, static sizes, nothing read back before it), read the
+// received headers, unpack into one contiguous stream per local partition (source ranks in order).  out_ptrs / out_counts
+// (ppr entries) describe the result, which stays valid until the next call.
+int capi_xchg_route(ppcsr_xchg *x, uint32_t init_n, uint32_t n_parts, const ppcsr::Op *d_ops, uint64_t n, uint64_t cap,
+                    const ppcsr::Op **out_ptrs, uint64_t *out_counts) {
+  using namespace ppcsr;
+  Rccl &r = rccl();
+  auto failm = [&](const std::string &m) { x->err = m; return (int)PPCSR_EHIP; };
+  const uint32_t world = (uint32_t)x->nranks;
+  if (n_parts % world || n_parts > kMaxParts) return failm("partitions must be a multiple of the ranks (and at most 64)");
+  const uint32_t ppr = n_parts / world, hrows = (ppr + 2) / 3;
+  if (n > cap) return failm("block larger than the agreed capacity");
+  const uint64_t rows = cap + hrows;
+  if (gpu::set_device(x->device)) return failm("hipSetDevice failed");
+  if (x->cap_rows < rows) {
+    for (void *p : {(void *)x->d_send, (void *)x->d_recv}) if (p) gpu::dfree(p);
+    x->d_send = x->d_recv = nullptr;
+    x->cap_rows = 0;
+    if (gpu::dmalloc((void **)&x->d_send, (uint64_t)world * rows * sizeof(Op)) || gpu::dmalloc((void **)&x->d_recv, (uint64_t)world * rows * sizeof(Op)))
+      return failm("out of device memory (exchange chunks)");
+    x->cap_rows = rows;
+  }
+  if (x->bucket_cap < std::max<uint64_t>(n, 1)) {
+    if (x->d_bucketed) gpu::dfree(x->d_bucketed);
+    x->d_bucketed = nullptr;
+    if (gpu::dmalloc((void **)&x->d_bucketed, std::max<uint64_t>(n, 1) * sizeof(Op))) return failm("out of device memory");
+    x->bucket_cap = std::max<uint64_t>(n, 1);
+  }
+  if (!x->d_counts && gpu::dmalloc((void **)&x->d_counts, kMaxParts * sizeof(unsigned long long))) return failm("out of device memory");
+  if (!x->d_seg && gpu::dmalloc((void **)&x->d_seg, 3ull * kMaxParts * kMaxParts * sizeof(unsigned long long))) return failm("out of device memory");
+  if (!x->h_hdr && gpu::hmalloc((void **)&x->h_hdr, (uint64_t)kMaxParts * 32 * sizeof(Op))) return failm("out of pinned memory");
+  if (!x->h_seg && gpu::hmalloc((void **)&x->h_seg, 3ull * kMaxParts * kMaxParts * sizeof(unsigned long long))) return failm("out of pinned memory");
+  std::string msg;
+  int rc = bucket_ops_device(init_n, n_parts, d_ops, n, x->d_bucketed, x->d_counts, (void *)x->stream, &msg);
+  if (rc != PPCSR_OK) return failm(msg);
+  GPU_LAUNCH(x->stream, k_xchg_pack, std::max<uint64_t>(1, std::min<uint64_t>(2048, (n + 255) / 256)), 256, (const Op *)x->d_bucketed,
+             (const unsigned long long *)x->d_counts, n, n_parts, ppr, rows, hrows, x->d_send);
+  ncclResult_t e = r.GroupStart();
+  for (uint32_t peer = 0; peer < world && e == ncclSuccess; peer++) {
+    e = r.Send(x->d_send + (uint64_t)peer * rows, rows * sizeof(Op), ncclChar, (int)peer, x->comm, x->stream);
+    if (e == ncclSuccess) e = r.Recv(x->d_recv + (uint64_t)peer * rows, rows * sizeof(Op), ncclChar, (int)peer, x->comm, x->stream);
+  }
+  const ncclResult_t e2 = r.GroupEnd();
+  if (e != ncclSuccess || e2 != ncclSuccess) return failm(std::string("RCCL send/recv: ") + r.GetErrorString(e != ncclSuccess ? e : e2));
+  for (uint32_t src = 0; src < world; src++)  // the headers: world x hrows rows of 12 B
+    if (gpu::d2h(x->h_hdr + (uint64_t)src * hrows, x->d_recv + (uint64_t)src * rows, hrows * sizeof(Op), x->stream)) return failm("header copy failed");
+  if (gpu::sync(x->stream)) return failm("exchange stream failed");
+  // segment table: partition-major, source-minor
+  unsigned long long total = 0;
+  unsigned long long *ssrc = x->h_seg, *sdst = x->h_seg + kMaxParts * kMaxParts, *slen = x->h_seg + 2 * kMaxParts * kMaxParts;
+  std::vector<unsigned long long> part_first(ppr, 0);
+  for (uint32_t q = 0; q < ppr; q++) {
+    part_first[q] = total;
+    for (uint32_t src = 0; src < world; src++) {
+      const uint32_t *hdr = reinterpret_cast<const uint32_t *>(x->h_hdr + (uint64_t)src * hrows);
+      unsigned long long before = 0;
+      for (uint32_t q2 = 0; q2 < q; q2++) before += hdr[q2];
+      const uint32_t sgi = q * world + src;
+      ssrc[sgi] = (unsigned long long)src * rows + hrows + before;
+      sdst[sgi] = total;
+      slen[sgi] = hdr[q];
+      total += hdr[q];
+    }
+    out_counts[q] = total - part_first[q];
+  }
+  if (x->out_cap < std::max<unsigned long long>(total, 1)) {
+    if (x->d_out) gpu::dfree(x->d_out);
+    x->d_out = nullptr;
+    if (gpu::dmalloc((void **)&x->d_out, std::max<unsigned long long>(total, 1) * sizeof(Op))) return failm("out of device memory");
+    x->out_cap = std::max<unsigned long long>(total, 1);
+  }
+  if (gpu::h2d(x->d_seg, x->h_seg, 3ull * kMaxParts * kMaxParts * sizeof(unsigned long long), x->stream)) return failm("segment table copy failed");
+  GPU_LAUNCH(x->stream, k_xchg_unpack, world * ppr, 1024, (const Op *)x->d_recv, rows, hrows, world, ppr, (const unsigned long long *)x->d_seg,
+             (const unsigned long long *)(x->d_seg + kMaxParts * kMaxParts), (const unsigned long long *)(x->d_seg + 2 * kMaxParts * kMaxParts), x->d_out);
+  if (gpu::sync(x->stream)) return failm("exchange stream failed");
+  if (gpu::last_error()) return failm("exchange kernels failed");
+  for (uint32_t q = 0; q < ppr; q++) out_ptrs[q] = x->d_out + part_first[q];
+  return 0;
+}
+const char *capi_xchg_error(ppcsr_xchg *x) { return x ? x->err.c_str() : ""; }
+#endif
 
 int gpu_device_count_for_capi(int *n) { return gpu::device_count(n); }
 int capi_set_device(int d) { return gpu::set_device(d) ? ppcsr::PPCSR_EHIP : 0; }

@@ -2011,4 +2011,48 @@ PMA_KERNEL void k_bucket_scatter(const Op *ops, uint64_t n, uint32_t part_size, 
   }
 }
 
+// ---- native exchange (pppcsr_exchange_apply): fixed-capacity chunks, one per peer ------------------------------------
+// chunk layout (rows of 12 B): [hrows header rows holding the ppr bucket sizes | the peer's ppr buckets back to back | padding]
+// k_xchg_pack: bucketed ops (grouped by partition) -> send chunks; counts[P] on the device, nothing read back by the host
+PMA_KERNEL void k_xchg_pack(const Op *bucketed, const unsigned long long *counts, uint64_t n, uint32_t nparts, uint32_t ppr, uint64_t rows,
+                            uint32_t hrows, Op *send) {
+  PMA_SHARED unsigned long long off[kMaxParts + 1];
+  if (wv::thread_idx() == 0) {
+    unsigned long long run = 0;
+    for (uint32_t p = 0; p < nparts; p++) {
+      off[p] = run;
+      run += counts[p];
+    }
+    off[nparts] = run;
+  }
+  wv::block_sync();
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  const uint64_t gid = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx();
+  const uint32_t world = nparts / ppr;
+  for (uint64_t i = gid; i < (uint64_t)world * hrows * 3ull; i += stride) {  // headers
+    const uint32_t peer = (uint32_t)(i / (hrows * 3ull)), w = (uint32_t)(i % (hrows * 3ull));
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(send + (uint64_t)peer * rows);
+    hdr[w] = (w < ppr) ? (uint32_t)counts[peer * ppr + w] : 0u;
+  }
+  for (uint64_t i = gid; i < n; i += stride) {
+    uint32_t p = 0;  // partition of bucketed row i (nparts <= 64: a short scan of the prefix)
+    while (p + 1 < nparts && off[p + 1] <= i) p++;
+    const uint32_t peer = p / ppr;
+    send[(uint64_t)peer * rows + hrows + (i - off[peer * ppr])] = bucketed[i];
+  }
+}
+// k_xchg_unpack: received chunks -> one contiguous stream per local partition, source ranks in order (= global stream order).
+// starts[q * world + r] = first output row of (partition q, source r) inside out_q; the host computed them from the headers.
+PMA_KERNEL void k_xchg_unpack(const Op *recv, uint64_t rows, uint32_t hrows, uint32_t world, uint32_t ppr, const unsigned long long *seg_src,
+                              const unsigned long long *seg_dst, const unsigned long long *seg_len, Op *out) {
+  // one (partition, source) segment per blockIdx.y-less flat index: grid-stride over segments, threads over rows
+  const uint32_t nseg = world * ppr;
+  for (uint32_t sgi = wv::block_idx(); sgi < nseg; sgi += wv::grid_dim()) {
+    const unsigned long long len = seg_len[sgi], so = seg_src[sgi], dofs = seg_dst[sgi];
+    for (unsigned long long i = wv::thread_idx(); i < len; i += wv::block_dim()) out[dofs + i] = recv[so + i];
+  }
+  (void)rows;
+  (void)hrows;
+}
+
 }  // namespace ppcsr

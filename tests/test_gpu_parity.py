@@ -434,6 +434,31 @@ def test_bucket_ops_device_matches_host_routing(pkg, streams):
         np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), hb)
 
 
+def test_native_rccl_exchange_single_rank(pkg, streams):
+    """pppcsr_exchange_apply with a one-rank RCCL communicator (all a one-GPU box can run: RCCL refuses two ranks on one
+    device): device bucketing -> chunk packing -> grouped ncclSend / ncclRecv to self -> unpack -> concurrent per-partition
+    apply, against the oracle's PPPCSR partition by partition.  The multi-rank routing rule itself is covered by the
+    gloo tests (same chunk layout, torch carrier)."""
+    import torch
+    n, P = 50000, 8
+    o = OraclePPPCSR(n, True, 1, P)
+    pp = pkg.PPPCSR(n, numDomain=1, partitionsPerDomain=P, local=(0, P, 0))
+    pp.comm_create(pkg.PPPCSR.comm_unique_id(), 1, 0, 0)
+    for k in range(3):
+        ops = streams.random_stream(n, [200000, 1, 70000][k], seed=60 + k, p_delete=0.25)
+        t = torch.from_numpy(ops.view(np.int32)).cuda()
+        torch.cuda.synchronize()
+        pp.exchange_apply(t.data_ptr(), len(ops), 200000)
+        o.apply(ops)
+    for k in range(P):
+        a, b = pp.partition(k), o.partition(k)
+        assert a.geometry() == b.geometry()
+        ei, en = a.state()
+        oi, on = b.state()
+        assert np.array_equal(ei, oi) and np.array_equal(en, on), f"partition {k}"
+    pp.close()
+
+
 def test_scan_all_repeated_across_resizes(pkg, streams):
     """bulk scan called repeatedly while the array doubles and halves (its scratch state is per array size); long runs
     of isolated vertices (adjacent sentinels spanning several waves) included"""
