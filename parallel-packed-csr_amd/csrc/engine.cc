@@ -1494,13 +1494,18 @@ int Engine::bfs(uint32_t start, uint32_t *levels, double *device_ms) {
   GCHK(gpu::set_device(device_));
   const uint32_t nn = n();
   if (start >= nn) return fail(PPCSR_EINVAL, "bfs: start vertex out of range");
-  uint32_t *d_lv = nullptr, *d_f0 = nullptr, *d_f1 = nullptr, *d_cnt = nullptr;
+  uint32_t *d_lv = nullptr, *d_f0 = nullptr, *d_f1 = nullptr, *d_cnt = nullptr, *d_fb = nullptr, *d_vb = nullptr;
   DevGuard tmpg;
-  tmpg.add(&d_lv); tmpg.add(&d_f0); tmpg.add(&d_f1); tmpg.add(&d_cnt);
+  tmpg.add(&d_lv); tmpg.add(&d_f0); tmpg.add(&d_f1); tmpg.add(&d_cnt); tmpg.add(&d_fb); tmpg.add(&d_vb);
+  const uint64_t bit_words = ((uint64_t)nn + 63) / 64 * 2;  // frontier / visited bitmaps of the streaming levels
+  GCHK(gpu::dmalloc((void **)&d_fb, bit_words * sizeof(uint32_t)));
+  GCHK(gpu::dmalloc((void **)&d_vb, bit_words * sizeof(uint32_t)));
   GCHK(gpu::dmalloc((void **)&d_lv, (uint64_t)nn * sizeof(uint32_t)));
   GCHK(gpu::dmalloc((void **)&d_f0, (uint64_t)nn * sizeof(uint32_t)));
   GCHK(gpu::dmalloc((void **)&d_f1, (uint64_t)nn * sizeof(uint32_t)));
-  GCHK(gpu::dmalloc((void **)&d_cnt, 2 * sizeof(uint32_t)));  // [0] vertices found, [1] a hub was left to the streaming pass
+  // [0] vertices found, [1] a hub was left to the streaming pass, [kBfsStripeWords...] the streaming pass's striped count
+  constexpr uint32_t cnt_words = (kBfsStripes + 1) * kBfsStripeWords;
+  GCHK(gpu::dmalloc((void **)&d_cnt, cnt_words * sizeof(uint32_t)));
   p.timer.start(p.stream);
   GCHK(gpu::dset(d_lv, 0xFF, (uint64_t)nn * sizeof(uint32_t), p.stream));
   const uint32_t zero = 0;
@@ -1511,19 +1516,25 @@ int Engine::bfs(uint32_t start, uint32_t *levels, double *device_ms) {
   // does not depend on hub degrees — and the list is rebuilt only when the frontier becomes small again.
   uint32_t nfront = 1, level = 0;
   uint32_t *cur = d_f0, *nxt = d_f1;
-  uint32_t h_cnt[2] = {0, 0};
+  std::vector<uint32_t> h_cnt(cnt_words, 0);
+  auto striped = [&]() {
+    uint32_t sum = 0;
+    for (uint32_t k = 1; k <= kBfsStripes; k++) sum += h_cnt[k * kBfsStripeWords];
+    return sum;
+  };
   bool have_list = true;
   const uint64_t N = p.v.g.N;
   const uint32_t big = (uint32_t)std::max<uint64_t>(64, (uint64_t)nn / 256);  // frontier size from which the pass is cheaper
   while (nfront > 0) {
-    GCHK(gpu::dset(d_cnt, 0, 2 * sizeof(uint32_t), p.stream));
+    GCHK(gpu::dset(d_cnt, 0, cnt_words * sizeof(uint32_t), p.stream));
     if (nfront >= big) {
-      GPU_LAUNCH(p.stream, k_bfs_edges, grid_for((N + 63) / 64, 4, 8192), 256, p.v, level, d_lv, d_cnt);
+      GPU_LAUNCH(p.stream, k_bfs_bits, grid_for(nn, 256, 4096), 256, (const uint32_t *)d_lv, nn, level, d_fb, d_vb);
+      GPU_LAUNCH(p.stream, k_bfs_edges_bits, grid_for((N + 255) / 256, 4, 8192), 256, p.v, level, (const uint32_t *)d_fb, (const uint32_t *)d_vb, d_lv, d_cnt + kBfsStripeWords);
       have_list = false;
     } else {
       if (!have_list) {  // (the pass only counted claims — an upper bound; the list gives the exact frontier)
         GPU_LAUNCH(p.stream, k_bfs_collect, grid_for(nn, 256), 256, (const uint32_t *)d_lv, nn, level, cur, d_cnt);
-        GCHK(gpu::d2h(h_cnt, d_cnt, sizeof(uint32_t), p.stream));
+        GCHK(gpu::d2h(h_cnt.data(), d_cnt, sizeof(uint32_t), p.stream));
         GCHK(gpu::sync(p.stream));
         nfront = h_cnt[0];
         GCHK(gpu::dset(d_cnt, 0, 2 * sizeof(uint32_t), p.stream));
@@ -1532,17 +1543,18 @@ int Engine::bfs(uint32_t start, uint32_t *levels, double *device_ms) {
       have_list = true;
       std::swap(cur, nxt);
     }
-    GCHK(gpu::d2h(h_cnt, d_cnt, 2 * sizeof(uint32_t), p.stream));
+    GCHK(gpu::d2h(h_cnt.data(), d_cnt, cnt_words * sizeof(uint32_t), p.stream));
     GCHK(gpu::sync(p.stream));
     GCHK(gpu::last_error());
     if (h_cnt[1]) {  // hubs of this level were skipped by the per-vertex kernel: one pass finishes the level
-      GPU_LAUNCH(p.stream, k_bfs_edges, grid_for((N + 63) / 64, 4, 8192), 256, p.v, level, d_lv, d_cnt);
-      GCHK(gpu::d2h(h_cnt, d_cnt, sizeof(uint32_t), p.stream));
+      GPU_LAUNCH(p.stream, k_bfs_bits, grid_for(nn, 256, 4096), 256, (const uint32_t *)d_lv, nn, level, d_fb, d_vb);
+      GPU_LAUNCH(p.stream, k_bfs_edges_bits, grid_for((N + 255) / 256, 4, 8192), 256, p.v, level, (const uint32_t *)d_fb, (const uint32_t *)d_vb, d_lv, d_cnt + kBfsStripeWords);
+      GCHK(gpu::d2h(h_cnt.data(), d_cnt, cnt_words * sizeof(uint32_t), p.stream));
       GCHK(gpu::sync(p.stream));
       GCHK(gpu::last_error());
       have_list = false;
     }
-    nfront = h_cnt[0];
+    nfront = h_cnt[0] + striped();
     level++;
   }
   p.timer.stop(p.stream);
