@@ -123,6 +123,11 @@ struct Engine::Impl {
   uint32_t rb_tile = 0;          // leaves per rebalance tile (power of two <= 256); 0 = pick per window
   uint32_t rb_min_tiles = 4096;  // auto tile: shrink the tile until the window has at least this many
   uint32_t rb_prefetch = 1;  // 1: four chunks in flight per wave, 0: one
+  uint64_t rb_inplace_min = 1ull << 19;  // partial windows of at least this many slots are rebalanced in place (0 = never)
+  uint32_t rb_inplace_cpw = 0;   // 64-slot chunks per wave of an in-place tile (8 or 16; 0 = by window size)
+  uint32_t *d_ip = nullptr;      // in-place rebalance: header (sticky error, ticket counters), tile order, the tiles' flags
+  uint32_t ip_epoch = 0;
+  bool ip_used = false;          // an in-place rebalance ran since the error flag was last looked at
   uint32_t scatter_variant = 2;  // 0: LDS-staged k_scatter_fill, 1: register-run k_scatter_runs, 2: runs + in-tile leaf scan (3 launches)
   bool carry_dumped = false;
   bool partial = false;
@@ -291,6 +296,8 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   GCHK(gpu::dmalloc((void **)&p.d_total, sizeof(unsigned long long)));
   GCHK(gpu::hmalloc((void **)&p.h_total, sizeof(unsigned long long)));
   GCHK(gpu::dmalloc((void **)&p.d_table, sizeof(ChainTable)));
+  GCHK(gpu::dmalloc((void **)&p.d_ip, (kIpHdrWords + 2 * (uint64_t)kIpMaxTiles) * sizeof(uint32_t)));
+  GCHK(gpu::dset(p.d_ip, 0, (kIpHdrWords + 2 * (uint64_t)kIpMaxTiles) * sizeof(uint32_t), p.stream));
   GCHK(ensure_plans(p));
   memset(p.h_ctl, 0, sizeof(Control));
 
@@ -316,10 +323,6 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   GPU_LAUNCH(p.stream, k_recount, grid_for((N + 63) / 64, 4), 256, p.v, (uint64_t)0, N);
   GCHK(gpu::sync(p.stream));
   GCHK(gpu::last_error());
-  if (getenv("PPCSR_DEBUG_PTRS"))
-    fprintf(stderr, "[ppcsr] items %p..%p nodes %p..%p leafcnt %p..%p wres %p rres %p dres %p plans %p ctl %p\n", (void *)p.v.items,
-            (void *)(p.v.items + N), (void *)p.v.nodes, (void *)(p.v.nodes + p.n_cap), (void *)p.v.leafcnt, (void *)(p.v.leafcnt + p.leaves_cap),
-            (void *)p.v.wres, (void *)p.v.rres, (void *)p.v.dres, (void *)p.d_plans, (void *)p.d_ctl);
   return PPCSR_OK;
 }
 
@@ -353,6 +356,7 @@ Engine::~Engine() {
   GPU_DFREE(p.d_total);
   gpu::hfree(p.h_total);
   GPU_DFREE(p.d_table);
+  if (p.d_ip) GPU_DFREE(p.d_ip);
   GPU_DFREE(p.d_plans);
   if (p.d_ops) GPU_DFREE(p.d_ops);
   if (p.d_rank) GPU_DFREE(p.d_rank);
@@ -457,6 +461,14 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "rb_min_tiles") {
     p.rb_min_tiles = value < 1 ? 1u : (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "rb_inplace_cpw") {
+    p.rb_inplace_cpw = value >= 16 ? 16u : (value >= 8 ? 8u : 0u);
+    return PPCSR_OK;
+  }
+  if (k == "rb_inplace_min") {
+    p.rb_inplace_min = value < 0 ? 0ull : (uint64_t)value;
     return PPCSR_OK;
   }
   if (k == "rb_prefetch") {
@@ -589,7 +601,7 @@ int Engine::apply_batch_device(const Op *d_ops, uint64_t n) {
   p.timer.stop(p.stream);
   p.st.last_batch_ms = p.timer.ms();
   p.st.ops_applied += n;
-  return PPCSR_OK;
+  return inplace_fault_check();
 }
 
 int Engine::run_rounds(const Op *d_ops, uint64_t n) {
@@ -639,16 +651,11 @@ int Engine::run_rounds(const Op *d_ops, uint64_t n) {
       for (uint32_t r = 0; r < chunk_rounds; r++) {
         a.round = ++p.round;
         if (p.profile) p.events[4 * r + 0].record(p.stream);
-        static const bool dbg_sync = getenv("PPCSR_SYNC_DEBUG") != nullptr;
-        if (dbg_sync) fprintf(stderr, "[ppcsr] round %u k_plan\n", a.round);
         GPU_LAUNCH(p.stream, k_plan, blocks, 256, a);
-        if (dbg_sync) { gpu::sync(p.stream); fprintf(stderr, "[ppcsr] round %u k_check\n", a.round); }
         if (p.profile) p.events[4 * r + 1].record(p.stream);
         GPU_LAUNCH(p.stream, k_check, blocks, 256, a);
-        if (dbg_sync) { gpu::sync(p.stream); fprintf(stderr, "[ppcsr] round %u k_apply\n", a.round); }
         if (p.profile) p.events[4 * r + 2].record(p.stream);
         GPU_LAUNCH(p.stream, k_apply, blocks, 256, a);
-        if (dbg_sync) { gpu::sync(p.stream); fprintf(stderr, "[ppcsr] round %u done\n", a.round); }
         if (p.profile) p.events[4 * r + 3].record(p.stream);
       }
       GCHK(gpu::d2h(p.h_ctl, p.d_ctl, sizeof(Control), p.stream));
@@ -995,7 +1002,6 @@ int Engine::run_exclusive(Op op, uint32_t flags, const Op *d_ops, uint32_t spec_
     xv.vws = p.d_vws;
     xv.scratch_plan = p.d_xplan;
     xv.me1 = (spec && attempt == 0) ? spec_index + 1u : 0u;  // (a retry follows a doubling: whole-array rule, see the caller)
-    if (getenv("PPCSR_SYNC_DEBUG")) fprintf(stderr, "[ppcsr] k_exclusive op (%u,%u,%u) flags %u attempt %d\n", op.src, op.dst, op.op, flags, attempt);
     GPU_LAUNCH(p.stream, k_exclusive, 1, 64, p.v, op, d_ops, spec ? spec_index : kMax, flags, p.d_xout, p.d_stats, p.excl_in_wave, xv);
     GCHK(gpu::d2h(p.h_xout, p.d_xout, sizeof(ExclOut), p.stream));
     GCHK(gpu::sync(p.stream));
@@ -1094,7 +1100,7 @@ int Engine::rank_scan(const uint32_t *d_cnt, uint64_t nleaves, bool table, uint6
   if (rc != PPCSR_OK) return rc;
   const uint64_t ntiles = (nleaves + kScanTile - 1) / kScanTile;
   GPU_LAUNCH(p.stream, k_scan_tiles, ntiles, 256, d_cnt, nleaves, p.d_tiles);
-  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, table ? p.d_table : (ChainTable *)nullptr, tb_index, tb_len);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, table ? p.d_table : (ChainTable *)nullptr, tb_index, tb_len, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
   GPU_LAUNCH(p.stream, k_scan_apply, ntiles, 256, d_cnt, nleaves, (const uint32_t *)p.d_tiles, p.d_rank);
   return PPCSR_OK;
 }
@@ -1122,7 +1128,7 @@ int Engine::rebalance_fused(const View &nv, const Edge *src_items, uint64_t src_
   if (rc != PPCSR_OK) return rc;
   GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, src_cnt, nleaves, tile, p.d_tiles, inplace ? p.d_rank : (uint32_t *)nullptr,
              inplace ? (uint32_t *)nullptr : dst_cnt, inplace ? (uint64_t)0 : dst_nleaves);
-  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, tb_index, tb_len);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, tb_index, tb_len, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
   GPU_LAUNCH(p.stream, k_rb_scatter, ntiles, 256, nv, src_items, src_lo, src_len, src_sh,
              inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, tile, p.rb_prefetch ? 4u : 1u, (const uint32_t *)p.d_tiles,
              (const ChainTable *)p.d_table, dst, dst_bias, dst_cnt, nv.g.sh, (uint64_t)0);
@@ -1187,6 +1193,18 @@ int Engine::resize(uint64_t newN) {
   return PPCSR_OK;  // (a structure in the sequential regime is re-checked by add_node / apply_batch, not here: the caller may be in the middle of an update)
 }
 
+// an in-place rebalance whose tile order was not a valid schedule gave up waiting and said so: the array is not to be trusted
+int Engine::inplace_fault_check() {
+  Impl &p = *p_;
+  if (!p.ip_used) return PPCSR_OK;
+  uint32_t err = 0;
+  GCHK(gpu::d2h(&err, p.d_ip + 1, sizeof(uint32_t), p.stream));
+  GCHK(gpu::sync(p.stream));
+  p.ip_used = false;
+  if (err) return fail(PPCSR_EINTERNAL, "in-place window rebalance: a tile waited for a source tile that never reported (tile order invalid)");
+  return PPCSR_OK;
+}
+
 // window rebalance too large for one wave: leaf-rank scan + exact position table + ONE fused scatter/fill pass into a
 // persistent scratch array; a whole-array window then just swaps the buffers, a partial window is copied back
 int Engine::big_redistribute(uint64_t wstart, uint64_t wlen, bool sync) {
@@ -1197,6 +1215,39 @@ int Engine::big_redistribute(uint64_t wstart, uint64_t wlen, bool sync) {
   int rc = fused ? ensure_scratch(nleaves) : rank_scan(v.leafcnt + leaf_lo, nleaves, true, wstart, wlen);
   if (rc != PPCSR_OK) return rc;
   const bool whole = (wstart == 0 && wlen == v.g.N);
+  if (fused && !whole && p.rb_inplace_min && wlen >= p.rb_inplace_min) {
+    // in place: tiles of 2048 (4096) slots held in registers, ordered so that nobody overwrites what has not been read
+    const uint32_t cpw = p.rb_inplace_cpw ? p.rb_inplace_cpw : ((wlen / 2048u <= kIpMaxTiles) ? 8u : 16u);
+    const uint32_t tile_slots = 4u * cpw * 64u;
+    const uint32_t tile_leaves = tile_slots >> v.g.sh;
+    const uint64_t ntiles = wlen / tile_slots;
+    if (ntiles >= 1 && ntiles <= kIpMaxTiles && wlen % tile_slots == 0 && tile_leaves >= 1 && tile_leaves <= kRbTile && (64u >> v.g.sh) >= 1u) {
+      rc = ensure_tiles(ntiles);
+      if (rc != PPCSR_OK) return rc;
+      if (++p.ip_epoch == 0) {  // (flags are compared with the epoch: clear them when it wraps)
+        GCHK(gpu::dset(p.d_ip + kIpHdrWords + kIpMaxTiles, 0, (uint64_t)kIpMaxTiles * sizeof(uint32_t), p.stream));
+        p.ip_epoch = 1;
+      }
+      uint32_t *order = p.d_ip + kIpHdrWords, *flags = p.d_ip + kIpHdrWords + kIpMaxTiles;
+      GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, v.leafcnt + leaf_lo, nleaves, tile_leaves, p.d_tiles, p.d_rank, (uint32_t *)nullptr, (uint64_t)0);
+      GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, wstart, wlen, order, p.d_ip, tile_slots);
+      if (cpw == 8)
+        GPU_LAUNCH(p.stream, k_rb_inplace8, ntiles, 256, v, wstart, wlen, v.g.sh, (const uint32_t *)p.d_rank, (const uint32_t *)p.d_tiles,
+                   (const ChainTable *)p.d_table, (const uint32_t *)order, p.d_ip, flags, p.ip_epoch);
+      else
+        GPU_LAUNCH(p.stream, k_rb_inplace16, ntiles, 256, v, wstart, wlen, v.g.sh, (const uint32_t *)p.d_rank, (const uint32_t *)p.d_tiles,
+                   (const ChainTable *)p.d_table, (const uint32_t *)order, p.d_ip, flags, p.ip_epoch);
+      p.ip_used = true;
+      if (sync) {
+        GCHK(gpu::sync(p.stream));
+        GCHK(gpu::last_error());
+        rc = inplace_fault_check();
+        if (rc != PPCSR_OK) return rc;
+      }
+      p.st.big_redistributes++;
+      return PPCSR_OK;
+    }
+  }
   const uint64_t need = whole ? v.g.N : wlen;
   if (whole ? (p.scratch_cap != need) : (p.scratch_cap < need)) {  // a swapped-in buffer must be exactly N slots
     if (p.d_scratch) GPU_DFREE(p.d_scratch);
@@ -1358,7 +1409,7 @@ int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap, co
   if (fresh_state) GCHK(gpu::dset(d_cs, 0, nchunks * sizeof(uint32_t), p.stream));  // later scans find it zeroed (k_chunk_counts)
   GPU_LAUNCH(p.stream, k_chunk_sentinels, grid_for(n(), 256), 256, p.v, d_cs);
   GPU_LAUNCH(p.stream, k_chunk_counts, ntiles, 256, p.v, d_cs, d_cc, tile, p.d_tiles);
-  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, (ChainTable *)nullptr, (uint64_t)0, (uint64_t)0);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, (ChainTable *)nullptr, (uint64_t)0, (uint64_t)0, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
   GPU_LAUNCH(p.stream, k_scan_write, ntiles, 256, p.v, (const uint32_t *)d_cc, tile, (const uint32_t *)p.d_tiles, d_rows, d_dst, cap,
              d_values, d_contrib);
   return PPCSR_OK;
@@ -1826,7 +1877,7 @@ int Engine::rebalance_bench(uint64_t wlen, int iters, double *ms_per_call) {
   GCHK(gpu::sync(p.stream));
   GCHK(gpu::last_error());
   *ms_per_call = p.timer.ms() / iters;
-  return PPCSR_OK;
+  return inplace_fault_check();
 }
 
 int bucket_ops_device(uint32_t init_n, uint32_t n_parts, const Op *d_ops, uint64_t n, Op *d_out, unsigned long long *d_counts,

@@ -76,6 +76,7 @@ class Engine {
                     bool *resized = nullptr, bool later_committed = false);
   int resize(uint64_t newN);
   int big_redistribute(uint64_t wstart, uint64_t wlen, bool sync = true);
+  int inplace_fault_check();
   int rank_scan(const uint32_t *d_cnt, uint64_t nleaves, bool table = false, uint64_t tb_index = 0, uint64_t tb_len = 0);
   int recheck_ranges();  // narrow == 0: look whether the vertex ranges are sane again and re-enable narrowing + parallel rounds
   int ensure_scratch(uint64_t nleaves);

@@ -734,7 +734,7 @@ PMA_DEV void redistribute_block(const View &v, uint64_t wstart, uint64_t wlen, E
   if (j == 0) {
     for (uint64_t o = tid; o < wlen; o += nthreads) scratch[o] = null_edge();
   } else {
-    int hint = 0, hint2 = 0;
+    int hint = -1, hint2 = -1;
     constexpr int kB = 4;  // chunks requested back to back per wave
     for (uint32_t c0 = (uint32_t)w * kB; c0 < nchunks; c0 += nwaves * kB) {
       Edge e[kB];
@@ -872,11 +872,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
     }
     const uint32_t c_leaf = v.leafcnt[leaf];
     bool nul0 = false;
-#if defined(PPCSR_BISECT_GAP64)
-    constexpr uint32_t kGapPre = 64;
-#else
     constexpr uint32_t kGapPre = 16;  // slots of the gap search requested with this batch (a null within 16 slots in 99.7 % of the cases at density 0.7)
-#endif
     if (op.op != 0 && (uint32_t)lane < kGapPre) {
       const uint64_t g0 = (uint64_t)index + 1ull + (uint64_t)lane;
       if (g0 < g.N) nul0 = (v.items[g0].value == 0);
@@ -1020,11 +1016,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
     uint32_t down = 0, up = 0;
     // both directions' first kW vertices are requested together, kW lanes each (one round trip for almost every update:
     // a one-leaf window holds a handful of sentinels at most; 64 node records per direction cost 3 KB of fetches per update)
-#if defined(PPCSR_BISECT_W32)
-    constexpr uint32_t kW = 32;
-#else
     constexpr uint32_t kW = 8;
-#endif
     uint32_t b0 = 0;
     bool v0 = false;
     if ((uint32_t)lane < kW) {

@@ -249,13 +249,27 @@ PMA_HD inline uint64_t chain_single_pos(const ChainSeg &sg, uint64_t index, uint
 }
 
 // position of element k (0 <= k < j) from the table; *hint is a segment cursor (monotone callers)
+// segment that covers chain step t: the last one with t0 <= t.  hint: the segment of the caller's previous lookup (its
+// lookups move slowly), or -1 = none yet: bisect instead of walking up from segment 0 (a table has tens of segments and
+// every step is a dependent LDS read)
+PMA_HD inline int chain_seg_find(const ChainTable *tb, uint64_t t, int hint) {
+  int s = hint;
+  if (s < 0 || s >= tb->nseg) {
+    int lo = 0, hi = tb->nseg - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tb->seg[mid].t0 <= t) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+  }
+  while (s > 0 && tb->seg[s].t0 > t) s--;
+  while (s + 1 < tb->nseg && tb->seg[s + 1].t0 <= t) s++;
+  return s;
+}
 PMA_HD inline uint64_t chain_pos(const ChainTable *tb, uint64_t k, int *hint) {
   if (k == 0) return tb->index;
   const uint64_t t = tb->j - 1 - k;
-  int s = *hint;
-  if (s < 0 || s >= tb->nseg) s = 0;
-  while (s > 0 && tb->seg[s].t0 > t) s--;
-  while (s + 1 < tb->nseg && tb->seg[s + 1].t0 <= t) s++;
+  const int s = chain_seg_find(tb, t, *hint);
   *hint = s;
   const ChainSeg &sg = tb->seg[s];
   const uint64_t d = t - sg.t0;
@@ -270,10 +284,7 @@ PMA_HD inline uint64_t chain_pos(const ChainTable *tb, uint64_t k, int *hint) {
 PMA_HD inline bool chain_linear_run(const ChainTable *tb, uint64_t k0, uint64_t cnt, int *hint, uint64_t *A, uint64_t *D, int *shift) {
   if (k0 == 0 || tb->j < 2 || k0 + cnt > tb->j - 1) return false;
   const uint64_t t_hi = tb->j - 1 - k0, t_lo = tb->j - 1 - (k0 + cnt);
-  int s = *hint;
-  if (s < 0 || s >= tb->nseg) s = 0;
-  while (s > 0 && tb->seg[s].t0 > t_lo) s--;
-  while (s + 1 < tb->nseg && tb->seg[s + 1].t0 <= t_lo) s++;
+  const int s = chain_seg_find(tb, t_lo, *hint);
   *hint = s;
   const ChainSeg &sg = tb->seg[s];
   if (t_hi > sg.t0 + sg.count) return false;  // the run continues in an earlier segment

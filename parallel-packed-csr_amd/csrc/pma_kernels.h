@@ -511,9 +511,120 @@ PMA_KERNEL void k_scan_tiles(const uint32_t *cnt, uint64_t nleaves, uint32_t *ti
   wv::block_sync();
   if (wv::thread_idx() == 0) tilesum[b] = red[0] + red[1] + red[2] + red[3];
 }
+// ---- partial window rebalanced IN PLACE (no scratch copy, no copy-back) ----------------------------------------------
+// The reference spreads a window inside the array itself (PCSR.cpp:207-247: pack to the left, then place right to left).
+// Here a tile of kIpChunks x 4 x 64 source slots is held in the registers of one workgroup: the workgroup loads its tile,
+// PUBLISHES that it has done so, waits until every tile whose source slots its own destination range covers has published
+// too, and only then writes elements and null runs.  Both maps (k-th live element -> source slot, -> destination slot) are
+// monotone, so tile i's destination range [c_i, d_i) is contiguous, d_i = c_{i+1}, and at every tile boundary the flow
+// goes one way: "R" (d_i beyond tile i's last source slot: tile i writes over sources of tiles i+1...) or "L" (tile i+1
+// writes over sources of tiles ...i).  A tile waits only for tiles further along its own run of R (or L) boundaries, so
+//   key(i) = max(#consecutive R boundaries starting at i|i+1, #consecutive L boundaries ending at i-1|i)
+// is strictly larger than the key of every tile that tile i waits for.  rb_order_body (the tail of k_scan_tilesums) sorts
+// the tiles by key; k_rb_inplace workgroups draw tickets in that order — whoever a workgroup waits for drew an earlier ticket, is resident (or done) and
+// publishes without waiting for anybody: no deadlock whatever the number of resident workgroups.  (A bounded spin turns a
+// broken order into an error flag instead of a hang.)
+constexpr uint32_t kIpMaxTiles = 8192, kIpOrderThreads = 1024;
+constexpr uint32_t kIpHdrWords = 32 * 9;  // words before the order list in the engine's buffer
+constexpr uint32_t kIpTicketStride = 32;  // ctl[1]: sticky error flag; ctl[kIpTicketStride * (1 + x)]: ticket counter of XCD x
+PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint32_t ntiles, uint32_t tile_slots, uint32_t *order, uint32_t *ctl) {
+  PMA_SHARED ChainTable stb;
+  PMA_SHARED unsigned long long nr[kIpMaxTiles / 64], nl[kIpMaxTiles / 64];  // bit b: boundary b|b+1 is NOT "R" / NOT "L"
+  PMA_SHARED uint32_t hist[kIpMaxTiles + 1];
+  PMA_SHARED uint32_t wtot[kIpOrderThreads / 64];
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
+    uint32_t *sp = reinterpret_cast<uint32_t *>(&stb);
+    const uint32_t words = (uint32_t)((sizeof(ChainTable) - sizeof(ChainSeg) * (size_t)(kMaxSeg - tb->nseg)) / 4);
+    for (uint32_t i = wv::thread_idx(); i < words; i += wv::block_dim()) sp[i] = g[i];
+  }
+  for (uint32_t i = wv::thread_idx(); i <= ntiles; i += wv::block_dim()) hist[i] = 0u;
+  if (wv::thread_idx() < 8u) ctl[kIpTicketStride * (1u + wv::thread_idx())] = 0u;  // the ticket counters
+  wv::block_sync();
+  const int lane = wv::lane(), w = wv::wave_in_block();
+  const uint64_t j = stb.j, wend = stb.index + stb.len;
+  const uint32_t nwords = (ntiles + 63u) / 64u;
+  int hint = -1;
+  for (uint32_t wd = (uint32_t)w; wd < nwords; wd += kIpOrderThreads / 64) {
+    const uint32_t b = wd * 64u + (uint32_t)lane;
+    bool is_r = false, is_l = false;
+    if (b + 1u < ntiles) {
+      const uint64_t K = tile_excl[b + 1u];
+      const uint64_t D = K < j ? chain_pos(&stb, K, &hint) : wend;      // where tile b's destination range ends
+      const uint64_t B = stb.index + (uint64_t)(b + 1u) * tile_slots;   // where tile b's source slots end
+      is_r = D > B;
+      is_l = D < B;
+    }
+    const uint64_t mr = wv::ballot(!is_r), ml = wv::ballot(!is_l);
+    if (lane == 0) {
+      nr[wd] = mr;
+      nl[wd] = ml;
+    }
+  }
+  wv::block_sync();
+  constexpr uint32_t kPer = kIpMaxTiles / kIpOrderThreads;
+  uint32_t key[kPer];
+#pragma unroll
+  for (uint32_t r = 0; r < kPer; r++) {
+    const uint32_t i = r * kIpOrderThreads + wv::thread_idx();
+    key[r] = 0;
+    if (i >= ntiles) continue;
+    uint32_t wd = i >> 6;  // first boundary >= i that is not R (bit ntiles-1 is always set)
+    uint64_t m = nr[wd] >> (i & 63u);
+    uint32_t nb;
+    if (m) nb = i + (uint32_t)wv::ctz64(m);
+    else {
+      do wd++; while (nr[wd] == 0ull);
+      nb = wd * 64u + (uint32_t)wv::ctz64(nr[wd]);
+    }
+    const uint32_t d_r = nb - i;
+    uint32_t d_l = 0;
+    if (i > 0) {  // last boundary <= i-1 that is not L (none: every boundary down to tile 0 is L)
+      const uint32_t b = i - 1u;
+      int wl = (int)(b >> 6);
+      m = nl[wl] << (63u - (b & 63u));
+      if (m) d_l = (uint32_t)wv::clz64(m);
+      else {
+        do wl--; while (wl >= 0 && nl[wl] == 0ull);
+        d_l = wl < 0 ? i : b - ((uint32_t)wl * 64u + 63u - (uint32_t)wv::clz64(nl[wl]));
+      }
+    }
+    key[r] = d_r > d_l ? d_r : d_l;
+    wv::atomic_add_u32(&hist[key[r]], 1u);
+  }
+  wv::block_sync();
+  {  // exclusive scan of hist[0 .. ntiles]
+    const uint32_t total = ntiles + 1u, per = (total + kIpOrderThreads - 1u) / kIpOrderThreads;
+    const uint32_t lo = wv::thread_idx() * per, hi = lo + per < total ? lo + per : total;
+    uint32_t mine = 0;
+    for (uint32_t i = lo; i < hi; i++) mine += hist[i];
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) wtot[w] = incl;
+    wv::block_sync();
+    uint32_t run = incl - mine;
+    for (int q = 0; q < w; q++) run += wtot[q];
+    for (uint32_t i = lo; i < hi; i++) {
+      const uint32_t x = hist[i];
+      hist[i] = run;
+      run += x;
+    }
+  }
+  wv::block_sync();
+#pragma unroll
+  for (uint32_t r = 0; r < kPer; r++) {
+    const uint32_t i = r * kIpOrderThreads + wv::thread_idx();
+    if (i < ntiles) order[wv::atomic_add_u32(&hist[key[r]], 1u)] = i;
+  }
+}
+
+
 constexpr uint32_t kTileSumThreads = 1024;
 PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned long long *total, ChainTable *tb,
-                                uint64_t tb_index, uint64_t tb_len) {
+                                uint64_t tb_index, uint64_t tb_len, uint32_t *order, uint32_t *ctl, uint32_t tile_slots) {
   // ONE workgroup of kTileSumThreads.  Each thread owns a contiguous run of tile sums (independent loads, all in
   // flight together); waves combine through LDS; the prefix is written back while one lane builds the rebalance's exact
   // position table from the grand total (saves a launch).
@@ -546,6 +657,10 @@ PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned lon
     const uint32_t x = tilesum[i];
     tilesum[i] = run;
     run += x;
+  }
+  if (order != nullptr) {  // in-place window: the order in which its tiles may be taken (needs the scanned sums and the table)
+    wv::block_sync();
+    rb_order_body(tilesum, tb, (uint32_t)ntiles, tile_slots, order, ctl);
   }
 }
 PMA_KERNEL void k_scan_apply(const uint32_t *cnt, uint64_t nleaves, const uint32_t *tilesum, uint32_t *rank) {
@@ -602,7 +717,7 @@ PMA_KERNEL void k_scatter_fill(View v, const Edge *src, uint64_t src_lo, uint64_
       dst[stb.index + t - dst_bias] = null_edge();
     return;
   }
-  int hint = 0, hint2 = 0;
+  int hint = -1, hint2 = -1;
   for (uint64_t ch = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); ch < nchunks; ch += wstride) {
     const uint64_t off = ch * 64 + (uint64_t)lane;
     Edge e = null_edge();
@@ -695,7 +810,7 @@ PMA_KERNEL void k_scatter_runs(View v, const Edge *src, uint64_t src_lo, uint64_
       dst[stb.index + t - dst_bias] = null_edge();
     return;
   }
-  int hint = 0, hint2 = 0, hint3 = 0;
+  int hint = -1, hint2 = -1, hint3 = -1;
   for (uint64_t ch = (uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block(); ch < nchunks; ch += wstride) {
     const uint64_t off = ch * 64 + (uint64_t)lane;
     Edge e = null_edge();
@@ -844,7 +959,7 @@ PMA_KERNEL void k_rb_scatter(View v, const Edge *__restrict__ src, uint64_t src_
   const uint32_t chunks = tile_leaves / lpc;        // chunks in this tile
   const uint64_t tile_slot0 = (tile * tile_leaves) << src_sh;
   const uint64_t lt_mask = (1ull << lane) - 1ull;   // lanes below this one
-  int hint = 0, hint2 = 0, hint3 = 0;
+  int hint = -1, hint2 = -1, hint3 = -1;
   if (batch >= (uint32_t)kRbBatch) {
     for (uint32_t c0 = (uint32_t)w * kRbBatch; c0 < chunks; c0 += 4 * kRbBatch) {
       Edge e[kRbBatch];
@@ -871,6 +986,121 @@ PMA_KERNEL void k_rb_scatter(View v, const Edge *__restrict__ src, uint64_t src_
                        &hint, &hint2, &hint3);
     }
   }
+}
+
+constexpr uint32_t kIpSpinLimit = 1u << 22;
+template <int CPW>  // chunks (64 slots) per wave: the tile is 4 * CPW * 64 slots
+PMA_DEV void rb_inplace_body(const View &v, uint64_t wstart, uint64_t wlen, int sh, const uint32_t *__restrict__ cnt,
+                             const uint32_t *__restrict__ tile_excl, const ChainTable *tb, const uint32_t *__restrict__ order, uint32_t *ctl,
+                             uint32_t *flags, uint32_t epoch) {
+  PMA_SHARED ChainTable stb;
+  PMA_SHARED uint32_t pre[kRbTile];
+  PMA_SHARED uint32_t wsum[4];
+  PMA_SHARED uint32_t s_tile;
+  constexpr uint32_t kTileSlots = 4u * CPW * 64u;
+  if (wv::thread_idx() == 0) {
+    // Ticket: position t * 8 + x of the order, drawn from the counter of this workgroup's XCD x (one counter for all would
+    // hand out ~one ticket per 9 ns: same-address atomics are served one after the other).  Each of the 8 sub-lists is
+    // consumed in order, and a workgroup turns to another XCD's list only when its own is used up, so the earliest
+    // unfinished tile of the order is always held by a resident workgroup or is the next ticket of an XCD with free slots.
+    const uint32_t ntiles = (uint32_t)(wlen / kTileSlots), xcc = wv::xcc_id();
+    uint32_t pos = 0xFFFFFFFFu;
+    for (uint32_t a = 0; a < 8u && pos == 0xFFFFFFFFu; a++) {
+      const uint32_t x = (xcc + a) & 7u;
+      const uint32_t have = x < ntiles ? (ntiles - x + 7u) / 8u : 0u;
+      if (have == 0u) continue;
+      const uint32_t t = wv::atomic_add_u32(&ctl[kIpTicketStride * (1u + x)], 1u);
+      if (t < have) pos = t * 8u + x;
+    }
+    s_tile = pos == 0xFFFFFFFFu ? pos : order[pos];
+  }
+  wv::block_sync();
+  const int lane = wv::lane(), w = wv::wave_in_block();
+  const uint32_t tile = s_tile;
+  if (tile == 0xFFFFFFFFu) return;  // (more workgroups than tiles: cannot happen with the engine's launch)
+  const uint64_t tile_slot0 = (uint64_t)tile * kTileSlots;
+  Edge e[CPW];  // requested first: everything below overlaps with these loads
+#pragma unroll
+  for (int q = 0; q < CPW; q++) {
+    const uint64_t off = tile_slot0 + (uint64_t)(w * CPW + q) * 64u + (uint64_t)lane;
+    e[q] = null_edge();
+    if (off < wlen) e[q] = v.items[wstart + off];
+  }
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
+    uint32_t *sp = reinterpret_cast<uint32_t *>(&stb);
+    const uint32_t words = (uint32_t)((sizeof(ChainTable) - sizeof(ChainSeg) * (size_t)(kMaxSeg - tb->nseg)) / 4);
+    for (uint32_t i = wv::thread_idx(); i < words; i += wv::block_dim()) sp[i] = g[i];
+  }
+  const uint32_t tile_leaves = kTileSlots >> sh;
+  const uint64_t nleaves = wlen >> sh;
+  uint32_t tile_cnt;
+  {  // exclusive prefix of this tile's (parked) leaf counts, one leaf per thread
+    const uint64_t l = (uint64_t)tile * tile_leaves + wv::thread_idx();
+    const uint32_t x = (wv::thread_idx() < tile_leaves && l < nleaves) ? cnt[l] : 0u;
+    uint32_t incl = x;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[w] = incl;
+    wv::block_sync();
+    uint32_t woff = 0;
+    for (int q = 0; q < w; q++) woff += wsum[q];
+    pre[wv::thread_idx()] = woff + incl - x;
+    tile_cnt = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+  const uint64_t j = stb.j, wend = stb.index + stb.len;
+  uint32_t seen = 0;
+#pragma unroll
+  for (int q = 0; q < CPW; q++) seen += (uint32_t)wv::popc64(wv::ballot(e[q].value != 0));  // (the loads have returned)
+  wv::block_sync();
+  if (wv::thread_idx() == 0) wv::flag_publish(&flags[tile], epoch);
+  if (j == 0) {  // empty window: nothing is read by anybody, every tile clears its own slots
+    for (uint32_t t = wv::thread_idx(); t < kTileSlots; t += wv::block_dim())
+      if (tile_slot0 + t < wlen) v.items[wstart + tile_slot0 + t] = null_edge();
+    return;
+  }
+  if (tile_cnt == 0) return;
+  const uint64_t base_rank = tile_excl[tile];
+  int hint = -1, hint2 = -1, hint3 = -1;
+  if (w == 0) {  // wait for the tiles whose source slots [c, d) covers
+    const uint64_t c = chain_pos(&stb, base_rank, &hint);
+    const uint64_t d = base_rank + tile_cnt < j ? chain_pos(&stb, base_rank + tile_cnt, &hint2) : wend;
+    const uint32_t lo = (uint32_t)((c - wstart) / kTileSlots), hi = (uint32_t)((d - 1u - wstart) / kTileSlots);
+    bool bad = false;
+    for (uint32_t t0 = lo; t0 <= hi; t0 += 64u) {
+      const uint32_t t = t0 + (uint32_t)lane;
+      uint32_t spins = 0;
+      while (wv::ballot(t <= hi && t != tile && wv::flag_read(&flags[t]) != epoch) != 0ull) {
+        if (++spins > kIpSpinLimit) {
+          bad = true;
+          break;
+        }
+        wv::spin_pause();
+      }
+    }
+    if (bad && lane == 0) ctl[1] = 1u;
+    wv::flag_acquire();
+  }
+  wv::block_sync();
+  (void)seen;
+  const uint32_t lpc = 64u >> sh;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int q = 0; q < CPW; q++) {
+    const uint32_t c = (uint32_t)(w * CPW + q);
+    if (tile_slot0 + (uint64_t)c * 64u < wlen)
+      rb_scatter_chunk(v, e[q], base_rank + pre[c * lpc], &stb, j, wend, v.items, 0, v.leafcnt, v.g.sh, 0, lane, lt_mask, &hint, &hint2, &hint3);
+  }
+}
+PMA_KERNEL void k_rb_inplace8(View v, uint64_t wstart, uint64_t wlen, int sh, const uint32_t *cnt, const uint32_t *tile_excl, const ChainTable *tb,
+                              const uint32_t *order, uint32_t *ctl, uint32_t *flags, uint32_t epoch) {
+  rb_inplace_body<8>(v, wstart, wlen, sh, cnt, tile_excl, tb, order, ctl, flags, epoch);
+}
+PMA_KERNEL void k_rb_inplace16(View v, uint64_t wstart, uint64_t wlen, int sh, const uint32_t *cnt, const uint32_t *tile_excl, const ChainTable *tb,
+                               const uint32_t *order, uint32_t *ctl, uint32_t *flags, uint32_t epoch) {
+  rb_inplace_body<16>(v, wstart, wlen, sh, cnt, tile_excl, tb, order, ctl, flags, epoch);
 }
 
 PMA_KERNEL void k_copy_slots(const Edge *src, Edge *dst, uint64_t len) {

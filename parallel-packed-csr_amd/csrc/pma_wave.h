@@ -39,6 +39,20 @@ PMA_DEV unsigned long long atomic_add_u64(unsigned long long *p, unsigned long l
 PMA_DEV uint32_t atomic_max_u32(uint32_t *p, uint32_t v) { return atomicMax(p, v); }
 PMA_DEV uint32_t atomic_exch_u32(uint32_t *p, uint32_t v) { return atomicExch(p, v); }
 PMA_DEV uint32_t atomic_cas_u32(uint32_t *p, uint32_t expect, uint32_t v) { return atomicCAS(p, expect, v); }
+// hand-off flags between workgroups (k_rb_inplace): "my loads have RETURNED" — published after a wait for them, polled with
+// agent-scope loads (a plain load may be served from a stale line of this XCD's L2 for ever).  No data travels with the
+// flag (the poller only WRITES afterwards), so neither side needs a release / acquire: at agent scope those are an L2
+// write-back and a cache invalidate per workgroup, which made the kernel 4x slower than the copy it replaces.
+PMA_DEV void flag_publish(uint32_t *p, uint32_t v) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+PMA_DEV uint32_t flag_read(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PMA_DEV void flag_acquire() { asm volatile("" ::: "memory"); }
+// which of the 8 XCDs this wave runs on (HW_REG_XCC_ID bits 3:0) — used for affinity only, never for correctness
+PMA_DEV uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }
+PMA_DEV void spin_pause() { __builtin_amdgcn_s_sleep(2); }
+PMA_DEV int clz64(uint64_t m) { return __clzll((long long)m); }
 PMA_DEV int popc64(uint64_t m) { return __popcll((unsigned long long)m); }
 PMA_DEV int ctz64(uint64_t m) { return __ffsll((long long)m) - 1; }
 PMA_DEV uint32_t block_idx() { return blockIdx.x; }

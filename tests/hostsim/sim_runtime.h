@@ -55,6 +55,12 @@ inline unsigned long long atomic_add_u64(unsigned long long *p, unsigned long lo
 inline uint32_t atomic_max_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomic_exch_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
 inline uint32_t atomic_cas_u32(uint32_t *p, uint32_t expect, uint32_t v) { uint32_t o = *p; if (o == expect) *p = v; return o; }
+inline void flag_publish(uint32_t *p, uint32_t v) { *p = v; }
+inline uint32_t flag_read(const uint32_t *p) { return *(const volatile uint32_t *)p; }
+inline void flag_acquire() {}
+inline uint32_t xcc_id() { return (uint32_t)sim::cur_block() & 7u; }
+inline void spin_pause() {}
+inline int clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }
 inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
 inline int ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
 inline uint32_t block_idx() { return (uint32_t)sim::cur_block(); }

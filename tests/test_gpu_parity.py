@@ -340,6 +340,43 @@ def test_big_window_rebalance(pkg, streams, variant, tile, batch):
     _same(e, o, "updates after the rebalances")
 
 
+@pytest.mark.parametrize("shape", ["uniform", "dense_left", "dense_right", "dense_middle", "sparse_middle"])
+def test_partial_window_rebalance_in_place(pkg, streams, shape):
+    """partial windows rebalanced inside the array (k_rb_order + k_rb_inplace; hundreds to thousands of 2048-slot tiles,
+    elements moving left, right, outward, inward — several tiles far) against the reference's redistribute() run by the oracle"""
+    n = 1 << 16
+    s, d = streams.rmat_edges(16, 500000, seed=4)
+    base = streams.adds(s, d)
+    lo, hi = {"uniform": (0, 0), "dense_left": (0, n // 16), "dense_right": (n // 4, n // 2), "dense_middle": (n // 6, n // 5),
+              "sparse_middle": (0, 0)}[shape]
+    extra = []
+    if hi > lo:
+        src = streams.uniform_ints(31, 400000, hi - lo, lo)
+        extra = [streams.adds(src, streams.uniform_ints(32, 400000, n))]
+    ops = np.concatenate([base] + extra)
+    e, o = pkg.PCSR(n), Oracle(n)
+    e.set_option("rb_inplace_min", 2048)
+    e.set_option("big_window", 4096)  # windows above it go to the host-driven path (in place) during the loads as well
+    e.apply(ops)
+    o.apply(ops)
+    if shape == "sparse_middle":
+        dele = base[(base[:, 0] >= n // 64) & (base[:, 0] < n // 8)].copy()
+        dele[:, 2] = 0
+        e.apply(dele)
+        o.apply(dele)
+    _same(e, o, "before")
+    N = e.geometry()[0]
+    for w in (N // 2, N // 4, N // 32, 4096):
+        e.bench_rebalance(w, 1)
+        o.debug_redistribute(0, w)
+        _same(e, o, f"{shape}: window {w}")
+    s2, d2 = streams.rmat_edges(16, 100000, seed=5)
+    more = streams.adds(s2, d2)
+    e.apply(more)
+    o.apply(more)
+    _same(e, o, "updates after the in-place rebalances")
+
+
 def test_bulk_build_fast_path(pkg, streams):
     """non-parity bulk build of a 1 M-edge RMAT graph: valid PMA invariants, same edge set / values /
     num_neighbors as the one-by-one build (oracle), consumers agree, and ordinary updates afterwards keep all of it"""

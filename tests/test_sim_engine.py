@@ -180,6 +180,43 @@ def test_sim_big_window_rebalance(sim, streams):
     _same(e, o, "updates after a rebalance")
 
 
+@pytest.mark.parametrize("shape", ["uniform", "dense_left", "dense_right", "dense_middle", "sparse_middle"])
+def test_sim_partial_window_rebalance_in_place(sim, streams, shape):
+    """partial windows rebalanced inside the array (k_rb_order + k_rb_inplace: tiles held in registers, written once every
+    tile whose source they cover has been read), on windows whose elements move left, right, outward and inward, against
+    the reference's redistribute() (PCSR.cpp:207-247) run by the oracle on the same window"""
+    n = 4096
+    base = streams.random_stream(n, 30000, seed=21)
+    lo, hi = {"uniform": (0, 0), "dense_left": (0, n // 8), "dense_right": (n // 4, n // 2), "dense_middle": (n // 5, n // 4),
+              "sparse_middle": (0, 0)}[shape]
+    extra = []
+    if hi > lo:  # pile edges onto a stretch of vertices: that part of the window is dense, the rest must make room
+        src = streams.uniform_ints(31, 12000, hi - lo, lo)
+        extra = [streams.adds(src, streams.uniform_ints(32, 12000, n))]
+    ops = np.concatenate([base] + extra)
+    # (big_window 2048: every window above it is rebalanced by the host-driven path, i.e. in place, during the loads too)
+    e, o = sim(n, True, mode=1, opt_horizon=64, big_window=2048), Oracle(n)
+    e.set_option("rb_inplace_min", 2048)
+    e.apply(ops)
+    o.apply(ops)
+    if shape == "sparse_middle":  # empty the middle of the left half: its neighbours move inward
+        dele = base[(base[:, 0] >= n // 6) & (base[:, 0] < n // 3)].copy()
+        dele[:, 2] = 0
+        e.apply(dele)
+        o.apply(dele)
+    _same(e, o, "before")
+    N = e.geometry()[0]
+    assert N >= 65536
+    for w in (N // 2, N // 4, 8192, 2048):
+        e.bench_rebalance(w, 1)
+        o.debug_redistribute(0, w)
+        _same(e, o, f"{shape}: window {w}")
+    more = streams.random_stream(n, 3000, seed=22, p_delete=0.3)
+    e.apply(more)
+    o.apply(more)
+    _same(e, o, "updates after the in-place rebalances")
+
+
 def test_sim_scan_all_and_queries(sim, streams):
     ops = streams.random_stream(120, 4000, seed=11, p_delete=0.2)
     e, o = sim(120), Oracle(120)
