@@ -101,11 +101,19 @@ struct Engine::Impl {
   // rollback, doubling again with every epoch that ends cleanly — while a stream that never rolls back keeps one
   // snapshot per epoch_ops updates
   uint32_t cur_epoch = 0;
-  uint32_t epoch_short = 8192;  // epoch length after a rollback
-  uint32_t epoch_clean = 0, epoch_grow_after = 8;  // clean epochs in a row / how many of them double the length again
+  // (a snapshot costs about one round; a rollback re-does half an epoch on average.  On a config #4 partition — 3 rollbacks
+  // per 1.25 M inserts — 8192 / 8 spent 16 % of the batch copying snapshots: 16384 / 2 took 30.4 ms instead of 38.4; the
+  // Zipf stream on the same partition, 50 rollbacks per 1.5 M updates, was indifferent: 208 ms either way)
+  uint32_t epoch_short = 16384;  // epoch length after a rollback
+  uint32_t epoch_clean = 0, epoch_grow_after = 2;  // clean epochs in a row / how many of them double the length again
   uint32_t region_slots = 4096;  // per-region prefix rule (>= kBigWindow so a window never leaves its region)
-  uint32_t opt_horizon = 6144;  // round width (upper bound when `adaptive` is on); dependency chains bound the number
-                                // of rounds, so a wider horizon mostly re-plans more: 6144 measured best on config #2
+  // Round width (upper bound when `adaptive` is on).  One update = one wave; `resident_waves` of them fit the chip at once
+  // (o_plan: 76 VGPRs = 6 waves per SIMD, 24 per CU, 6144 on 256 CUs).  A round's kernels are bound by latency, so a round
+  // of 2 x resident takes ~1.4x the time of one of 1 x resident; widths in between leave the second pass partly empty
+  // (config #2, updates/s: 6144 -> 139 M, 8192 -> 130 M, 12288 -> 156 M, 18432 -> 159 M, 24576 -> 139 M: the re-planned
+  // share grows with the width).  init() sets opt_horizon = 2 x resident, start_horizon = resident.
+  uint32_t resident_waves = 0;  // 0: unknown (emulator) — no quantisation of the adapted width
+  uint32_t opt_horizon = 6144;
   uint32_t start_horizon = 6144;
   uint32_t adaptive = 1;
   uint32_t scatter_blocks = 8192;
@@ -132,6 +140,12 @@ struct Engine::Impl {
   bool carry_dumped = false;
   bool partial = false;
   bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
+  // slots; a planned window at least this big lets nothing later overtake it (0: big_window / 2).  Such an update is
+  // likely to turn exclusive once the earlier updates have landed, and what has overtaken it by then is rolled back — but
+  // everything behind the barrier waits a round: at big_window / 4 a config #4 partition (critical density: a window of
+  // 8192 slots every few thousand updates) had 67 % of its non-commits "behind a barrier" and ran 373 rounds per 1.25 M
+  // inserts; at / 2: 276 rounds and the same 2-3 rollbacks; without any: 234 rounds, but slower ones
+  uint32_t soft_barrier = 0;
   uint32_t defer_barrier = 0;  // slots; a deferred update with a window at least this big lets nothing later overtake it (0: off)
   uint32_t diag = 0;     // count, per epoch, why planned updates did not commit (printed to stderr at the end of the epoch)
   std::vector<gpu::Event> events;  // init failed half-way: destructor frees only what exists
@@ -270,6 +284,15 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   (void)gpu::last_error();  // drop any stale error left on this thread by earlier, unrelated runtime calls
   GCHK(gpu::stream_create(&p.stream));
   GCHK(p.timer.init());
+  {
+    int cus = 0;
+    GCHK(gpu::device_cus(device, &cus));
+    if (cus > 0) {
+      p.resident_waves = (uint32_t)cus * 24u;
+      p.start_horizon = p.resident_waves;
+      p.opt_horizon = 2u * p.resident_waves;
+    }
+  }
   const uint64_t N = initial_N(init_n, src_n);
   Geometry g;
   compute_geometry(N, src_n, lock_search, &g);
@@ -483,6 +506,11 @@ int Engine::set_option(const char *key, int64_t value) {
     p.adaptive = value != 0;
     return PPCSR_OK;
   }
+  if (k == "resident_waves") {
+    if (value < 0 || value > (1 << 20)) return fail(PPCSR_EINVAL, "resident_waves out of range");
+    p.resident_waves = (uint32_t)value;
+    return PPCSR_OK;
+  }
   if (k == "start_horizon") {
     if (value < 1 || value > (1 << 20)) return fail(PPCSR_EINVAL, "start_horizon out of range");
     p.start_horizon = (uint32_t)value;
@@ -522,6 +550,10 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "epoch_grow_after") {
     p.epoch_grow_after = (uint32_t)std::max<int64_t>(1, value);
+    return PPCSR_OK;
+  }
+  if (k == "soft_barrier") {
+    p.soft_barrier = (uint32_t)std::max<int64_t>(0, value);
     return PPCSR_OK;
   }
   if (k == "defer_barrier") {
@@ -770,6 +802,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     c.e1 = (uint32_t)e1;
     c.max_horizon = p.opt_horizon;
     c.width_cap = p.opt_horizon;
+    c.resident = p.resident_waves;
     c.gbar[0] = c.gbar[1] = ~0ull;
     c.viol_idx = kMax;
     c.skip = kMax;
@@ -809,6 +842,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       a.regshift = rs;
       a.diag = p.diag;
       a.defer_barrier = p.defer_barrier;
+      a.soft_barrier = p.soft_barrier ? p.soft_barrier : a.v.big_window / 2u;
       // grid sized for the horizon the device last reported (it can only shrink within a chunk when fresh
       // updates run out; it never exceeds opt_horizon)
       // grid: wide enough for the adapted width to grow during the chunk (x1.25 per full-width round), narrow at the tail

@@ -16,6 +16,7 @@ typedef int stream_t;
 inline const char *err_str(int) { return "sim error"; }
 inline int set_device(int) { return 0; }
 inline int device_count(int *n) { *n = 1; return 0; }
+inline int device_cus(int, int *n) { *n = 0; return 0; }  // (the emulator has no residency to fill)
 inline int stream_create(stream_t *s) { *s = 0; return 0; }
 inline stream_t stream_from_ptr(void *) { return 0; }
 inline int stream_destroy(stream_t) { return 0; }
@@ -61,6 +62,7 @@ inline int dbg_report(const char *what, int e) {
 inline const char *err_str(int e) { return hipGetErrorString((hipError_t)e); }
 inline int set_device(int d) { return (int)hipSetDevice(d); }
 inline int device_count(int *n) { return (int)hipGetDeviceCount(n); }
+inline int device_cus(int d, int *n) { return (int)hipDeviceGetAttribute(n, hipDeviceAttributeMultiprocessorCount, d); }
 inline int stream_create(stream_t *s) { return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 inline stream_t stream_from_ptr(void *p) { return (stream_t)p; }
 inline int stream_destroy(stream_t s) { return dbg_report("hipStreamDestroy", (int)hipStreamDestroy(s)); }

@@ -1644,6 +1644,7 @@ struct OptCtl {
   uint32_t violation, excl, done, error;
   uint32_t max_horizon, excl_idx;  // max_horizon: width of the launched grid (the next round's horizon never exceeds it)
   uint32_t width_cap;              // upper bound of the adaptive width (the engine's opt_horizon)
+  uint32_t resident;               // waves the chip holds at once (0 = unknown): above it the width moves in whole multiples
   uint32_t maxc;  // 1 + largest stream index committed in this epoch
   uint32_t viol_idx;  // smallest stream index whose commit-time validation failed
   uint32_t adaptive;     // 1: adapt cur_horizon (experimental; a fixed width of 6144 measured best on config #2)
@@ -1679,6 +1680,7 @@ struct OptArgs {
   int regshift;
   uint32_t diag;
   uint32_t defer_barrier;  // 0: off
+  uint32_t soft_barrier;   // slots: see o_plan
   // windows above big_min slots are rebalanced by a workgroup of o_big (job queue + one scratch stretch per workgroup)
   uint32_t big_min;
   dev::BigJob *jobs;
@@ -1779,7 +1781,7 @@ PMA_KERNEL void o_plan(OptArgs a) {
     // ... and so is an update that has ALREADY been deferred at least once and whose window is big (a.defer_barrier
     // slots): its window keeps growing while it waits behind a hot range, and everything committed around it meanwhile
     // is a candidate for a rollback
-    if ((pr.wlen >= a.v.big_window / 4 || (a.defer_barrier && wid < used && pr.wlen >= a.defer_barrier)) && lane == 0)
+    if ((pr.wlen >= a.soft_barrier || (a.defer_barrier && wid < used && pr.wlen >= a.defer_barrier)) && lane == 0)
       wv::atomic_min_u64(&c->gbar[par], key + 1ull);
     const uint32_t ml = pr.mv_lo, mh = pr.mv_hi;
     for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_min_u64(&a.v.vw[u], key);
@@ -1815,6 +1817,15 @@ PMA_KERNEL void o_check(OptArgs a) {
   const uint32_t tag = (uint32_t)(key >> 32);
   bool fail = (kind == K_EXCL) || key_earlier(gbar, tag, idx);
   uint32_t why = (kind == K_EXCL) ? 0u : (fail ? 1u : 99u);  // diagnostics: first reason (lowest code wins below)
+  if (fail) {
+    // An exclusive update, or one behind this round's barrier: it does not commit now, and neither does anything after it
+    // (the barrier is earlier than all of them), so there is nobody to keep out of its regions and nothing to learn from
+    // its footprint — which, for a climb towards the root, is every leaf of the array (a 3.5 ms walk by one wave, while
+    // the rest of the launch waits).  Its stamps are looked at in the round that does check it.
+    if (a.diag && lane == 0) wv::atomic_add_u64(&c->why[why], 1ull);
+    if (lane == 0) a.status[wid] = 0u;
+    return;
+  }
 #define PMA_WHY(code) do { if (a.diag && (code) < why) why = (code); } while (0)
   bool stamp_bad = false;
   const uint32_t me1 = idx + 1u;  // stamps hold (index + 1) of the latest committed toucher
@@ -2123,11 +2134,24 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
     // more than can commit only makes every round slower — but a round's time grows far slower than its width (~30 us
     // + ~2.5 us per 1024 updates), so width is only given up when almost nothing of it commits.  Narrow by 1/4 when less
     // than 10 % of a full-width round committed, widen by 1/4 when more than 30 % did.
+    // Above one chip-full of waves (`resident`) only whole multiples make sense (a partly filled second pass costs a
+    // full pass of latency), and a multiple is only worth its re-planning when nearly all of the round commits: up at
+    // > 85 %, back down at < 70 % (config #4's partitions at critical density commit 60-70 % of a chip-full: at twice the
+    // width they lost 5 %; configs #2 / #3 commit 93-97 % and gain 11-12 %).
     uint32_t ch = cur_h ? cur_h : wcap;
+    const uint32_t res = c->resident;
     if (adaptive && hor >= ch) {  // only full-width rounds carry information about the width
-      if (ncommitted * 100u > hor * 30u) ch += ch / 4u;
-      else if (ncommitted * 100u < hor * 10u) ch -= ch / 4u;
+      if (res && ch >= res) {
+        if (ncommitted * 100u > hor * 85u) ch += res;
+        else if (ch > res && ncommitted * 100u < hor * 70u) ch -= res;
+        else if (ch == res && ncommitted * 100u < hor * 10u) ch -= ch / 4u;
+      } else {
+        if (ncommitted * 100u > hor * 30u) ch += ch / 4u;
+        else if (ncommitted * 100u < hor * 10u) ch -= ch / 4u;
+        if (res && ch > res) ch = res;
+      }
     }
+    if (res && ch > res) ch -= ch % res;
     if (ch < 1024u) ch = 1024u;
     if (ch > wcap) ch = wcap;  // (the launch grid — max_h — bounds the next round below, not the adapted width itself: the
                                // host narrows the grid at the tail of an epoch)
