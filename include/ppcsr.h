@@ -110,14 +110,19 @@ int ppcsr_pagerank(ppcsr_t h, const float *node_values, float *out, double *devi
 /* raw state for parity checks: items[N], nodes[n] exactly as the reference holds them (PCSR.h:67,128) */
 int ppcsr_export_state(ppcsr_t h, ppcsr_edge *items, ppcsr_node *nodes);
 int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out);
-/* knobs (int64 values):
- *   scheduler  "mode" (0 strict prefix rounds, 1 speculative rounds + validated rollback; default 1), "opt_horizon",
- *              "start_horizon", "adaptive", "epoch_ops", "region_slots", "small_batch" (batches up to this size take the
- *              strict rounds), "max_horizon" / "min_horizon" / "init_horizon" (strict rounds), "rounds_per_sync"
+/* knobs (int64 values; every key engine.cc's set_option accepts):
+ *   scheduler  "mode" (0 strict prefix rounds, 1 speculative rounds + validated rollback; default 1), "opt_horizon" (round
+ *              width cap; default 2 x "resident_waves" = 2 x CUs x 24), "start_horizon", "adaptive", "epoch_ops", "epoch_short", "epoch_grow_after",
+ *              "region_slots", "soft_barrier", "defer_barrier", "small_batch" (batches up to this size take the strict
+ *              rounds), "max_horizon" / "min_horizon" / "init_horizon" (strict rounds), "rounds_per_sync"
+ *   windows    "big_min" / "big_window" (slots: above big_min a workgroup of the round rebalances the window, above
+ *              big_window the update is exclusive), "big_grid", "excl_in_wave"
  *   rebalance  "scatter_variant" (0 LDS-staged, 1 register runs, 2 runs + in-tile leaf scan), "scatter_blocks",
- *              "rb_tile", "rb_min_tiles", "rb_prefetch"
+ *              "rb_tile", "rb_min_tiles", "rb_prefetch", "rb_inplace_min" (partial windows of at least this many slots are
+ *              rebalanced in place; 0 = always through the scratch array), "rb_inplace_cpw"
  *   search     "search_narrow" (0: literal binary walk only)
- *   measuring  "profile" (1: HIP events around every round kernel, reported through ppcsr_stats) */
+ *   measuring  "profile" (1: HIP events around every round kernel, reported through ppcsr_stats), "diag" (1: why updates
+ *              did not commit, per epoch, on stderr), "marker" (marker kernels for profile cuts), "test_block_rebalance" */
 int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value);
 /* device-side copy of the whole state and return to it (used by the benchmark to replay a batch on the same
  * core graph, and by the engine itself as the rollback point of speculative rounds); no reference equivalent */

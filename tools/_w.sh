@@ -1,17 +1,8 @@
-python bench.py --no-cpu-baseline --no-ref-cli --steps 3 > gpurun_out/w.json 2> gpurun_out/w.err || { tail -3 gpurun_out/w.err; exit 1; }
-python - <<PY
-import json
-d = json.loads(open('gpurun_out/w.json').read().strip().splitlines()[-1])
-print('config2', round(d['value']/1e6,1), d['engine']['rounds'], d['roofline']['kernel_ms'], d['roofline']['avg_launch_us'], d['parity_checked'])
-for k in ('config3_mixed','config5_shape_zipf'):
-    print(k, round(d[k]['value']/1e6,2), d[k]['engine']['rounds'], d[k]['engine']['replan_factor'], d[k]['parity_checked'])
-PY
-python bench.py --config 4 --no-cpu-baseline --no-ref-cli --steps 2 > gpurun_out/w4.json 2> gpurun_out/w4.err || { tail -3 gpurun_out/w4.err; exit 1; }
+for o in "opt_horizon=6144" "opt_horizon=12288" "opt_horizon=6144" "opt_horizon=12288"; do
+python bench.py --config 4 --no-cpu-baseline --no-ref-cli --no-secondary --no-check --steps 2 --opt $o > gpurun_out/w4.json 2> gpurun_out/w4.err || { tail -3 gpurun_out/w4.err; exit 1; }
 python - <<PY
 import json
 d = json.loads(open('gpurun_out/w4.json').read().strip().splitlines()[-1])
-print('config4', round(d['value']/1e6,1), d['ms_per_step'], d['engine']['rounds'], d['engine']['replan_factor'], d['parity_checked'])
-for k in d:
-    if isinstance(d[k], dict) and 'value' in d[k] and 'engine' in d[k]:
-        print(k, round(d[k]['value']/1e6,2), d[k]['engine']['rounds'], d[k]['engine']['replan_factor'], d[k].get('parity_checked'))
+print('$o', 'config4', round(d['value']/1e6,1), d['ms_per_step'], d['engine']['rounds'], d['engine']['replan_factor'])
 PY
+done
