@@ -110,8 +110,9 @@ struct Engine::Impl {
   // Round width (upper bound when `adaptive` is on).  One update = one wave; `resident_waves` of them fit the chip at once
   // (o_plan: 76 VGPRs = 6 waves per SIMD, 24 per CU, 6144 on 256 CUs).  A round's kernels are bound by latency, so a round
   // of 2 x resident takes ~1.4x the time of one of 1 x resident; widths in between leave the second pass partly empty
-  // (config #2, updates/s: 6144 -> 139 M, 8192 -> 130 M, 12288 -> 156 M, 18432 -> 159 M, 24576 -> 139 M: the re-planned
-  // share grows with the width).  init() sets opt_horizon = 2 x resident, start_horizon = resident.
+  // (config #2, updates/s: 6144 -> 139 M, 8192 -> 130 M, 12288 -> 162 M, 18432 -> 169 M, 24576 -> 153 M: the re-planned
+  // share grows with the width — 3 %, 7 %, 12 %).  init() sets opt_horizon = 3 x resident, start_horizon = resident; the
+  // adaptive width only climbs above 1 x while more than 85 % of a round commits.
   uint32_t resident_waves = 0;  // 0: unknown (emulator) — no quantisation of the adapted width
   uint32_t opt_horizon = 6144;
   uint32_t start_horizon = 6144;
@@ -290,7 +291,7 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
     if (cus > 0) {
       p.resident_waves = (uint32_t)cus * 24u;
       p.start_horizon = p.resident_waves;
-      p.opt_horizon = 2u * p.resident_waves;
+      p.opt_horizon = 3u * p.resident_waves;
     }
   }
   const uint64_t N = initial_N(init_n, src_n);

@@ -2215,7 +2215,7 @@ PMA_KERNEL void o_compact(OptArgs a) {
   PMA_SHARED uint32_t s_first;
   PMA_SHARED dev::BigShared sh;
   if (wv::block_idx() == 0) {
-    compact_block<8>(a, wsum, &s_first);
+    compact_block<24>(a, wsum, &s_first);  // (24 x 1024 threads: rounds up to 24576 wide stay in registers)
     return;
   }
   OptCtl *c = a.ctl;
