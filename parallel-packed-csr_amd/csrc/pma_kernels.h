@@ -2031,8 +2031,8 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
 // stable compaction of the deferred updates into the next carry list + next round's bookkeeping
 // ONE workgroup; everything it needs is requested in one batch of independent loads (control block, then each thread's
 // run of statuses and indices), because at ~6 K entries this step is nothing but load latency.
-// kPer: slots per thread held in registers (covers a horizon of kPer * blockDim).  wsum: 16 words of LDS, s_first_p: 1.
-template <uint32_t kPer>
+// kC: 64-slot chunks per wave held in registers (covers a horizon of kC * blockDim).  wsum: 16 words of LDS, s_first_p: 1.
+template <uint32_t kC>
 PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
@@ -2048,42 +2048,41 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
   const uint32_t tid = wv::thread_idx(), bd = wv::block_dim();
   const int lane = wv::lane(), w = wv::wave_in_block();
   const uint32_t nw = bd >> 6;
-  // each thread owns a run of consecutive slots, so ONE block-wide exclusive scan orders the whole horizon
-  const uint32_t per = (hor + bd - 1) / bd;
-  const uint32_t s0 = tid * per;
-  uint32_t mykeep = 0, mymaxc = 0;
-  uint32_t st[kPer], oi[kPer];
-  const bool regs = per <= kPer;
+  // Every wave owns a run of consecutive 64-slot chunks (lane l of chunk c: slot wbase + 64 c + l, so every load and every
+  // store is coalesced — with a run of consecutive slots per THREAD the 2 x kC loads of a wave touched 64 lines each, and
+  // at 18 K entries one CU's address path made this 15 us); a ballot per chunk counts and ranks, the waves' totals go
+  // through LDS.
+  const uint32_t cpw = (hor + nw * 64u - 1u) / (nw * 64u);  // chunks per wave
+  const uint32_t wbase = (uint32_t)w * cpw * 64u;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  uint32_t wkeep = 0, mymaxc = 0;
+  uint32_t st[kC], oi[kC];
+  const bool regs = cpw <= kC;
   if (regs) {
 #pragma unroll
-    for (uint32_t q = 0; q < kPer; q++) {
-      const uint32_t sl = s0 + q;
-      const bool in = q < per && sl < hor;
+    for (uint32_t q = 0; q < kC; q++) {
+      const uint32_t sl = wbase + q * 64u + (uint32_t)lane;
+      const bool in = q < cpw && sl < hor;
       st[q] = in ? a.status[sl] : OS_COMMITTED;
       oi[q] = in ? a.opidx[sl] : 0u;
     }
 #pragma unroll
-    for (uint32_t q = 0; q < kPer; q++) {
-      const bool in = q < per && s0 + q < hor;
-      if (in && st[q] != OS_COMMITTED) mykeep++;
-      else if (in && oi[q] + 1u > mymaxc) mymaxc = oi[q] + 1u;
+    for (uint32_t q = 0; q < kC; q++) {
+      if (q >= cpw) break;  // (wave-uniform)
+      const bool in = wbase + q * 64u + (uint32_t)lane < hor;
+      wkeep += (uint32_t)wv::popc64(wv::ballot(in && st[q] != OS_COMMITTED));
+      if (in && st[q] == OS_COMMITTED && oi[q] + 1u > mymaxc) mymaxc = oi[q] + 1u;
     }
   } else {
-    for (uint32_t q = 0; q < per; q++) {
-      const uint32_t sl = s0 + q;
-      if (sl < hor) {
-        if (a.status[sl] != OS_COMMITTED) mykeep++;
-        else if (a.opidx[sl] + 1u > mymaxc) mymaxc = a.opidx[sl] + 1u;
-      }
+    for (uint32_t q = 0; q < cpw; q++) {
+      const uint32_t sl = wbase + q * 64u + (uint32_t)lane;
+      const bool in = sl < hor;
+      const uint32_t s1 = in ? a.status[sl] : OS_COMMITTED, x = in ? a.opidx[sl] : 0u;
+      wkeep += (uint32_t)wv::popc64(wv::ballot(in && s1 != OS_COMMITTED));
+      if (in && s1 == OS_COMMITTED && x + 1u > mymaxc) mymaxc = x + 1u;
     }
   }
-  // wave-level inclusive scan of the per-thread counts, then wave totals through LDS
-  uint32_t incl = mykeep;
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
-    if (lane >= o) incl += y;
-  }
-  if (lane == 63) wsum[w] = incl;
+  if (lane == 0) wsum[w] = wkeep;
   if (tid == 0) *s_first_p = kMax;
   wv::block_sync();
   uint32_t woff = 0, tot = 0;
@@ -2091,23 +2090,33 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
     if (q < (uint32_t)w) woff += wsum[q];
     tot += wsum[q];
   }
-  uint32_t o = woff + incl - mykeep;
+  uint32_t o = woff;
   if (regs) {
 #pragma unroll
-    for (uint32_t q = 0; q < kPer; q++) {
-      if (q < per && s0 + q < hor && st[q] != OS_COMMITTED) {
-        if (o == 0) *s_first_p = oi[q];
-        cout[o++] = oi[q];
+    for (uint32_t q = 0; q < kC; q++) {
+      if (q >= cpw) break;
+      const bool keep = wbase + q * 64u + (uint32_t)lane < hor && st[q] != OS_COMMITTED;
+      const uint64_t m = wv::ballot(keep);
+      if (keep) {
+        const uint32_t pos = o + (uint32_t)wv::popc64(m & lt);
+        if (pos == 0) *s_first_p = oi[q];
+        cout[pos] = oi[q];
       }
+      o += (uint32_t)wv::popc64(m);
     }
   } else {
-    for (uint32_t q = 0; q < per; q++) {
-      const uint32_t sl = s0 + q;
-      if (sl < hor && a.status[sl] != OS_COMMITTED) {
-        const uint32_t x = a.opidx[sl];
-        if (o == 0) *s_first_p = x;
-        cout[o++] = x;
+    for (uint32_t q = 0; q < cpw; q++) {
+      const uint32_t sl = wbase + q * 64u + (uint32_t)lane;
+      const bool in = sl < hor;
+      const uint32_t s1 = in ? a.status[sl] : OS_COMMITTED, x = in ? a.opidx[sl] : 0u;
+      const bool keep = in && s1 != OS_COMMITTED;
+      const uint64_t m = wv::ballot(keep);
+      if (keep) {
+        const uint32_t pos = o + (uint32_t)wv::popc64(m & lt);
+        if (pos == 0) *s_first_p = x;
+        cout[pos] = x;
       }
+      o += (uint32_t)wv::popc64(m);
     }
   }
   const uint32_t ncommitted = hor - tot;

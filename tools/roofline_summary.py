@@ -96,13 +96,15 @@ def main():
     N = bj["config"]["N_slots"][0]
     for sec, w in (("full_rebalance", N), ("half_rebalance", N // 2)):
         ks = res[sec]["kernels"]
-        if "k_rb_scatter" in ks:
-            calls = ks["k_rb_scatter"]["launches"]
+        main = "k_rb_scatter" if "k_rb_scatter" in ks else next((k for k in ks if k.startswith("k_rb_inplace")), None)
+        if main:
+            calls = ks[main]["launches"]
             us = sum(v["total_ms"] for v in ks.values()) * 1e3 / calls
             hbm = sum((v.get("hbm_bytes_per_launch") or 0.0) * v["launches"] for v in ks.values()) / calls
             alg = 24.0 * w
             derived[sec] = {"window_slots": w, "calls": calls, "kernel_us_per_call": us, "alg_bytes": alg, "achieved_GBps": alg / (us * 1e-6) / 1e9,
-                            "frac_of_8TBps": alg / (us * 1e-6) / 1e9 / HBM_PEAK, "hbm_bytes_per_call": hbm, "traffic_over_algorithmic": hbm / alg}
+                            "frac_of_8TBps": alg / (us * 1e-6) / 1e9 / HBM_PEAK, "hbm_bytes_per_call": hbm, "traffic_over_algorithmic": hbm / alg,
+                            "kernels": {k: round(v["avg_us"], 2) for k, v in ks.items()}}
     ks = res["scan_all"]["kernels"]
     if "k_scan_write" in ks and bj.get("neighbour_scan"):
         calls = ks["k_scan_write"]["launches"]
