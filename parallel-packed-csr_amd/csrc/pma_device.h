@@ -317,7 +317,12 @@ struct InsertPlan {
 // range [min_node,max_node] is tracked only as far as it steers `tries`.
 // c_leaf: leafcnt of index's leaf, gap_right: find_gap_right(index + 1) when occupied — both loaded by the caller in one
 // batch so that they do not sit one behind the other on the dependent-load chain.
-PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, uint32_t c_leaf, uint32_t gap_right, RangeRec &rr) {
+// cap: a window beyond this many slots is not for the caller to handle (the round planner: View::big_window — the update
+// turns exclusive whatever the final window is, and the exclusive executor plans again with no cap): the climb stops there
+// instead of counting on towards the root, which is a walk over every leaf of the array by ONE wave (1 ms at 2^24 slots)
+// while the rest of the launch waits.
+PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, uint32_t c_leaf, uint32_t gap_right, RangeRec &rr,
+                               uint64_t cap = ~0ull) {
   const Geometry &g = v.g;
   const int sh = g.sh;
   const uint64_t logN = (uint64_t)g.logN;
@@ -366,6 +371,11 @@ PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, uin
     }
     while ((uint64_t)c + 1 >= (uint64_t)g.t_up[level]) {  // PCSR.cpp:1028-1061
       len *= 2;
+      if (len > cap && len <= g.N) {
+        out.max_len = len;
+        out.node_index_final = node_index & ~(len - 1);
+        return out;
+      }
       if (len <= g.N) {
         level--;
         const uint64_t new_idx = node_index & ~(len - 1);
@@ -419,7 +429,7 @@ struct RemovePlan {
   int half;  // climb reached the root: half_list()
   uint64_t wstart, wlen;
 };
-PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index, RangeRec &rr) {
+PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index, RangeRec &rr, uint64_t cap = ~0ull) {
   const Geometry &g = v.g;
   const int sh = g.sh;
   RemovePlan out;
@@ -431,6 +441,7 @@ PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index, RangeRec &rr) {
   rec_range(rr, v, (uint32_t)node_index, (uint32_t)node_index);
   while ((uint64_t)c < (uint64_t)g.t_lo[level] + 1) {  // (c - 1) < t_lo
     len *= 2;
+    if (len > cap && len <= g.N) break;  // (wlen > cap: exclusive, see plan_insert)
     if (len <= g.N) {
       level--;
       const uint64_t new_idx = node_index & ~(len - 1);
@@ -885,7 +896,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
         wl = wh = leaf;
       } else {
         const uint32_t gap_right = occupied ? find_gap_right(v, index + 1, kMaxSlide, true, nul0, kGapPre) : index;
-        InsertPlan ip = plan_insert(v, index, occupied, c_leaf, gap_right, rr);
+        InsertPlan ip = plan_insert(v, index, occupied, c_leaf, gap_right, rr, v.big_window);
         // tries > 3 (PCSR.cpp:952-955): the reference gives up on leaf locks, takes the global write lock and runs
         // insert(..., nullptr) — same slide, same write, but the window comes from POST-insert densities (PCSR.cpp:578-590).
         // That climb is a function of the leaf counts and of where the slide's gap is, so it is planned here like any
@@ -947,6 +958,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
                 need_double = true;
                 break;
               }
+              if (len > v.big_window) break;  // exclusive whatever the final window is (see plan_insert's cap)
               level--;
               const uint64_t new_idx = node_index & ~(len - 1);
               if (len == wn) {
@@ -990,7 +1002,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
       if (!occupied || is_sentinel(elem) || at.dest != op.dst) {
         kind = K_NOTFOUND;
       } else {
-        const RemovePlan rp = plan_remove(v, index, rr);
+        const RemovePlan rp = plan_remove(v, index, rr, v.big_window);
         if (rp.half || rp.wlen > v.big_window) {
           kind = K_EXCL;
         } else {
