@@ -125,6 +125,31 @@ def test_horizon_options_changed_between_batches(pkg, streams):
     _same(eng, o, "after option changes")
 
 
+@pytest.mark.parametrize("opts", [
+    {"resident_waves": 0, "opt_horizon": 6144},                       # round 1's fixed width, no quantisation
+    {"resident_waves": 6144, "opt_horizon": 24576},                   # up to four passes of resident waves
+    {"resident_waves": 1024, "opt_horizon": 3072, "start_horizon": 512},
+    {"soft_barrier": 1 << 30, "epoch_short": 1024, "epoch_grow_after": 1},
+    {"soft_barrier": 2048, "epoch_short": 4096, "epoch_grow_after": 8, "rb_inplace_min": 4096, "big_window": 8192},
+])
+def test_scheduler_knobs_do_not_change_the_result(pkg, streams, opts):
+    """round width in multiples of the resident waves, soft barrier, epoch lengths, in-place windows: every setting is a
+    schedule of the same sequential semantics — RMAT hubs + a hot-vertex tail, slot by slot against the oracle"""
+    n = 1 << 15
+    s, d = streams.rmat_edges(15, 400000, seed=8)
+    zs = streams.zipf_sources(n, 60000, seed=9, alpha=1.2)
+    ops = np.concatenate([streams.adds(s, d), streams.adds(zs, streams.uniform_ints(10, 60000, n))])
+    ops = np.concatenate([ops, streams.mixed_existing_stream(ops[:400000], streams.adds(*streams.rmat_edges(15, 30000, seed=11)), seed=12)])
+    eng, o = pkg.PCSR(n), Oracle(n)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    eng.apply(ops)
+    o.apply(ops)
+    _same(eng, o, str(opts))
+    st = eng.stats()
+    assert st["committed"] >= len(ops) - st["exclusive_ops"] - 1
+
+
 def test_hubs_and_last_vertex(mk, streams):
     m = 20000
     for src_mode in ("last", "first", "tail"):
