@@ -1037,11 +1037,15 @@ int Engine::run_exclusive(Op op, uint32_t flags, const Op *d_ops, uint32_t spec_
     xv.vws = p.d_vws;
     xv.scratch_plan = p.d_xplan;
     xv.me1 = (spec && attempt == 0) ? spec_index + 1u : 0u;  // (a retry follows a doubling: whole-array rule, see the caller)
+    const auto tx0 = std::chrono::steady_clock::now();
     GPU_LAUNCH(p.stream, k_exclusive, 1, 64, p.v, op, d_ops, spec ? spec_index : kMax, flags, p.d_xout, p.d_stats, p.excl_in_wave, xv);
     GCHK(gpu::d2h(p.h_xout, p.d_xout, sizeof(ExclOut), p.stream));
     GCHK(gpu::sync(p.stream));
     GCHK(gpu::last_error());
     const ExclOut x = *p.h_xout;
+    if (getenv("PPCSR_TRACE_EXCL"))
+      fprintf(stderr, "[excl] op (%u,%u,%u) flags %u -> result %u window (%u,%u) found %u, %.0f us\n", op.src, op.dst, op.op, flags, x.result, x.wstart, x.wlen, x.found,
+              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tx0).count());
     switch (x.result) {
       case X_DONE: return PPCSR_OK;
       case X_VIOLATION:

@@ -54,9 +54,29 @@ PMA_DEV uint32_t count_leaves(const View &v, uint32_t leaf_lo, uint32_t nleaves)
   for (uint32_t i = (uint32_t)wv::lane(); i < nleaves; i += 64) s += v.leafcnt[leaf_lo + i];
   return wv::reduce_add(s);
 }
-PMA_DEV uint32_t count_window(const View &v, uint64_t start, uint64_t len) {
+// the same for the exclusive executor, whose climbs go all the way to the root (2^19 leaves at 2^24 slots: one load per trip
+// made that a 3 ms walk): 16 leaves per lane per trip, four 16-byte loads in flight.  Not for the round planner — its
+// climbs stop at big_window, and these registers would cost it a wave per SIMD.
+PMA_DEV uint32_t count_leaves_wide(const View &v, uint32_t leaf_lo, uint32_t nleaves) {
+  if (nleaves < 1024u || (leaf_lo & 3u)) return count_leaves(v, leaf_lo, nleaves);
+  const uint4 *p4 = reinterpret_cast<const uint4 *>(v.leafcnt + leaf_lo);
+  const uint32_t n4 = nleaves >> 2;  // (a power of two >= 256)
+  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (uint32_t i = (uint32_t)wv::lane(); i < n4; i += 256u) {
+    const uint4 a = p4[i], b = p4[i + 64u], c = p4[i + 128u], d = p4[i + 192u];
+    s0 += a.x + a.y + a.z + a.w;
+    s1 += b.x + b.y + b.z + b.w;
+    s2 += c.x + c.y + c.z + c.w;
+    s3 += d.x + d.y + d.z + d.w;
+  }
+  return wv::reduce_add(s0 + s1 + s2 + s3);
+}
+template <bool WIDE>
+PMA_DEV uint32_t count_window_t(const View &v, uint64_t start, uint64_t len) {
+  if (WIDE) return count_leaves_wide(v, (uint32_t)(start >> v.g.sh), (uint32_t)(len >> v.g.sh));
   return count_leaves(v, (uint32_t)(start >> v.g.sh), (uint32_t)(len >> v.g.sh));
 }
+PMA_DEV uint32_t count_window(const View &v, uint64_t start, uint64_t len) { return count_window_t<false>(v, start, len); }
 
 // fix the node index after sentinel `e` has been placed at slot `in` (fix_sentinel, PCSR.cpp:168-183)
 PMA_DEV void fix_sentinel(const View &v, const Edge &e, uint32_t in) {
@@ -321,6 +341,7 @@ struct InsertPlan {
 // turns exclusive whatever the final window is, and the exclusive executor plans again with no cap): the climb stops there
 // instead of counting on towards the root, which is a walk over every leaf of the array by ONE wave (1 ms at 2^24 slots)
 // while the rest of the launch waits.
+template <bool WIDE = false>
 PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, uint32_t c_leaf, uint32_t gap_right, RangeRec &rr,
                                uint64_t cap = ~0ull) {
   const Geometry &g = v.g;
@@ -388,11 +409,11 @@ PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, uin
             break;
           }
           // window grew to the left: new count = old window + left half
-          c += count_window(v, new_idx, len / 2);
+          c += count_window_t<WIDE>(v, new_idx, len / 2);
           rec_range(rr, v, (uint32_t)new_idx, (uint32_t)(new_idx + len / 2 - 1));
           node_index = new_idx;
         } else {
-          c += count_window(v, new_idx + len / 2, len / 2);
+          c += count_window_t<WIDE>(v, new_idx + len / 2, len / 2);
           rec_range(rr, v, (uint32_t)(new_idx + len / 2), (uint32_t)(new_idx + len - 1));
         }
       } else {
@@ -429,6 +450,7 @@ struct RemovePlan {
   int half;  // climb reached the root: half_list()
   uint64_t wstart, wlen;
 };
+template <bool WIDE = false>
 PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index, RangeRec &rr, uint64_t cap = ~0ull) {
   const Geometry &g = v.g;
   const int sh = g.sh;
@@ -446,11 +468,11 @@ PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index, RangeRec &rr, uint
       level--;
       const uint64_t new_idx = node_index & ~(len - 1);
       if (new_idx < node_index) {
-        c += count_window(v, new_idx, len / 2);
+        c += count_window_t<WIDE>(v, new_idx, len / 2);
         rec_range(rr, v, (uint32_t)new_idx, (uint32_t)(new_idx + len / 2 - 1));
         node_index = new_idx;
       } else {
-        c += count_window(v, new_idx + len / 2, len / 2);
+        c += count_window_t<WIDE>(v, new_idx + len / 2, len / 2);
         rec_range(rr, v, (uint32_t)(new_idx + len / 2), (uint32_t)(new_idx + len - 1));
       }
     } else {

@@ -182,14 +182,38 @@ struct XValid {
   Plan *scratch_plan;  // receives the read ranges of the search
   uint32_t me1;
 };
+// does a[lo..hi] hold a value above thr?  (this lane's share; the caller ballots.)  An exclusive update's window can be the
+// whole array — 2^19 stamps per array: one 4-byte load per trip made the executor's validation a 4 ms walk (8 ns per leaf,
+// pure latency); long ranges go 16 stamps per lane per trip, four 16-byte loads in flight.
+PMA_DEV bool xv_any_above(const uint32_t *a, uint64_t lo, uint64_t hi, uint32_t thr) {
+  const uint64_t lane = (uint64_t)wv::lane();
+  bool bad = false;
+  if (hi >= lo && hi - lo >= 2048u) {
+    const uint64_t al = (lo + 3u) & ~3ull;
+    for (uint64_t i = lo + lane; i < al; i += 64) bad |= a[i] > thr;
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(a + al);
+    const uint64_t n4 = (hi + 1u - al) >> 2;
+    uint64_t i = lane;
+    for (; i + 192u < n4; i += 256u) {
+      const uint4 x = p4[i], y = p4[i + 64u], z = p4[i + 128u], w = p4[i + 192u];
+      bad |= x.x > thr || x.y > thr || x.z > thr || x.w > thr || y.x > thr || y.y > thr || y.z > thr || y.w > thr;
+      bad |= z.x > thr || z.y > thr || z.z > thr || z.w > thr || w.x > thr || w.y > thr || w.z > thr || w.w > thr;
+    }
+    for (; i < n4; i += 64u) {
+      const uint4 x = p4[i];
+      bad |= x.x > thr || x.y > thr || x.z > thr || x.w > thr;
+    }
+    lo = al + (n4 << 2);
+  }
+  for (uint64_t i = lo + lane; i <= hi; i += 64) bad |= a[i] > thr;
+  return bad;
+}
 PMA_DEV bool xv_bad_writes(const View &v, const XValid &xv, uint64_t leaf_lo, uint64_t leaf_hi) {
   if (!xv.me1) return false;
   const uint64_t nleaves = v.g.N >> v.g.sh;
   if (leaf_lo > 0) leaf_lo--;
   if (leaf_hi + 1 < nleaves) leaf_hi++;
-  bool bad = false;
-  for (uint64_t l = leaf_lo + (uint64_t)wv::lane(); l <= leaf_hi; l += 64)
-    if (xv.wstamp[l] > xv.me1 || xv.rstamp[l] > xv.me1) bad = true;
+  const bool bad = xv_any_above(xv.wstamp, leaf_lo, leaf_hi, xv.me1) || xv_any_above(xv.rstamp, leaf_lo, leaf_hi, xv.me1);
   return wv::ballot(bad) != 0;
 }
 PMA_DEV bool xv_bad_reads(const View &v, const XValid &xv, const dev::RangeRec &rr, uint32_t src) {
@@ -198,8 +222,7 @@ PMA_DEV bool xv_bad_reads(const View &v, const XValid &xv, const dev::RangeRec &
   const uint32_t nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
   for (uint32_t r = 0; r < nr; r++) {
     const uint32_t lo = xv.scratch_plan->rlo[r], hi = xv.scratch_plan->rhi[r];
-    for (uint32_t l = lo + (uint32_t)wv::lane(); l <= hi; l += 64)
-      if (xv.wstamp[l] > xv.me1) bad = true;
+    bad |= xv_any_above(xv.wstamp, lo, hi, xv.me1);
   }
   if (wv::lane() == 0 && (rr.sdep & 1u) && xv.vws[src] > xv.me1) bad = true;
   if (wv::lane() == 1 && (rr.sdep & 2u) && src + 1u < v.g.n && xv.vws[src + 1u] > xv.me1) bad = true;
@@ -266,7 +289,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
       ip.max_len = logN;
       ip.node_index_final = 0;
       if (!(flags & XF_FORCE_NOINFO) && !add_node) {
-        ip = dev::plan_insert(v, index, occupied, v.leafcnt[index >> g.sh],
+        ip = dev::plan_insert<true>(v, index, occupied, v.leafcnt[index >> g.sh],
                               occupied ? dev::find_gap_right(v, index + 1, kMaxSlide) : index, rr);
         status = ip.status;
       }
@@ -362,10 +385,10 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
               level--;
               const uint64_t new_idx = node_index & ~(len - 1);
               if (new_idx < node_index) {
-                c += dev::count_window(v, new_idx, len / 2);
+                c += dev::count_window_t<true>(v, new_idx, len / 2);
                 node_index = new_idx;
               } else {
-                c += dev::count_window(v, new_idx + len / 2, len / 2);
+                c += dev::count_window_t<true>(v, new_idx + len / 2, len / 2);
               }
             } else {
               result = X_NEED_DOUBLE;
@@ -410,7 +433,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
         if (lane == 0) wv::atomic_add_u64(&st->not_found, 1ull);
       } else {
         found = 1;
-        const dev::RemovePlan rp = dev::plan_remove(v, index, rr);
+        const dev::RemovePlan rp = dev::plan_remove<true>(v, index, rr);
         if (xv_bad_reads(v, xv, rr, op.src) ||
             (!rp.half && xv_bad_writes(v, xv, rp.wstart >> sh, (rp.wstart + rp.wlen - 1) >> sh)))
           PMA_X_VIOLATION();

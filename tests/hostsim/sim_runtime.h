@@ -16,6 +16,9 @@
 #define PMA_LAUNCH_BOUNDS(threads, waves_per_simd)
 #define PMA_SHARED static
 
+struct uint4 {
+  uint32_t x, y, z, w;
+};
 namespace sim {
 struct Fiber;
 extern Fiber *cur;
