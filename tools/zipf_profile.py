@@ -1,3 +1,6 @@
+"""The hot-vertex stress stream (config #5's shape on the config #2 graph): 1 M inserts whose sources are Zipf(1.2) ranks —
+18 % of them into ONE vertex.  python3 tools/zipf_profile.py [option=value ...]; PPCSR_TRACE_EXCL=1 lists the exclusive
+updates, option diag=1 prints per epoch why planned updates did not commit."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
