@@ -113,9 +113,9 @@ def test_horizon_options_changed_between_batches(pkg, streams):
     ops = streams.random_stream(n, 90000, seed=77, p_delete=0.15)
     eng, o = pkg.PCSR(n), Oracle(n)
     eng.set_option("small_batch", 0)
-    eng.apply(ops[:30000])               # speculative, 6144-wide rounds
+    eng.apply(ops[:30000])               # speculative, rounds up to opt_horizon wide (3 x the resident waves)
     eng.set_option("max_horizon", 1024)  # used to reallocate the shared buffer with 1024 records
-    eng.apply(ops[30000:60000])          # speculative again: o_plan writes plans[wid] for wid < 6144
+    eng.apply(ops[30000:60000])          # speculative again: o_plan writes plans[wid] for wid < opt_horizon
     eng.set_option("mode", 0)
     eng.apply(ops[60000:75000])          # strict rounds on the same buffer
     eng.set_option("mode", 1)

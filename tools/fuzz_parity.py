@@ -49,6 +49,10 @@ for c in range(cases):
     if rng.integers(0, 2):
         opts = dict(opt_horizon=int(rng.choice([256, 1024, 6144, 16384])), region_slots=int(rng.choice([64, 1024, 4096])),
                     epoch_ops=int(rng.choice([4096, 65536, 1 << 20])), small_batch=int(rng.choice([0, 256, 5000])))
+    if rng.integers(0, 2):  # round-2 knobs: width in multiples of a (pretended) chip-full, barrier, big windows, epochs
+        opts.update(resident_waves=int(rng.choice([0, 512, 6144])), big_window=int(rng.choice([2048, 8192, 32768])),
+                    soft_barrier=int(rng.choice([0, 1024, 1 << 30])), rb_inplace_min=int(rng.choice([0, 2048, 1 << 19])),
+                    epoch_short=int(rng.choice([512, 16384])), epoch_grow_after=int(rng.choice([1, 2, 8])))
     if rng.integers(0, 5) == 0:
         opts["mode"] = 0
     eng, o = pkg.PCSR(n, lock_search=lock), Oracle(n, lock_search=lock)
