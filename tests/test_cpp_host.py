@@ -46,15 +46,19 @@ def test_reference_parallel_tests_restated():
 def test_cli_pppcsr_drives_all_partitions_at_once(tmp_path):
     """-pppcsrnuma -partitions_per_domain=8 on one GPU: the CLI's PPPCSR shim sits on pppcsr_apply_batch (owner bucketing +
     one host thread and stream per partition), so all partitions are applied at once: its phase-2 time must beat the same
-    binary forced to drive the partitions one after the other (PPCSR_PP_THREADS=1) by a clear margin, and stay close to
-    the same C-ABI call issued from python (a different HIP runtime build — PyTorch's bundled one — hence the loose bound)"""
+    binary forced to drive the partitions one after the other (PPCSR_PP_THREADS=1), and stay close to the same C-ABI call
+    issued from python (a different HIP runtime build — PyTorch's bundled one — hence the loose bound).  The batch is
+    250 K updates per partition: since the rounds are three chip-fulls of waves wide, ONE partition fills the GPU while its
+    kernels run, and what running them side by side buys is the overlap of one partition's host round trips with the
+    others' kernels (config #4 at full size on one GPU: 140 ms against 234 ms one after the other); at 62 K updates per
+    partition the eight host threads cost more than that (28 ms against 23 ms)."""
     import time
     import pandas as pd
     from helpers import load_pkg
     _ensure_built()
     st = load_streams()
     pkg = load_pkg()
-    scale, m, u = 18, 2_000_000, 500_000
+    scale, m, u = 18, 2_000_000, 2_000_000
     s, d = st.rmat_edges(scale, m, seed=1)
     n0 = 1 << scale
     core = st.adds(st.permute_labels(s, n0), d)
@@ -93,7 +97,7 @@ def test_cli_pppcsr_drives_all_partitions_at_once(tmp_path):
         ms = float([l for l in r.stdout.splitlines() if l.startswith("MS")][0].split()[1])
         best_py = ms if best_py is None else min(best_py, ms)
     print(f"cli phase 2: {best_cli} ms (partitions one after the other: {serial_cli} ms), pppcsr_apply_batch from python: {best_py:.1f} ms")
-    assert best_cli <= serial_cli + 2.0, (best_cli, serial_cli)  # all partitions at once (8 x 62 K updates: mostly fixed costs; +2: whole ms)
+    assert best_cli <= serial_cli + 2.0, (best_cli, serial_cli)  # all partitions at once (+2: the CLI prints whole ms)
     assert best_cli <= 2.0 * best_py + 3.0, (best_cli, best_py)
 
 
