@@ -108,13 +108,13 @@ struct Engine::Impl {
   uint32_t epoch_clean = 0, epoch_grow_after = 2;  // clean epochs in a row / how many of them double the length again
   uint32_t region_slots = 4096;  // per-region prefix rule (>= kBigWindow so a window never leaves its region)
   // Round width (upper bound when `adaptive` is on).  One update = one wave; `resident_waves` of them fit the chip at once
-  // (o_plan: 76 VGPRs = 6 waves per SIMD, 24 per CU, 6144 on 256 CUs).  A round's kernels are bound by latency, so a round
+  // (o_plan: 78 VGPRs = 6 waves per SIMD, 24 per CU, 6144 on 256 CUs).  A round's kernels are bound by latency, so a round
   // of 2 x resident takes ~1.4x the time of one of 1 x resident; widths in between leave the second pass partly empty
   // (config #2, updates/s: 6144 -> 139 M, 8192 -> 130 M, 12288 -> 162 M, 18432 -> 169 M, 24576 -> 153 M: the re-planned
   // share grows with the width — 3 %, 7 %, 12 %).  init() sets opt_horizon = 3 x resident, start_horizon = resident; the
   // adaptive width only climbs above 1 x while more than 85 % of a round commits.
   uint32_t resident_waves = 0;  // 0: unknown (emulator) — no quantisation of the adapted width
-  uint32_t opt_horizon = 6144;
+  uint32_t opt_horizon = 6144;    // (the CPU emulator, which reports no CUs, keeps these)
   uint32_t start_horizon = 6144;
   uint32_t adaptive = 1;
   uint32_t scatter_blocks = 8192;

@@ -1670,7 +1670,7 @@ struct OptCtl {
   uint32_t resident;               // waves the chip holds at once (0 = unknown): above it the width moves in whole multiples
   uint32_t maxc;  // 1 + largest stream index committed in this epoch
   uint32_t viol_idx;  // smallest stream index whose commit-time validation failed
-  uint32_t adaptive;     // 1: adapt cur_horizon (experimental; a fixed width of 6144 measured best on config #2)
+  uint32_t adaptive;     // 1: adapt cur_horizon to the share of a round that commits (see compact_block)
   uint32_t cur_horizon;  // adaptive round width (<= max_horizon): grows while most of the round commits, shrinks otherwise
   unsigned long long gbar[2];  // keyed min index of a K_EXCL update in the horizon
   unsigned long long rounds, committed, planned, blocked, failed;
