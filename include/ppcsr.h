@@ -119,7 +119,7 @@ int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out);
  *              big_window the update is exclusive), "big_grid", "excl_in_wave"
  *   rebalance  "scatter_variant" (0 LDS-staged, 1 register runs, 2 runs + in-tile leaf scan), "scatter_blocks",
  *              "rb_tile", "rb_min_tiles", "rb_prefetch", "rb_inplace_min" (partial windows of at least this many slots are
- *              rebalanced in place; 0 = always through the scratch array), "rb_inplace_cpw"
+ *              rebalanced in place; 0 = always through the scratch array), "rb_inplace_cpw", "rb_inplace_lists"
  *   search     "search_narrow" (0: literal binary walk only)
  *   measuring  "profile" (1: HIP events around every round kernel, reported through ppcsr_stats), "diag" (1: why updates
  *              did not commit, per epoch, on stderr), "marker" (marker kernels for profile cuts), "test_block_rebalance" */

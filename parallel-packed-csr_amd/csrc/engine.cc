@@ -136,6 +136,7 @@ struct Engine::Impl {
   uint32_t rb_inplace_cpw = 0;   // 64-slot chunks per wave of an in-place tile (8 or 16; 0 = by window size)
   uint32_t *d_ip = nullptr;      // in-place rebalance: header (sticky error, ticket counters), tile order, the tiles' flags
   uint32_t ip_epoch = 0;
+  uint32_t ip_lists = 1;         // ticket lists of the in-place rebalance: the XCD ids seen at creation (k_xcc_probe), else 1
   bool ip_used = false;          // an in-place rebalance ran since the error flag was last looked at
   uint32_t scatter_variant = 2;  // 0: LDS-staged k_scatter_fill, 1: register-run k_scatter_runs, 2: runs + in-tile leaf scan (3 launches)
   bool carry_dumped = false;
@@ -322,6 +323,25 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   GCHK(gpu::dmalloc((void **)&p.d_table, sizeof(ChainTable)));
   GCHK(gpu::dmalloc((void **)&p.d_ip, (kIpHdrWords + 2 * (uint64_t)kIpMaxTiles) * sizeof(uint32_t)));
   GCHK(gpu::dset(p.d_ip, 0, (kIpHdrWords + 2 * (uint64_t)kIpMaxTiles) * sizeof(uint32_t), p.stream));
+  {  // which XCD ids do workgroups report here?  (the in-place rebalance stripes its ticket counter over them)
+    uint32_t *probe = p.d_ip + kIpHdrWords;  // (scratch: the order list is written before every use)
+    GPU_LAUNCH(p.stream, k_xcc_probe, 2048, 64, probe);
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    GCHK(gpu::d2h(cnt, probe, sizeof(cnt), p.stream));
+    GCHK(gpu::sync(p.stream));
+    GCHK(gpu::dset(probe, 0, sizeof(cnt), p.stream));
+    uint32_t L = 0, lo = ~0u, hi = 0;
+    while (L < 8 && cnt[L]) L++;
+    bool ok = (L == 1 || L == 2 || L == 4 || L == 8);
+    for (uint32_t i = 0; i < 8; i++) {
+      if (i >= L && cnt[i]) ok = false;  // (ids must be exactly 0 .. L-1)
+      if (i < L) {
+        lo = std::min(lo, cnt[i]);
+        hi = std::max(hi, cnt[i]);
+      }
+    }
+    p.ip_lists = (ok && lo * 2 >= hi) ? L : 1u;
+  }
   GCHK(ensure_plans(p));
   memset(p.h_ctl, 0, sizeof(Control));
 
@@ -485,6 +505,11 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "rb_min_tiles") {
     p.rb_min_tiles = value < 1 ? 1u : (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "rb_inplace_lists") {  // (test hook: 1, 2, 4 or 8 ticket lists whatever the probe saw)
+    if (value != 1 && value != 2 && value != 4 && value != 8) return fail(PPCSR_EINVAL, "rb_inplace_lists must be 1, 2, 4 or 8");
+    p.ip_lists = (uint32_t)value;
     return PPCSR_OK;
   }
   if (k == "rb_inplace_cpw") {
@@ -1272,10 +1297,10 @@ int Engine::big_redistribute(uint64_t wstart, uint64_t wlen, bool sync) {
       GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, wstart, wlen, order, p.d_ip, tile_slots);
       if (cpw == 8)
         GPU_LAUNCH(p.stream, k_rb_inplace8, ntiles, 256, v, wstart, wlen, v.g.sh, (const uint32_t *)p.d_rank, (const uint32_t *)p.d_tiles,
-                   (const ChainTable *)p.d_table, (const uint32_t *)order, p.d_ip, flags, p.ip_epoch);
+                   (const ChainTable *)p.d_table, (const uint32_t *)order, p.d_ip, flags, p.ip_epoch, p.ip_lists);
       else
         GPU_LAUNCH(p.stream, k_rb_inplace16, ntiles, 256, v, wstart, wlen, v.g.sh, (const uint32_t *)p.d_rank, (const uint32_t *)p.d_tiles,
-                   (const ChainTable *)p.d_table, (const uint32_t *)order, p.d_ip, flags, p.ip_epoch);
+                   (const ChainTable *)p.d_table, (const uint32_t *)order, p.d_ip, flags, p.ip_epoch, p.ip_lists);
       p.ip_used = true;
       if (sync) {
         GCHK(gpu::sync(p.stream));

@@ -1015,25 +1015,27 @@ constexpr uint32_t kIpSpinLimit = 1u << 22;
 template <int CPW>  // chunks (64 slots) per wave: the tile is 4 * CPW * 64 slots
 PMA_DEV void rb_inplace_body(const View &v, uint64_t wstart, uint64_t wlen, int sh, const uint32_t *__restrict__ cnt,
                              const uint32_t *__restrict__ tile_excl, const ChainTable *tb, const uint32_t *__restrict__ order, uint32_t *ctl,
-                             uint32_t *flags, uint32_t epoch) {
+                             uint32_t *flags, uint32_t epoch, uint32_t nlists) {
   PMA_SHARED ChainTable stb;
   PMA_SHARED uint32_t pre[kRbTile];
   PMA_SHARED uint32_t wsum[4];
   PMA_SHARED uint32_t s_tile;
   constexpr uint32_t kTileSlots = 4u * CPW * 64u;
   if (wv::thread_idx() == 0) {
-    // Ticket: position t * 8 + x of the order, drawn from the counter of this workgroup's XCD x (one counter for all would
-    // hand out ~one ticket per 9 ns: same-address atomics are served one after the other).  Each of the 8 sub-lists is
+    // Ticket: position t * L + x of the order, drawn from the counter of this workgroup's XCD x (one counter for all would
+    // hand out ~one ticket per 9 ns: same-address atomics are served one after the other).  Each of the L sub-lists is
     // consumed in order, and a workgroup turns to another XCD's list only when its own is used up, so the earliest
     // unfinished tile of the order is always held by a resident workgroup or is the next ticket of an XCD with free slots.
-    const uint32_t ntiles = (uint32_t)(wlen / kTileSlots), xcc = wv::xcc_id();
+    // L = nlists is the number of XCD ids the engine SAW workgroups run on when it was created (k_xcc_probe: 8 on an
+    // MI355X in SPX mode; 1 — a single list, safe whatever the dispatcher does — if the ids were not 0..L-1 evenly).
+    const uint32_t ntiles = (uint32_t)(wlen / kTileSlots), L = nlists, xcc = wv::xcc_id() % L;
     uint32_t pos = 0xFFFFFFFFu;
-    for (uint32_t a = 0; a < 8u && pos == 0xFFFFFFFFu; a++) {
-      const uint32_t x = (xcc + a) & 7u;
-      const uint32_t have = x < ntiles ? (ntiles - x + 7u) / 8u : 0u;
+    for (uint32_t a = 0; a < L && pos == 0xFFFFFFFFu; a++) {
+      const uint32_t x = (xcc + a) % L;
+      const uint32_t have = x < ntiles ? (ntiles - x + L - 1u) / L : 0u;
       if (have == 0u) continue;
       const uint32_t t = wv::atomic_add_u32(&ctl[kIpTicketStride * (1u + x)], 1u);
-      if (t < have) pos = t * 8u + x;
+      if (t < have) pos = t * L + x;
     }
     s_tile = pos == 0xFFFFFFFFu ? pos : order[pos];
   }
@@ -1118,12 +1120,16 @@ PMA_DEV void rb_inplace_body(const View &v, uint64_t wstart, uint64_t wlen, int 
   }
 }
 PMA_KERNEL void k_rb_inplace8(View v, uint64_t wstart, uint64_t wlen, int sh, const uint32_t *cnt, const uint32_t *tile_excl, const ChainTable *tb,
-                              const uint32_t *order, uint32_t *ctl, uint32_t *flags, uint32_t epoch) {
-  rb_inplace_body<8>(v, wstart, wlen, sh, cnt, tile_excl, tb, order, ctl, flags, epoch);
+                              const uint32_t *order, uint32_t *ctl, uint32_t *flags, uint32_t epoch, uint32_t nlists) {
+  rb_inplace_body<8>(v, wstart, wlen, sh, cnt, tile_excl, tb, order, ctl, flags, epoch, nlists);
+}
+// which XCD ids do workgroups of this device report, and how evenly?  (one atomic per workgroup into 8 counters)
+PMA_KERNEL void k_xcc_probe(uint32_t *counts) {
+  if (wv::thread_idx() == 0) wv::atomic_add_u32(&counts[wv::xcc_id() & 7u], 1u);
 }
 PMA_KERNEL void k_rb_inplace16(View v, uint64_t wstart, uint64_t wlen, int sh, const uint32_t *cnt, const uint32_t *tile_excl, const ChainTable *tb,
-                               const uint32_t *order, uint32_t *ctl, uint32_t *flags, uint32_t epoch) {
-  rb_inplace_body<16>(v, wstart, wlen, sh, cnt, tile_excl, tb, order, ctl, flags, epoch);
+                               const uint32_t *order, uint32_t *ctl, uint32_t *flags, uint32_t epoch, uint32_t nlists) {
+  rb_inplace_body<16>(v, wstart, wlen, sh, cnt, tile_excl, tb, order, ctl, flags, epoch, nlists);
 }
 
 PMA_KERNEL void k_copy_slots(const Edge *src, Edge *dst, uint64_t len) {

@@ -365,8 +365,9 @@ def test_big_window_rebalance(pkg, streams, variant, tile, batch):
     _same(e, o, "updates after the rebalances")
 
 
-@pytest.mark.parametrize("shape", ["uniform", "dense_left", "dense_right", "dense_middle", "sparse_middle"])
-def test_partial_window_rebalance_in_place(pkg, streams, shape):
+@pytest.mark.parametrize("shape,lists", [("uniform", 0), ("dense_left", 0), ("dense_right", 0), ("dense_middle", 0), ("sparse_middle", 0),
+                                         ("dense_middle", 1), ("dense_right", 2), ("sparse_middle", 4)])
+def test_partial_window_rebalance_in_place(pkg, streams, shape, lists):
     """partial windows rebalanced inside the array (k_rb_order + k_rb_inplace; hundreds to thousands of 2048-slot tiles,
     elements moving left, right, outward, inward — several tiles far) against the reference's redistribute() run by the oracle"""
     n = 1 << 16
@@ -381,6 +382,8 @@ def test_partial_window_rebalance_in_place(pkg, streams, shape):
     ops = np.concatenate([base] + extra)
     e, o = pkg.PCSR(n), Oracle(n)
     e.set_option("rb_inplace_min", 2048)
+    if lists:  # ticket lists: by default as many as the XCD ids the engine saw at creation (8 on an MI355X), 1 = one counter
+        e.set_option("rb_inplace_lists", lists)
     e.set_option("big_window", 4096)  # windows above it go to the host-driven path (in place) during the loads as well
     e.apply(ops)
     o.apply(ops)
