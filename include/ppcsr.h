@@ -113,7 +113,7 @@ int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out);
 /* knobs (int64 values; every key engine.cc's set_option accepts):
  *   scheduler  "mode" (0 strict prefix rounds, 1 speculative rounds + validated rollback; default 1), "opt_horizon" (round
  *              width cap; default 3 x "resident_waves" = 3 x CUs x 24), "start_horizon", "adaptive", "epoch_ops", "epoch_short", "epoch_grow_after",
- *              "region_slots", "soft_barrier", "defer_barrier", "small_batch" (batches up to this size take the strict
+ *              "region_slots" / "region_wide" / "region_calm", "soft_barrier", "defer_barrier", "small_batch" (batches up to this size take the strict
  *              rounds), "max_horizon" / "min_horizon" / "init_horizon" (strict rounds), "rounds_per_sync"
  *   windows    "big_min" / "big_window" (slots: above big_min a workgroup of the round rebalances the window, above
  *              big_window the update is exclusive), "big_grid", "excl_in_wave"

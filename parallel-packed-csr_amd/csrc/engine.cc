@@ -106,7 +106,14 @@ struct Engine::Impl {
   // Zipf stream on the same partition, 50 rollbacks per 1.5 M updates, was indifferent: 208 ms either way)
   uint32_t epoch_short = 16384;  // epoch length after a rollback
   uint32_t epoch_clean = 0, epoch_grow_after = 2;  // clean epochs in a row / how many of them double the length again
-  uint32_t region_slots = 4096;  // per-region prefix rule (>= kBigWindow so a window never leaves its region)
+  // per-region prefix rule: nothing later may commit in a region where an earlier update was deferred.  4096 slots blocked
+  // 43 K of the 69 K non-commits per 1 M updates of config #2 for nothing (179 M/s; 2048: 184, 1024: 187, 512: 188, 256: 189);
+  // the hot-vertex stream needs the rule (1024: 142 ms as with 4096, 83 rollbacks instead of 36; 256: 191 ms, 199 rollbacks)
+  uint32_t region_slots = 1024;
+  // ... so the rule is tightened where rollbacks happen: after one, regions are region_wide slots until region_calm epochs in
+  // a row have ended cleanly (a config #4 partition at critical density: 31.1 ms / 9 rollbacks with 1024 throughout, 26.7 ms
+  // / 3 rollbacks with 4096; its calm second half is config-#2-like again)
+  uint32_t region_wide = 4096, region_calm = 8, region_eff = 0, region_clean = 0;
   // Round width (upper bound when `adaptive` is on).  One update = one wave; `resident_waves` of them fit the chip at once
   // (o_plan: 78 VGPRs = 6 waves per SIMD, 24 per CU, 6144 on 256 CUs).  A round's kernels are bound by latency, so a round
   // of 2 x resident takes ~1.4x the time of one of 1 x resident; widths in between leave the second pass partly empty
@@ -457,6 +464,16 @@ int Engine::set_option(const char *key, int64_t value) {
   if (k == "region_slots") {
     if (value < 1 || (value & (value - 1))) return fail(PPCSR_EINVAL, "region_slots must be a power of two");
     p.region_slots = (uint32_t)value;
+    p.region_eff = 0;
+    return PPCSR_OK;
+  }
+  if (k == "region_wide") {
+    if (value < 1 || (value & (value - 1))) return fail(PPCSR_EINVAL, "region_wide must be a power of two");
+    p.region_wide = (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "region_calm") {
+    p.region_calm = (uint32_t)std::max<int64_t>(1, value);
     return PPCSR_OK;
   }
   if (k == "opt_horizon") {
@@ -834,7 +851,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     c.skip = kMax;
     GCHK(gpu::h2d(p.d_octl, p.h_octl, sizeof(OptCtl), p.stream));
     int rs = 0;
-    while ((p.region_slots >> rs) > (uint32_t)p.v.g.logN) rs++;
+    if (p.region_eff < p.region_slots) p.region_eff = p.region_slots;
+    while ((p.region_eff >> rs) > (uint32_t)p.v.g.logN) rs++;
     bool epoch_open = true;
     uint32_t hint_hor = c.hor[par];
     // tail sizing of the round chunks: updates still pending and updates committed per round (measured on the last chunk)
@@ -964,6 +982,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         p.st.wasted_rounds += c.rounds;  // (kept apart: `rounds` / `committed` / `planned` describe committed work only)
         p.cur_epoch = std::min<uint32_t>(p.cur_epoch, std::min<uint32_t>(p.epoch_ops, kEpochShort));
         p.epoch_clean = 0;
+        p.region_eff = std::max(p.region_slots, p.region_wide);
+        p.region_clean = 0;
         const uint64_t cut = (uint64_t)c.viol_idx + 1;
         if (retries < 3 && c.viol_idx != kMax && cut > e0 && cut < e1) {
           retries++;
@@ -1009,6 +1029,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         e0 = e1;
         retries = 0;
         epoch_open = false;
+        if (p.region_eff != p.region_slots && ++p.region_clean >= p.region_calm) p.region_eff = p.region_slots;
         if (++p.epoch_clean >= p.epoch_grow_after) {
           p.cur_epoch = (uint32_t)std::min<uint64_t>(p.epoch_ops, 2ull * p.cur_epoch);
           p.epoch_clean = 0;
