@@ -10,7 +10,9 @@ ROOT = os.path.dirname(HERE)
 
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                # the rebalance position chain must round like the reference's x86-64 build: no FMA contraction
-               "-ffp-contract=off"]
+               "-ffp-contract=off",
+               # (compact_block leaves its unrolled loops early on a wave-uniform bound: "loop not unrolled" is intended)
+               "-Wno-pass-failed"]
 
 
 def hipcc():
