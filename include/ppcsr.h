@@ -62,6 +62,8 @@ typedef struct {
   uint64_t narrow_lost;   /* how often that add_node path was taken */
   uint64_t narrow;        /* 1: regular structure (parallel rounds); 0: add_node after a doubling has left overlapping vertex ranges
                              (PCSR.cpp:533-540, 681-703): updates run one per round until a re-check finds the ranges sane again */
+  uint64_t chained;       /* updates committed by the in-round chains (a region's waiting updates executed one after the other
+                             by one wave inside a round instead of one per round) */
 } ppcsr_stats_t;
 
 /* PCSR::PCSR(init_n, src_n, lock_search, domain)  — PCSR.cpp:775-838; `device` replaces the NUMA domain */

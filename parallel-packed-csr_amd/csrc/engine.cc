@@ -84,8 +84,14 @@ struct Engine::Impl {
     View v{};
     uint64_t cap_slots = 0, cap_nodes = 0;
     bool valid = false;
+    uint32_t synced = 0;   // serial at which this copy was last synchronised with the live state (dirty tags above it differ)
+    uint64_t gen = 0;      // array generation it belongs to (a resize / bulk build / add_node starts a new one: full copy)
   };
   Snap snap, esnap;
+  // dirty tags: writers stamp View::ldirty / vdirty with `serial`; every snapshot synchronisation advances it
+  uint32_t serial = 1;
+  uint64_t array_gen = 1;
+  bool stamps_clean = false;  // the validation stamps hold nothing from an earlier batch or a rolled-back epoch
   // speculative scheduler state
   OptCtl *d_octl = nullptr, *h_octl = nullptr;
   uint32_t *d_vdbg = nullptr;
@@ -149,6 +155,7 @@ struct Engine::Impl {
   bool carry_dumped = false;
   bool partial = false;
   bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
+  bool in_batch = false;  // inside apply_batch_device (which ends with inplace_fault_check)
   // slots; a planned window at least this big lets nothing later overtake it (0: big_window / 2).  Such an update is
   // likely to turn exclusive once the earlier updates have landed, and what has overtaken it by then is rolled back — but
   // everything behind the barrier waits a round: at big_window / 4 a config #4 partition (critical density: a window of
@@ -156,7 +163,18 @@ struct Engine::Impl {
   // inserts; at / 2: 276 rounds and the same 2-3 rollbacks; without any: 234 rounds, but slower ones
   uint32_t soft_barrier = 0;
   uint32_t defer_barrier = 0;  // slots; a deferred update with a window at least this big lets nothing later overtake it (0: off)
+  // a soft barrier holds back later updates only inside the aligned block of zone_factor x its planned window (0: everywhere)
+  uint32_t zone_factor = 8;
   uint32_t diag = 0;     // count, per epoch, why planned updates did not commit (printed to stderr at the end of the epoch)
+  // in-round chains (o_chain): 0 never, 1 when the rounds commit little of what they plan (conflict chains), 2 always
+  uint32_t chain = 1, chain_steps = 8, chain_fence = 0;
+  bool chain_on = false;  // the regime the last round chunk was in (kept across epochs and batches)
+  unsigned long long *d_bk_cnt = nullptr, *d_xmin = nullptr;
+  uint32_t *d_bk_base = nullptr, *d_bk_list = nullptr, *d_bk_pos = nullptr, *d_bk_reg = nullptr;
+  uint64_t bk_cap = 0;
+  uint64_t xmin_cap = 0;
+  uint32_t *d_dg = nullptr;  // diag >= 2: per-update trace of the batch (OptArgs::dg)
+  uint64_t dg_cap = 0;
   std::vector<gpu::Event> events;  // init failed half-way: destructor frees only what exists
 };
 
@@ -177,6 +195,13 @@ static int ensure_plans(Engine::Impl &p) {
   return 0;
 }
 
+// the chain lists are tagged with the round too
+static int reset_chain_tags(Engine::Impl &p) {
+  int e;
+  if (p.d_bk_cnt && (e = gpu::dset(p.d_bk_cnt, 0, (uint64_t)kChainBuckets * sizeof(unsigned long long), p.stream))) return e;
+  if (p.d_xmin && (e = gpu::dset(p.d_xmin, 0xFF, p.xmin_cap * sizeof(unsigned long long), p.stream))) return e;
+  return 0;
+}
 // every round-tagged reservation array restarts together with the round counter (stale keys must never meet a reused tag)
 static int reset_tags(Engine::Impl &p) {
   const uint64_t leaves = p.v.g.N >> p.v.g.sh;
@@ -188,6 +213,7 @@ static int reset_tags(Engine::Impl &p) {
   if (p.d_pfail && (e = gpu::dset(p.d_pfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream))) return e;
   if (p.v.vw && (e = gpu::dset(p.v.vw, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
   if (p.v.vr && (e = gpu::dset(p.v.vr, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
+  if ((e = reset_chain_tags(p))) return e;
   p.round = 0;
   return 0;
 }
@@ -210,8 +236,13 @@ static int alloc_aux(Engine::Impl &p, View &v) {
   if ((e = gpu::dset(p.d_regfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream))) return e;
   if ((e = gpu::dset(p.d_wstamp, 0, leaves * sizeof(uint32_t), p.stream))) return e;
   if ((e = gpu::dset(p.d_rstamp, 0, leaves * sizeof(uint32_t), p.stream))) return e;
+  if ((e = gpu::dmalloc((void **)&v.ldirty, leaves * sizeof(uint32_t)))) return e;
+  if ((e = gpu::dset(v.ldirty, 0, leaves * sizeof(uint32_t), p.stream))) return e;
+  if ((e = gpu::dmalloc((void **)&p.d_xmin, (leaves + 2) * sizeof(unsigned long long)))) return e;  // (per region; regions >= 1 leaf)
+  p.xmin_cap = leaves + 2;
   p.leaves_cap = leaves;
   p.round = 0;
+  if ((e = reset_chain_tags(p))) return e;
   if (v.vw && (e = gpu::dset(v.vw, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
   if (v.vr && (e = gpu::dset(v.vr, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
   return 0;
@@ -224,8 +255,12 @@ static int alloc_vertex_aux(Engine::Impl &p, View &v) {
   if (v.vr) GPU_DFREE(v.vr);
   if (p.d_vws) GPU_DFREE(p.d_vws);
   if (p.d_vrs) GPU_DFREE(p.d_vrs);
+  if (v.vdirty) GPU_DFREE(v.vdirty);
   v.vw = v.vr = nullptr;
+  v.vdirty = nullptr;
   p.d_vws = p.d_vrs = nullptr;
+  if ((e = gpu::dmalloc((void **)&v.vdirty, cap * sizeof(uint32_t)))) return e;
+  if ((e = gpu::dset(v.vdirty, 0, cap * sizeof(uint32_t), p.stream))) return e;
   if ((e = gpu::dmalloc((void **)&v.vw, cap * sizeof(unsigned long long)))) return e;
   if ((e = gpu::dmalloc((void **)&v.vr, cap * sizeof(unsigned long long)))) return e;
   if ((e = gpu::dmalloc((void **)&p.d_vws, cap * sizeof(uint32_t)))) return e;
@@ -237,6 +272,11 @@ static int alloc_vertex_aux(Engine::Impl &p, View &v) {
   return 0;
 }
 static void free_aux(Engine::Impl &p, View &v) {
+  if (v.ldirty) GPU_DFREE(v.ldirty);
+  v.ldirty = nullptr;
+  if (p.d_xmin) GPU_DFREE(p.d_xmin);
+  p.d_xmin = nullptr;
+  p.xmin_cap = 0;
   GPU_DFREE(v.wres);
   GPU_DFREE(v.rres);
   GPU_DFREE(v.dres);
@@ -307,6 +347,7 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   compute_geometry(N, src_n, lock_search, &g);
   p.v.g = g;
   p.v.big_window = kBigWindow;
+  p.v.serial = p.serial;
   p.n_cap = std::max<uint64_t>(src_n, 16);
   p.leaves_cap = N >> g.sh;
   GCHK(gpu::dmalloc((void **)&p.v.items, N * sizeof(Edge)));
@@ -389,6 +430,7 @@ Engine::~Engine() {
   if (p.v.vr) GPU_DFREE(p.v.vr);
   if (p.d_vws) GPU_DFREE(p.d_vws);
   if (p.d_vrs) GPU_DFREE(p.d_vrs);
+  if (p.v.vdirty) GPU_DFREE(p.v.vdirty);
   GPU_DFREE(p.d_octl);
   gpu::hfree(p.h_octl);
   if (p.d_opidx) GPU_DFREE(p.d_opidx);
@@ -418,6 +460,12 @@ Engine::~Engine() {
   if (p.d_jobs) GPU_DFREE(p.d_jobs);
   if (p.d_xplan) GPU_DFREE(p.d_xplan);
   if (p.d_bigscratch) GPU_DFREE(p.d_bigscratch);
+  if (p.d_bk_cnt) GPU_DFREE(p.d_bk_cnt);
+  if (p.d_bk_base) GPU_DFREE(p.d_bk_base);
+  if (p.d_bk_list) GPU_DFREE(p.d_bk_list);
+  if (p.d_bk_pos) GPU_DFREE(p.d_bk_pos);
+  if (p.d_bk_reg) GPU_DFREE(p.d_bk_reg);
+  if (p.d_dg) GPU_DFREE(p.d_dg);
   for (Impl::Snap *sp : {&p.snap, &p.esnap}) {
     if (sp->v.items) GPU_DFREE(sp->v.items);
     if (sp->v.nodes) GPU_DFREE(sp->v.nodes);
@@ -599,12 +647,30 @@ int Engine::set_option(const char *key, int64_t value) {
     p.soft_barrier = (uint32_t)std::max<int64_t>(0, value);
     return PPCSR_OK;
   }
+  if (k == "chain") {
+    if (value < 0 || value > 2) return fail(PPCSR_EINVAL, "chain must be 0 (off), 1 (auto) or 2 (always)");
+    p.chain = (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "chain_fence") {
+    p.chain_fence = (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "chain_steps") {
+    p.chain_steps = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 64));
+    return PPCSR_OK;
+  }
+  if (k == "zone_factor") {
+    if (value < 0 || (value & (value - 1))) return fail(PPCSR_EINVAL, "zone_factor must be 0 or a power of two");
+    p.zone_factor = (uint32_t)std::min<int64_t>(value, 1 << 20);
+    return PPCSR_OK;
+  }
   if (k == "defer_barrier") {
     p.defer_barrier = (uint32_t)std::max<int64_t>(0, value);
     return PPCSR_OK;
   }
-  if (k == "diag") {
-    p.diag = value != 0;
+  if (k == "diag") {  // 1: per-epoch counts of why updates did not commit; 2: + a per-update trace, dumped per epoch to $PPCSR_DIAG_DUMP
+    p.diag = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 2));
     return PPCSR_OK;
   }
   if (k == "profile") {
@@ -646,6 +712,11 @@ int Engine::apply_batch_device(const Op *d_ops, uint64_t n) {
   if (n == 0) return PPCSR_OK;
   GCHK(gpu::set_device(device_));
   p.timer.start(p.stream);
+  struct InBatch {
+    bool &f;
+    explicit InBatch(bool &x) : f(x) { f = true; }
+    ~InBatch() { f = false; }
+  } in_batch_guard(p.in_batch);
   const uint64_t kChunk = 1ull << 30;
   for (uint64_t off = 0; off < n; off += kChunk) {
     const uint64_t m = std::min(kChunk, n - off);
@@ -770,8 +841,8 @@ int Engine::run_rounds(const Op *d_ops, uint64_t n) {
   return PPCSR_OK;
 }
 
-static int snap_save(Engine::Impl &p, Engine::Impl::Snap &sn);
-static int snap_load(Engine::Impl &p, Engine::Impl::Snap &sn);
+static int snap_commit(Engine::Impl &p, Engine::Impl::Snap &sn);
+static int snap_rollback(Engine::Impl &p, Engine::Impl::Snap &sn, Engine::Impl::Snap &other);
 
 // Speculative rounds (pma_kernels.h, second half): epochs of at most `epoch_ops` updates, each with a rollback
 // snapshot; a validation failure replays the epoch with the strict prefix rounds, an exclusive update ends the epoch.
@@ -815,6 +886,34 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       p.bigscratch_cap = need;
     }
   }
+  if (p.chain && p.bk_cap < (uint64_t)p.opt_horizon + 8) {  // per-region lists of the in-round chains
+    for (void *q : {(void *)p.d_bk_cnt, (void *)p.d_bk_base, (void *)p.d_bk_list, (void *)p.d_bk_pos, (void *)p.d_bk_reg})
+      if (q) gpu::dfree(q);
+    p.d_bk_cnt = nullptr;
+    p.d_bk_base = p.d_bk_list = p.d_bk_pos = p.d_bk_reg = nullptr;
+    p.bk_cap = 0;
+    const uint64_t cap = (uint64_t)p.opt_horizon + 8;
+    GCHK(gpu::dmalloc((void **)&p.d_bk_cnt, (uint64_t)kChainBuckets * sizeof(unsigned long long)));
+    GCHK(gpu::dmalloc((void **)&p.d_bk_base, (uint64_t)kChainBuckets * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_bk_list, cap * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_bk_pos, cap * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_bk_reg, cap * sizeof(uint32_t)));
+    p.bk_cap = cap;
+    GCHK(gpu::dset(p.d_bk_cnt, 0, (uint64_t)kChainBuckets * sizeof(unsigned long long), p.stream));
+    GCHK(gpu::dset(p.d_bk_pos, 0xFF, cap * sizeof(uint32_t), p.stream));
+    if (p.round) GCHK(reset_tags(p));  // (the counts are tagged with the round: one clean start for everything that is)
+  }
+  if (p.diag >= 2) {
+    if (p.dg_cap < n) {
+      if (p.d_dg) GPU_DFREE(p.d_dg);
+      p.d_dg = nullptr;
+      p.dg_cap = 0;
+      GCHK(gpu::dmalloc((void **)&p.d_dg, n * 4 * sizeof(uint32_t)));
+      p.dg_cap = n;
+    }
+    GCHK(gpu::dset(p.d_dg, 0, n * 4 * sizeof(uint32_t), p.stream));
+  }
+  p.stamps_clean = false;  // (stream indices start over with every batch)
   uint64_t e0 = 0;
   uint64_t forced_e1 = 0;  // after a rollback: end the retried epoch right after the update that failed validation
   int retries = 0;
@@ -825,14 +924,32 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     if (forced_e1 > e0 && forced_e1 < e1) e1 = forced_e1;
     if (p.round > 0xFFFF0000u) GCHK(reset_tags(p));
     p.carry_dumped = false;
-    GCHK(snap_save(p, p.esnap));
+    // rollback point of the epoch: the epoch snapshot catches up with what the previous epoch wrote (dirty tags) — a full
+    // copy only the first time and after the array was replaced
+    GCHK(snap_commit(p, p.esnap));
+    if (const char *tv = getenv("PPCSR_TRACE_NN")) {  // debug: num_neighbors of one vertex, live and in the epoch snapshot
+      const uint32_t vtx = (uint32_t)atoi(tv);
+
+      Node a_, b_;
+      uint32_t tg = 0;
+      GCHK(gpu::d2h(&a_, p.v.nodes + vtx, sizeof(Node), p.stream));
+      GCHK(gpu::d2h(&b_, p.esnap.v.nodes + vtx, sizeof(Node), p.stream));
+      GCHK(gpu::d2h(&tg, p.v.vdirty + vtx, sizeof(uint32_t), p.stream));
+      GCHK(gpu::sync(p.stream));
+      fprintf(stderr, "[nn] epoch start e0=%llu: live nn %u snap nn %u tag %u synced %u serial %u\n", (unsigned long long)e0, a_.num_neighbors, b_.num_neighbors, tg,
+              p.esnap.synced, p.serial);
+    }
     GCHK(gpu::d2d(p.d_stats_snap, p.d_stats, kStatShards * sizeof(StatShard), p.stream));
-    {
+    if (!p.stamps_clean) {
+      // validation stamps hold 1 + the stream index of the latest committed toucher: what earlier epochs of this batch left
+      // is smaller than anything this epoch compares with, so they are cleared at the start of a batch and after a
+      // rollback only (the rolled-back commits must not look like later updates to the retried ones)
       const uint64_t leaves = p.v.g.N >> p.v.g.sh;
       GCHK(gpu::dset(p.d_wstamp, 0, leaves * sizeof(uint32_t), p.stream));
       GCHK(gpu::dset(p.d_rstamp, 0, leaves * sizeof(uint32_t), p.stream));
       GCHK(gpu::dset(p.d_vws, 0, (p.n_cap + 1) * sizeof(uint32_t), p.stream));
       GCHK(gpu::dset(p.d_vrs, 0, (p.n_cap + 1) * sizeof(uint32_t), p.stream));
+      p.stamps_clean = true;
     }
     OptCtl &c = *p.h_octl;
     memset(&c, 0, sizeof(c));
@@ -847,6 +964,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     c.width_cap = p.opt_horizon;
     c.resident = p.resident_waves;
     c.gbar[0] = c.gbar[1] = ~0ull;
+    c.sbar[0] = c.sbar[1] = ~0ull;
     c.viol_idx = kMax;
     c.skip = kMax;
     GCHK(gpu::h2d(p.d_octl, p.h_octl, sizeof(OptCtl), p.stream));
@@ -859,6 +977,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     uint64_t chunk_pending = e1 - e0;
     double chunk_cpr = 0.9 * (double)c.hor[par];
     unsigned long long prev_rounds = 0, prev_committed = 0;
+    unsigned long long chunk_planned0 = 0, chunk_committed0 = 0;
     uint32_t excl_cooldown = 0;  // chunks to keep short after an exclusive update (the launches behind it in its chunk are wasted)
     while (epoch_open) {
       OptArgs a;
@@ -886,6 +1005,18 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       a.regshift = rs;
       a.diag = p.diag;
       a.defer_barrier = p.defer_barrier;
+      a.zone_factor = p.zone_factor;
+      const bool use_chain = p.chain == 2 || (p.chain == 1 && p.chain_on);
+      a.chain = use_chain ? std::max<uint32_t>(1u, p.chain_steps) : 0u;
+      a.chain_fence = p.chain_fence;
+      a.chshift = std::max(0, 10 - p.v.g.sh);
+      a.bk_cnt = p.d_bk_cnt;
+      a.bk_base = p.d_bk_base;
+      a.bk_list = p.d_bk_list;
+      a.bk_pos = p.d_bk_pos;
+      a.bk_reg = p.d_bk_reg;
+      a.xmin = p.d_xmin;
+      a.dg = p.diag >= 2 ? p.d_dg : (uint32_t *)nullptr;
       a.soft_barrier = p.soft_barrier ? p.soft_barrier : a.v.big_window / 2u;
       // grid sized for the horizon the device last reported (it can only shrink within a chunk when fresh
       // updates run out; it never exceeds opt_horizon)
@@ -923,10 +1054,12 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         a.round = ++p.round;
         if (p.profile) p.events[5 * r + 0].record(p.stream);
         GPU_LAUNCH(p.stream, o_plan, blocks, 256, a);
+        if (use_chain) GPU_LAUNCH(p.stream, o_bscan, 1, 1024, a);  // (profile: counted with o_plan)
         if (p.profile) p.events[5 * r + 1].record(p.stream);
         GPU_LAUNCH(p.stream, o_check, blocks, 256, a);
         if (p.profile) p.events[5 * r + 2].record(p.stream);
         GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
+        if (use_chain) GPU_LAUNCH(p.stream, o_chain, blocks, 256, a);  // (profile: counted with o_apply)
         if (p.profile) p.events[5 * r + 3].record(p.stream);
         GPU_LAUNCH(p.stream, o_compact, 1u + (use_big ? p.big_grid : 0u), 1024, a);  // workgroup 0 compacts, the others rebalance big windows
         if (p.profile) p.events[5 * r + 4].record(p.stream);
@@ -945,12 +1078,45 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       }
       p.st.round_syncs++;
       if (c.error) return fail(PPCSR_EINTERNAL, "device-side error " + std::to_string(c.error));
+      {  // which regime were these rounds in?  Chains pay when a round commits little of what it plans (conflict chains:
+         // every round re-plans the same waiting updates), and cost a launch per round when nearly everything commits
+        const unsigned long long dp = c.planned - chunk_planned0, dc = c.committed - chunk_committed0;
+        if (dp >= 2048) {
+          if (dc * 100ull < dp * 60ull) p.chain_on = true;
+          else if (dc * 100ull > dp * 92ull) p.chain_on = false;
+        }
+        chunk_planned0 = c.planned;
+        chunk_committed0 = c.committed;
+      }
       if (p.diag && (c.violation || c.excl || c.done))
         fprintf(stderr, "[ppcsr diag] epoch [%llu,%llu) %s after %llu rounds: committed %llu planned %llu | not committed because: excl-kind %llu, "
                 "behind-barrier %llu, dup %llu, W-W %llu, W-after-R %llu, R-after-W %llu, sentinel-read %llu, sentinel-move %llu, region %llu, "
                 "growth-zone %llu, stamp %llu\n",
                 (unsigned long long)e0, (unsigned long long)e1, c.violation ? "ROLLBACK" : (c.excl ? "exclusive" : "done"), c.rounds, c.committed,
                 c.planned, c.why[0], c.why[1], c.why[2], c.why[3], c.why[4], c.why[5], c.why[6], c.why[7], c.why[8], c.why[9], c.why[10]);
+      if (p.diag && (c.violation || c.excl || c.done) && c.chain_why[9])
+        fprintf(stderr, "[ppcsr diag]   chains: heads %llu steps %llu | ended by: list-end %llu, stop-index %llu, step-limit %llu, excl-kind %llu, many-ranges %llu, "
+                "leaves-region %llu, big-window %llu, stamps %llu | regions under a queued window %llu\n", c.chain_why[9], c.chain_why[10], c.chain_why[0],
+                c.chain_why[1], c.chain_why[2], c.chain_why[3], c.chain_why[4], c.chain_why[5], c.chain_why[6], c.chain_why[7], c.chain_why[8]);
+      if (p.diag && (c.violation || c.excl || c.done) && c.chain_why[9])
+        fprintf(stderr, "[ppcsr diag]   stop index from: exclusive %llu, global barrier %llu, foreign update %llu, list overflow %llu, zone %llu | list errors %llu\n", c.chain_stop[1],
+                c.chain_stop[2], c.chain_stop[3], c.chain_stop[4], c.chain_stop[5], c.chain_why[11]);
+      if (p.diag >= 2 && (c.violation || c.done) && getenv("PPCSR_DIAG_DUMP")) {
+        const uint64_t cnt = e1 - e0;
+        std::vector<uint32_t> tr(cnt * 4);
+        std::vector<Op> hops(cnt);
+        GCHK(gpu::d2h(tr.data(), p.d_dg + 4 * e0, cnt * 4 * sizeof(uint32_t), p.stream));
+        GCHK(gpu::d2h(hops.data(), d_ops + e0, cnt * sizeof(Op), p.stream));
+        GCHK(gpu::sync(p.stream));
+        if (FILE *f = fopen(getenv("PPCSR_DIAG_DUMP"), "ab")) {
+          const uint64_t hdr[4] = {e0, e1, c.rounds, c.violation ? 1ull : 0ull};
+          fwrite(hdr, sizeof(hdr), 1, f);
+          fwrite(tr.data(), sizeof(uint32_t), tr.size(), f);
+          fwrite(hops.data(), sizeof(Op), hops.size(), f);
+          fclose(f);
+        }
+        GCHK(gpu::dset(p.d_dg + 4 * e0, 0, cnt * 4 * sizeof(uint32_t), p.stream));  // (a retried epoch starts its trace over)
+      }
       const uint32_t npar = (p.round + 1) & 1u;
       // An exclusive update runs now, alone, in the middle of the epoch: it is the lowest pending update, so it sees exactly
       // the state sequential execution gives it unless a LATER update was committed earlier on something it reads or
@@ -977,7 +1143,18 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
           fprintf(stderr, "[ppcsr] rollback: epoch [%llu,%llu) viol_idx=%u excl=%u maxc=%u after %llu rounds; kind=%u leaf=%u stamp=%u what=%u wleaf=[%u,%u] index=%u nr=%u\n",
                   (unsigned long long)e0, (unsigned long long)e1, c.viol_idx, c.excl, c.maxc, c.rounds, c.viol_info[0],
                   c.viol_info[1], c.viol_info[2], c.viol_info[3], c.viol_info[4], c.viol_info[5], c.viol_info[6], c.viol_info[7]);
-        GCHK(snap_load(p, p.esnap));
+        if (const char *tv = getenv("PPCSR_TRACE_NN")) {
+          const uint32_t vtx = (uint32_t)atoi(tv);
+          Node a_;
+          uint32_t tg = 0;
+          GCHK(gpu::d2h(&a_, p.v.nodes + vtx, sizeof(Node), p.stream));
+          GCHK(gpu::d2h(&tg, p.v.vdirty + vtx, sizeof(uint32_t), p.stream));
+          GCHK(gpu::sync(p.stream));
+          GCHK(gpu::sync(p.stream));
+          fprintf(stderr, "[nn] before rollback: live nn %u tag %u synced %u serial %u (viol_idx %u, rounds %llu)\n", a_.num_neighbors, tg, p.esnap.synced, p.serial, c.viol_idx, c.rounds);
+        }
+        GCHK(snap_rollback(p, p.esnap, p.snap));
+        p.stamps_clean = false;
         GCHK(gpu::d2d(p.d_stats, p.d_stats_snap, kStatShards * sizeof(StatShard), p.stream));
         p.st.wasted_rounds += c.rounds;  // (kept apart: `rounds` / `committed` / `planned` describe committed work only)
         p.cur_epoch = std::min<uint32_t>(p.cur_epoch, std::min<uint32_t>(p.epoch_ops, kEpochShort));
@@ -1071,11 +1248,15 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
 
 int Engine::run_exclusive(Op op, uint32_t flags, const Op *d_ops, uint32_t spec_index, bool *violation, bool *resized, bool later_committed) {
   Impl &p = *p_;
-  p.st.exclusive_ops++;
   if (violation) *violation = false;
   if (resized) *resized = false;
   const bool spec = spec_index != kMax;
   if (spec && !p.d_xplan) GCHK(gpu::dmalloc((void **)&p.d_xplan, sizeof(Plan)));
+  bool counted = false;  // exclusive_ops counts executed updates: not the attempts, not a run that is rolled back
+  auto count_once = [&]() {
+    if (!counted) p.st.exclusive_ops++;
+    counted = true;
+  };
   for (int attempt = 0; attempt < 8; attempt++) {
     XValid xv;
     xv.wstamp = p.d_wstamp;
@@ -1093,7 +1274,9 @@ int Engine::run_exclusive(Op op, uint32_t flags, const Op *d_ops, uint32_t spec_
       fprintf(stderr, "[excl] op (%u,%u,%u) flags %u -> result %u window (%u,%u) found %u, %.0f us\n", op.src, op.dst, op.op, flags, x.result, x.wstart, x.wlen, x.found,
               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tx0).count());
     switch (x.result) {
-      case X_DONE: return PPCSR_OK;
+      case X_DONE:
+        count_once();
+        return PPCSR_OK;
       case X_VIOLATION:
         if (violation) *violation = true;
         return PPCSR_OK;
@@ -1106,8 +1289,13 @@ int Engine::run_exclusive(Op op, uint32_t flags, const Op *d_ops, uint32_t spec_
           return PPCSR_OK;
         }
         if (resized) *resized = true;
+        count_once();
         return resize(x.result == X_NEED_DOUBLE ? p.v.g.N * 2 : p.v.g.N / 2);
-      case X_NEED_REDIST: return big_redistribute(x.wstart, x.wlen, false);
+      case X_NEED_REDIST:
+        count_once();
+        // (inside a batch the in-place rebalance's sticky fault flag is read once, at the end of apply_batch_device; a
+        // single-update caller — add_node, the strict rounds of a one-update batch — has it checked right here)
+        return big_redistribute(x.wstart, x.wlen, !spec && !p.in_batch);
       case X_DOUBLE_THEN_RETRY: {
         if (spec && later_committed) {
           if (violation) *violation = true;
@@ -1116,6 +1304,7 @@ int Engine::run_exclusive(Op op, uint32_t flags, const Op *d_ops, uint32_t spec_
         if (resized) *resized = true;
         int rc = resize(p.v.g.N * 2);
         if (rc != PPCSR_OK) return rc;
+        count_once();
         flags |= XF_FORCE_NOINFO | XF_SKIP_COUNT;
         if (flags & XF_ADD_NODE) {
           // add_node found the end of the array occupied: the reference doubles and then re-searches the new sentinel's
@@ -1211,8 +1400,10 @@ int Engine::rebalance_fused(const View &nv, const Edge *src_items, uint64_t src_
   int rc = ensure_scratch(nleaves);  // d_rank parks the source counts of an in-place window
   if (rc == PPCSR_OK) rc = ensure_tiles(ntiles);
   if (rc != PPCSR_OK) return rc;
+  // (inplace: a window of the live array, src_cnt = its slice of the live leaf counts -> the matching slice of the dirty tags)
   GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, src_cnt, nleaves, tile, p.d_tiles, inplace ? p.d_rank : (uint32_t *)nullptr,
-             inplace ? (uint32_t *)nullptr : dst_cnt, inplace ? (uint64_t)0 : dst_nleaves);
+             inplace ? (uint32_t *)nullptr : dst_cnt, inplace ? (uint64_t)0 : dst_nleaves,
+             inplace ? p.v.ldirty + (src_cnt - p.v.leafcnt) : (uint32_t *)nullptr, p.serial);
   GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, tb_index, tb_len, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
   GPU_LAUNCH(p.stream, k_rb_scatter, ntiles, 256, nv, src_items, src_lo, src_len, src_sh,
              inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, tile, p.rb_prefetch ? 4u : 1u, (const uint32_t *)p.d_tiles,
@@ -1272,6 +1463,7 @@ int Engine::resize(uint64_t newN) {
   p.v = nv;
   p.v.wres = p.v.rres = p.v.dres = nullptr;
   GCHK(alloc_aux(p, p.v));  // fresh reservation / stamp arrays for the new leaf count
+  p.array_gen++;  // (snapshots of the old array are copied in full the next time they are used)
   if (newN > oldN) p.st.double_calls++; else p.st.half_calls++;
   p.st.redistribute_calls++;
   p.st.redistribute_slots += newN;
@@ -1314,7 +1506,8 @@ int Engine::big_redistribute(uint64_t wstart, uint64_t wlen, bool sync) {
         p.ip_epoch = 1;
       }
       uint32_t *order = p.d_ip + kIpHdrWords, *flags = p.d_ip + kIpHdrWords + kIpMaxTiles;
-      GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, v.leafcnt + leaf_lo, nleaves, tile_leaves, p.d_tiles, p.d_rank, (uint32_t *)nullptr, (uint64_t)0);
+      GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, v.leafcnt + leaf_lo, nleaves, tile_leaves, p.d_tiles, p.d_rank, (uint32_t *)nullptr, (uint64_t)0,
+                 v.ldirty + leaf_lo, p.serial);
       GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, wstart, wlen, order, p.d_ip, tile_slots);
       if (cpw == 8)
         GPU_LAUNCH(p.stream, k_rb_inplace8, ntiles, 256, v, wstart, wlen, v.g.sh, (const uint32_t *)p.d_rank, (const uint32_t *)p.d_tiles,
@@ -1344,8 +1537,10 @@ int Engine::big_redistribute(uint64_t wstart, uint64_t wlen, bool sync) {
   if (fused) {
     rc = rebalance_fused(v, v.items, wstart, wlen, v.g.sh, v.leafcnt + leaf_lo, true, wstart, wlen, p.d_scratch, wstart, v.leafcnt, 0);
     if (rc != PPCSR_OK) return rc;
-  } else
+  } else {
     GCHK(gpu::dset(v.leafcnt + leaf_lo, 0, nleaves * sizeof(uint32_t), p.stream));
+    GPU_LAUNCH(p.stream, k_fill_u32, grid_for(nleaves, 256), 256, v.ldirty + leaf_lo, nleaves, p.serial);  // dirty tags of the window
+  }
   if (fused) {
   } else if (p.scatter_variant == 1)
     GPU_LAUNCH(p.stream, k_scatter_runs, grid_for((wlen + 63) / 64, 4, p.scatter_blocks), 256, v, (const Edge *)v.items, wstart, wlen, v.g.sh,
@@ -1410,6 +1605,7 @@ int Engine::add_node() {  // PCSR.cpp:681-703
   GCHK(gpu::h2d(p.v.nodes + len, &nd, sizeof(Node), p.stream));
   GCHK(gpu::sync(p.stream));
   p.v.g.n = len + 1;
+  p.array_gen++;  // (the vertex set changed: snapshots are copied in full the next time)
   Op op{len, nd.beginning, sval};
   const int rc = run_exclusive(op, XF_ADD_NODE | XF_FORCE_NOINFO);
   if (rc != PPCSR_OK) {
@@ -1620,6 +1816,7 @@ int Engine::bulk_build(const Op *host_ops, uint64_t m, double *device_ms) {
   p.v = nv;
   p.v.wres = p.v.rres = p.v.dres = nullptr;
   GCHK(alloc_aux(p, p.v));
+  p.array_gen++;
   return PPCSR_OK;
 }
 
@@ -1878,12 +2075,13 @@ int Engine::stats(EngineStats *out) {
     s.duplicates += h.duplicates;
     s.noops += h.noops;
     s.slide_slots += h.slide_slots;
+    s.chained += h.chained;
   }
   *out = s;
   return PPCSR_OK;
 }
 
-static int snap_save(Engine::Impl &p, Engine::Impl::Snap &sn) {
+static int snap_full_save(Engine::Impl &p, Engine::Impl::Snap &sn) {
   const uint64_t N = p.v.g.N, leaves = N >> p.v.g.sh;
   int e;
   if (sn.cap_slots < N) {
@@ -1910,7 +2108,7 @@ static int snap_save(Engine::Impl &p, Engine::Impl::Snap &sn) {
   sn.valid = true;
   return 0;
 }
-static int snap_load(Engine::Impl &p, Engine::Impl::Snap &sn) {
+static int snap_full_load(Engine::Impl &p, Engine::Impl::Snap &sn) {
   const uint64_t N = sn.v.g.N, leaves = N >> sn.v.g.sh;
   int e;
   if (p.v.g.N != N) {  // the array was resized since the snapshot: go back to buffers of the old size
@@ -1928,11 +2126,68 @@ static int snap_load(Engine::Impl &p, Engine::Impl::Snap &sn) {
   if ((e = gpu::d2d(p.v.leafcnt, sn.v.leafcnt, leaves * sizeof(uint32_t), p.stream))) return e;
   return 0;
 }
+static void advance_serial(Engine::Impl &p, uint32_t by) {
+  p.serial += by;
+  p.v.serial = p.serial;
+}
+static bool snap_in_step(const Engine::Impl &p, const Engine::Impl::Snap &sn) {
+  return sn.valid && sn.gen == p.array_gen && sn.v.g.N == p.v.g.N && sn.v.g.n == p.v.g.n && sn.v.g.logN == p.v.g.logN && p.serial < 0xFFFFFF00u;
+}
+// live state -> snapshot.  In step with the arrays (same generation): only what was written since its last synchronisation
+// (dirty tags); otherwise a full copy.
+static int snap_commit(Engine::Impl &p, Engine::Impl::Snap &sn) {
+  int e;
+  if (p.serial >= 0xFFFFFF00u) {  // (4 G synchronisations: start the tags over; every snapshot is copied in full once)
+    const uint64_t leaves = p.v.g.N >> p.v.g.sh;
+    if ((e = gpu::dset(p.v.ldirty, 0, leaves * sizeof(uint32_t), p.stream))) return e;
+    if ((e = gpu::dset(p.v.vdirty, 0, (p.n_cap + 1) * sizeof(uint32_t), p.stream))) return e;
+    p.serial = 1;
+    p.v.serial = 1;
+    p.snap.gen = p.esnap.gen = 0;
+  }
+  if (!snap_in_step(p, sn)) {
+    if ((e = snap_full_save(p, sn))) return e;
+    sn.gen = p.array_gen;
+  } else {
+    const uint64_t leaves = p.v.g.N >> p.v.g.sh;
+    GPU_LAUNCH(p.stream, k_snap_sync_leaves, (uint32_t)std::min<uint64_t>((leaves + 255) / 256, 4096), 256, p.v.items, p.v.leafcnt, sn.v.items, sn.v.leafcnt,
+               p.v.ldirty, leaves, p.v.g.sh, sn.synced, 0u, 0u, (unsigned long long *)nullptr);
+    if (p.v.g.n)
+      GPU_LAUNCH(p.stream, k_snap_sync_nodes, (uint32_t)std::min<uint64_t>(((uint64_t)p.v.g.n + 255) / 256, 4096), 256, p.v.nodes, sn.v.nodes, p.v.vdirty,
+                 (uint64_t)p.v.g.n, sn.synced, 0u, 0u);
+  }
+  sn.synced = p.serial;
+  advance_serial(p, 1);
+  return 0;
+}
+// snapshot -> live state (rollback / restore()); `other` is the engine's second snapshot
+static int snap_rollback(Engine::Impl &p, Engine::Impl::Snap &sn, Engine::Impl::Snap &other) {
+  int e;
+  if (!snap_in_step(p, sn)) {
+    if ((e = snap_full_load(p, sn))) return e;
+    p.array_gen++;  // the live arrays were rewritten wholesale: nothing the other snapshot knows about them holds
+    sn.gen = p.array_gen;
+    other.gen = 0;
+    sn.synced = p.serial;
+    advance_serial(p, 1);
+    return 0;
+  }
+  const uint64_t leaves = p.v.g.N >> p.v.g.sh;
+  const uint32_t newtag = p.serial + 1u;  // what the rollback writes is "written" for the other snapshot
+  GPU_LAUNCH(p.stream, k_snap_sync_leaves, (uint32_t)std::min<uint64_t>((leaves + 255) / 256, 4096), 256, p.v.items, p.v.leafcnt, sn.v.items, sn.v.leafcnt,
+             p.v.ldirty, leaves, p.v.g.sh, sn.synced, newtag, 1u, (unsigned long long *)nullptr);
+  if (p.v.g.n)
+    GPU_LAUNCH(p.stream, k_snap_sync_nodes, (uint32_t)std::min<uint64_t>(((uint64_t)p.v.g.n + 255) / 256, 4096), 256, p.v.nodes, sn.v.nodes, p.v.vdirty,
+               (uint64_t)p.v.g.n, sn.synced, newtag, 1u);
+  sn.synced = newtag;
+  advance_serial(p, 2);
+  return 0;
+}
 
 int Engine::snapshot() {
   Impl &p = *p_;
   GCHK(gpu::set_device(device_));
-  GCHK(snap_save(p, p.snap));
+  GCHK(snap_commit(p, p.snap));
   GCHK(gpu::sync(p.stream));
   return PPCSR_OK;
 }
@@ -1941,7 +2196,8 @@ int Engine::restore() {
   Impl &p = *p_;
   if (!p.snap.valid) return fail(PPCSR_EINVAL, "restore without snapshot");
   GCHK(gpu::set_device(device_));
-  GCHK(snap_load(p, p.snap));
+  GCHK(snap_rollback(p, p.snap, p.esnap));
+  p.stamps_clean = false;
   return PPCSR_OK;
 }
 

@@ -27,6 +27,11 @@ struct View {
   unsigned long long *dres;  // per-leaf: earliest pending DUPLICATE update (overwrites one slot's value, moves nothing)
   unsigned long long *vw;    // per-vertex: earliest pending update that may MOVE this vertex's sentinel
   unsigned long long *vr;    // per-vertex: earliest pending update that READS this sentinel's position
+  // dirty tags (incremental snapshots): every writer stamps the leaves / node records it modifies with the engine's current
+  // `serial`; a snapshot that was last synchronised at serial S copies (either way) exactly the entries whose tag is > S
+  uint32_t *ldirty;  // per leaf
+  uint32_t *vdirty;  // per vertex (node record: beginning, end, num_neighbors)
+  uint32_t serial;
   Geometry g;
   // largest rebalance window a round accepts (larger ones make the update exclusive).  Strict rounds: kBigWindow (one
   // wave rebalances it); speculative rounds: up to kBigLeaves leaves, rebalanced by a workgroup (o_big)
@@ -39,7 +44,7 @@ constexpr int kStatShards = 256;
 constexpr uint32_t kLdsWindow = 512;   // windows up to this many slots are rebalanced inside one wave's LDS tile (12 KB)
 
 struct StatShard {
-  unsigned long long redistribute_calls, redistribute_slots, not_found, duplicates, noops, slide_slots, committed, pad;
+  unsigned long long redistribute_calls, redistribute_slots, not_found, duplicates, noops, slide_slots, committed, chained;
 };
 
 namespace dev {
@@ -85,10 +90,16 @@ PMA_DEV void fix_sentinel(const View &v, const Edge &e, uint32_t in) {
   if (vid == kMax) {
     vid = 0;
   } else {
-    v.nodes[vid - 1].end = in;
+    wv::store_agent_u32(&v.nodes[vid - 1].end, in);
+    wv::atomic_max_u32(&v.vdirty[vid - 1], v.serial);
   }
-  v.nodes[vid].beginning = in;
-  if (vid == v.g.n - 1) v.nodes[vid].end = (uint32_t)(v.g.N - 1);
+  wv::store_agent_u32(&v.nodes[vid].beginning, in);
+  wv::atomic_max_u32(&v.vdirty[vid], v.serial);
+  if (vid == v.g.n - 1) wv::store_agent_u32(&v.nodes[vid].end, (uint32_t)(v.g.N - 1));
+}
+// dirty tags of the leaves [lo, hi] (whole wave)
+PMA_DEV void mark_leaves(const View &v, uint64_t lo, uint64_t hi) {
+  for (uint64_t leaf = lo + (uint64_t)wv::lane(); leaf <= hi; leaf += 64) wv::atomic_max_u32(&v.ldirty[leaf], v.serial);
 }
 
 constexpr uint32_t kLongRange = 8;  // read ranges spanning more leaves are walked by the whole wave
@@ -873,10 +884,18 @@ PMA_DEV void slide_left_wave(const View &v, uint32_t gap, uint32_t last) {
 // ---- full per-op planning (search + window plan) -------------------------------------------------------
 // What the planning kernels need from the plan right away (the full record goes to memory for the later kernels)
 struct PlanRegs {
-  uint32_t kind, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, nr, nlong, sdep;
+  uint32_t kind, index, wstart, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, nr, nlong, sdep, sleaf_b, sleaf_e;
   uint32_t my_lo, my_hi;  // lane r: read range r (r < 64)
 };
-PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
+// LOCAL (the in-round chains, o_chain): everything is derived from the slots [r0, r1] of ONE region and from nothing else —
+// no node records, no slots or leaf counts of other regions — so that the waves that work on different regions at the same
+// time never read what another one is writing (XCDs do not see each other's stores inside a launch).  The vertex' range is
+// not looked up in nodes[]: one sweep over the region finds the tight bracket directly — the last live slot of `src` with
+// dest < key (or the slot after sentinel src), the first with dest > key (or sentinel src + 1), or the key itself — and the
+// reference's walk on that bracket returns what it returns on the whole range (pma_search: the result is a function of the
+// final tight bracket).  Updates whose bracket is not inside the region come back as K_FOREIGN.
+template <bool LOCAL>
+PMA_DEV PlanRegs plan_op_t(const View &v, const Op op, Plan *plan, uint32_t r0 = 0, uint32_t r1 = 0) {
   const int lane = wv::lane();
   const Geometry &g = v.g;
   RangeRec rr;
@@ -884,14 +903,69 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
   rr.nr = 0;
   uint32_t kind = K_NOOP, index = 0, gap = 0, wstart = 0, wlen = 0, wl = 1, wh = 0, acalls = 0, aslots = 0;
   uint32_t sleaf_b = 0, sleaf_e = 0, mv_lo = 1, mv_hi = 0;
+  uint32_t s_start = 0, s_end = 0, sdep_mask = 3u;
+  bool located = true;
   if (op.src < g.n) {
-    const Node nd = v.nodes[op.src];
-    // nodes[src].{beginning,end} are the positions of sentinels src / src+1: that dependency is tracked per vertex
-    // (Plan::mv_lo/mv_hi of the writers, View::vw/vr), not through the leaves that hold them
-    sleaf_b = nd.beginning >> g.sh;
-    sleaf_e = nd.end >> g.sh;
+    if (!LOCAL) {
+      const Node nd = v.nodes[op.src];
+      // nodes[src].{beginning,end} are the positions of sentinels src / src+1: that dependency is tracked per vertex
+      // (Plan::mv_lo/mv_hi of the writers, View::vw/vr), not through the leaves that hold them
+      sleaf_b = nd.beginning >> g.sh;
+      sleaf_e = nd.end >> g.sh;
+      s_start = nd.beginning + 1;
+      s_end = nd.end;
+    } else {
+      // one sweep over the region: every lane looks at its share of the slots (independent loads, all in flight together)
+      uint32_t la = 0, lb = kMax, leq = kMax, ls0 = kMax, ls1 = kMax;  // la: 1 + slot
+      for (uint32_t s = r0 + (uint32_t)lane; s <= r1; s += 64u) {
+        const Edge e = v.items[s];
+        if (e.value == 0) continue;
+        if (is_sentinel(e)) {
+          if (e.src == op.src) ls0 = s;
+          if (e.src == op.src + 1u) ls1 = s;
+        } else if (e.src == op.src) {
+          if (e.dest < op.dst) la = s + 1u;            // (slots ascend with the trip count: the last one stays)
+          else if (e.dest == op.dst) leq = s;
+          else if (lb == kMax) lb = s;
+        }
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t ya = wv::shfl(la, lane ^ o), yb = wv::shfl(lb, lane ^ o), ye = wv::shfl(leq, lane ^ o), y0 = wv::shfl(ls0, lane ^ o),
+                       y1 = wv::shfl(ls1, lane ^ o);
+        la = ya > la ? ya : la;
+        lb = yb < lb ? yb : lb;
+        leq = ye < leq ? ye : leq;
+        ls0 = y0 < ls0 ? y0 : ls0;
+        ls1 = y1 < ls1 ? y1 : ls1;
+      }
+      sdep_mask = 0u;
+      if (leq != kMax) {  // the key itself
+        s_start = leq;
+        s_end = leq + 1u;
+      } else {
+        if (la != 0u) s_start = la - 1u;
+        else if (ls0 != kMax) {
+          s_start = ls0 + 1u;
+          sdep_mask |= 1u;
+          sleaf_b = ls0 >> g.sh;
+        } else located = false;
+        if (lb != kMax) s_end = lb;
+        else if (ls1 != kMax) {
+          s_end = ls1;
+          sdep_mask |= 2u;
+          sleaf_e = ls1 >> g.sh;
+        } else located = false;
+        if (located && s_end <= s_start) located = false;  // (cannot happen in a sorted neighbourhood)
+      }
+      if ((uint64_t)r1 + 1u >= g.N) located = false;  // (the array's last region: slot N-1 has rules of its own)
+    }
+  }
+  if (op.src < g.n && !located) {
+    kind = K_FOREIGN;
+  } else if (op.src < g.n) {
     SearchHit hit;
-    index = pma_search(v, op.dst, nd.beginning + 1, nd.end, rr, &hit);
+    index = pma_search(v, op.dst, s_start, s_end, rr, &hit);
+    rr.sdep &= sdep_mask;
     const uint32_t leaf = index >> g.sh;
     // one batch of independent loads: the slot the search returned (unless the search already knows it), its leaf's
     // count, and — for an occupied slot — the first 64 slots of the gap search to the right
@@ -1048,6 +1122,32 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
     const uint32_t whi = wstart + wlen - 1u;
     const uint32_t hi = (kind == K_INSERT && gap > whi) ? gap : whi;
     uint32_t down = 0, up = 0;
+    if (LOCAL) {
+      // the sentinels inside [lo, hi], read off the slots themselves (ascending vertex ids with ascending positions)
+      uint32_t vfirst = kMax, vlast = 0, pfirst = 0;
+      bool anys = false;
+      for (uint32_t base = lo; base <= hi; base += 64u) {
+        const uint32_t s = base + (uint32_t)lane;
+        Edge e = null_edge();
+        if (s <= hi) e = v.items[s];
+        const uint64_t m = wv::ballot(s <= hi && e.value != 0 && is_sentinel(e));
+        if (m) {
+          const int lf = wv::ctz64(m), ll = 63 - __builtin_clzll(m);
+          if (!anys) {
+            vfirst = wv::shfl(e.src, lf);
+            pfirst = base + (uint32_t)lf;
+            anys = true;
+          }
+          vlast = wv::shfl(e.src, ll);
+        }
+        if (hi - base < 64u) break;
+      }
+      if (anys) {
+        mv_lo = vfirst;
+        mv_hi = vlast;
+        if (pfirst == wstart && (kind == K_REMOVE || index > wstart)) mv_lo++;
+      }
+    } else {
     // both directions' first kW vertices are requested together, kW lanes each (one round trip for almost every update:
     // a one-leaf window holds a handful of sentinels at most; 64 node records per direction cost 3 KB of fetches per update)
     constexpr uint32_t kW = 8;
@@ -1100,6 +1200,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
       const uint32_t b_lo = (down > 0) ? beg_lowest : v.nodes[mv_lo].beginning;
       if (b_lo == wstart && (kind == K_REMOVE || index > wstart)) mv_lo++;
     }
+    }
   }
   if (lane == 0) {
     plan->mv_lo = mv_lo;
@@ -1122,6 +1223,10 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
   PlanRegs pr;
   pr.sdep = rr.sdep;
   pr.kind = kind;
+  pr.index = index;
+  pr.wstart = wstart;
+  pr.sleaf_b = sleaf_b;
+  pr.sleaf_e = sleaf_e;
   pr.wlen = wlen;
   pr.wleaf_lo = wl;
   pr.wleaf_hi = wh;
@@ -1133,6 +1238,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
   pr.my_hi = rr.my_hi;
   return pr;
 }
+PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) { return plan_op_t<false>(v, op, plan); }
 
 // A window too large for one wave is handed to a workgroup (o_big) through the round's job queue: the update's own wave
 // does everything up to the final rebalance (slide, write, counters) and leaves the leaf counts exact.
@@ -1152,6 +1258,8 @@ PMA_DEV void apply_op(const View &v, const Op op, const Plan *plan, uint32_t *ld
   if (kind == K_DUP) {
     if (lane == 0) {
       v.items[index].value = op.op;
+      wv::atomic_max_u32(&v.ldirty[index >> g.sh], v.serial);
+      wv::atomic_max_u32(&v.vdirty[op.src], v.serial);
       wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 1u);
       wv::atomic_add_u64(&st->duplicates, 1ull);
     }
@@ -1159,10 +1267,15 @@ PMA_DEV void apply_op(const View &v, const Op op, const Plan *plan, uint32_t *ld
   }
   if (kind == K_NOTFOUND) {
     if (lane == 0) {
+      wv::atomic_max_u32(&v.vdirty[op.src], v.serial);
       wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
       wv::atomic_add_u64(&st->not_found, 1ull);
     }
     return;
+  }
+  if (kind == K_INSERT || kind == K_REMOVE) {  // everything this update writes lies in [wleaf_lo, wleaf_hi] (slide + window)
+    mark_leaves(v, plan->wleaf_lo, plan->wleaf_hi);
+    if (lane == 0) wv::atomic_max_u32(&v.vdirty[op.src], v.serial);
   }
   if (kind == K_INSERT) {
     const uint32_t gap = plan->gap;

@@ -218,6 +218,7 @@ PMA_DEV bool xv_bad_writes(const View &v, const XValid &xv, uint64_t leaf_lo, ui
 }
 PMA_DEV bool xv_bad_reads(const View &v, const XValid &xv, const dev::RangeRec &rr, uint32_t src) {
   if (!xv.me1) return false;
+  wv::fence();  // the ranges were recorded by lane 0 (rec_range): its stores before every lane's loads of them
   bool bad = false;
   const uint32_t nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
   for (uint32_t r = 0; r < nr; r++) {
@@ -253,6 +254,17 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
     return;                          \
   } while (0)
   const bool add_node = (flags & XF_ADD_NODE) != 0;
+  if (!add_node && op.src >= g.n) {  // silently ignored (PCSR.cpp:1375); the round planner classifies it K_NOOP, so it only
+                                     // gets here through a caller's mistake — never index nodes[] with it
+    if (lane == 0) {
+      wv::atomic_add_u64(&st->noops, 1ull);
+      out->result = X_DONE;
+      out->wstart = 0;
+      out->wlen = 0;
+      out->found = 0;
+    }
+    return;
+  }
   if (op.op != 0 || add_node) {
     Edge elem{op.src, op.dst, op.op};
     uint32_t index;
@@ -269,7 +281,10 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
       const Node nd = v.nodes[op.src];
       dev::SearchHit hit_;
       index = dev::pma_search(v, op.dst, nd.beginning + 1, nd.end, rr, &hit_);
-      if (!(flags & XF_SKIP_COUNT) && lane == 0) wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 1u);
+      if (!(flags & XF_SKIP_COUNT) && lane == 0) {
+        wv::atomic_max_u32(&v.vdirty[op.src], v.serial);
+        wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 1u);
+      }
     }
     const Edge at = v.items[index];
     wv::fence();  // every lane has read the slot before lane 0 may overwrite it
@@ -278,6 +293,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
       if (xv_bad_reads(v, xv, rr, op.src) || xv_bad_writes(v, xv, index >> sh, index >> sh)) PMA_X_VIOLATION();
       if (lane == 0) {
         v.items[index].value = elem.value;
+        wv::atomic_max_u32(&v.ldirty[index >> sh], v.serial);
         wv::atomic_add_u64(&st->duplicates, 1ull);
       }
     } else if (occupied && (uint64_t)index == g.N - 1) {  // PCSR.cpp:533-540
@@ -320,6 +336,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
           if (two + 2ull * logN - 1 > hi) hi = two + 2ull * logN - 1;
           if (hi > g.N - 1) hi = g.N - 1;
           if (xv_bad_reads(v, xv, rr, op.src) || xv_bad_writes(v, xv, lo >> sh, hi >> sh)) PMA_X_VIOLATION();
+          dev::mark_leaves(v, lo >> sh, hi >> sh);  // (dirty tags: the slide range and every window known so far)
         }
         wv::fence();  // planning reads are complete in every lane before the state is modified
         if (off_end) {
@@ -401,6 +418,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
             acalls = 2;
             aslots += wn;
             if (xv_bad_writes(v, xv, ws >> sh, (ws + wn - 1) >> sh)) PMA_X_VIOLATION();  // (the rollback restores what was done so far)
+            dev::mark_leaves(v, ws >> sh, (ws + wn - 1) >> sh);
           }
         }
         if (lane == 0) {
@@ -425,7 +443,10 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
       const Node nd = v.nodes[op.src];
       dev::SearchHit hit_;
       const uint32_t index = dev::pma_search(v, op.dst, nd.beginning + 1, nd.end, rr, &hit_);
-      if (!(flags & XF_SKIP_COUNT) && lane == 0) wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
+      if (!(flags & XF_SKIP_COUNT) && lane == 0) {
+        wv::atomic_max_u32(&v.vdirty[op.src], v.serial);
+        wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
+      }
       const Edge at = v.items[index];
       wv::fence();
       const Edge elem{op.src, op.dst, 1u};
@@ -438,6 +459,8 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
             (!rp.half && xv_bad_writes(v, xv, rp.wstart >> sh, (rp.wstart + rp.wlen - 1) >> sh)))
           PMA_X_VIOLATION();
         wv::fence();  // planning reads are complete in every lane before the state is modified
+        if (!rp.half) dev::mark_leaves(v, rp.wstart >> sh, (rp.wstart + rp.wlen - 1) >> sh);
+        if (lane == 0) wv::atomic_max_u32(&v.ldirty[index >> sh], v.serial);
         if (lane == 0) {
           v.items[index].value = 0;
           v.items[index].dest = 0;
@@ -878,12 +901,13 @@ PMA_KERNEL void k_scatter_runs(View v, const Edge *src, uint64_t src_lo, uint64_
 // register-run scatter of k_scatter_runs over the tile's chunks.  Three launches for a whole-array rebalance.
 constexpr uint32_t kRbTile = 256;  // maximum tile (= workgroup size); the engine picks a power of two <= this per window
 PMA_KERNEL void k_rb_tilesums(uint32_t *cnt, uint64_t nleaves, uint32_t tile_leaves, uint32_t *tilesum, uint32_t *copy_out,
-                              uint32_t *zero_ptr, uint64_t zero_n) {
+                              uint32_t *zero_ptr, uint64_t zero_n, uint32_t *dirty, uint32_t serial) {
   PMA_SHARED uint32_t red[4];
   const uint64_t b = wv::block_idx();
   const uint64_t l = b * tile_leaves + wv::thread_idx();
   const bool mine = wv::thread_idx() < tile_leaves && l < nleaves;
   uint32_t s = mine ? cnt[l] : 0u;
+  if (dirty != nullptr && mine) wv::atomic_max_u32(&dirty[l], serial);  // (a window of the live array is about to be rewritten: dirty tags)
   if (copy_out != nullptr && mine) {  // in-place window: park the source counts, clear them for the rebuild
     copy_out[l] = s;
     cnt[l] = 0u;
@@ -1076,9 +1100,8 @@ PMA_DEV void rb_inplace_body(const View &v, uint64_t wstart, uint64_t wlen, int 
     tile_cnt = wsum[0] + wsum[1] + wsum[2] + wsum[3];
   }
   const uint64_t j = stb.j, wend = stb.index + stb.len;
-  uint32_t seen = 0;
-#pragma unroll
-  for (int q = 0; q < CPW; q++) seen += (uint32_t)wv::popc64(wv::ballot(e[q].value != 0));  // (the loads have returned)
+  wv::wait_loads();  // EVERY wave's tile loads have returned before the barrier that precedes "tile read" (a workgroup barrier
+                     // does not wait for vmcnt, and flag_publish's own wait covers wave 0 only)
   wv::block_sync();
   if (wv::thread_idx() == 0) wv::flag_publish(&flags[tile], epoch);
   if (j == 0) {  // empty window: nothing is read by anybody, every tile clears its own slots
@@ -1109,7 +1132,6 @@ PMA_DEV void rb_inplace_body(const View &v, uint64_t wstart, uint64_t wlen, int 
     wv::flag_acquire();
   }
   wv::block_sync();
-  (void)seen;
   const uint32_t lpc = 64u >> sh;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
@@ -1130,6 +1152,76 @@ PMA_KERNEL void k_xcc_probe(uint32_t *counts) {
 PMA_KERNEL void k_rb_inplace16(View v, uint64_t wstart, uint64_t wlen, int sh, const uint32_t *cnt, const uint32_t *tile_excl, const ChainTable *tb,
                                const uint32_t *order, uint32_t *ctl, uint32_t *flags, uint32_t epoch, uint32_t nlists) {
   rb_inplace_body<16>(v, wstart, wlen, sh, cnt, tile_excl, tb, order, ctl, flags, epoch, nlists);
+}
+
+// ---- incremental snapshots (dirty tags) -----------------------------------------------------------------------------
+// A snapshot (rollback point of a speculative epoch, or the user's snapshot()) is a second copy of items / leaf counts /
+// node records that is kept in step with the live state by copying only what was written since it was last synchronised:
+// every writer stamps the leaves / node records it modifies with the engine's serial (View::ldirty / vdirty), and an entry
+// is dirty for a snapshot synchronised at serial S when its tag is > S.  to_live = 0: live -> snapshot ("commit": the
+// snapshot catches up); to_live = 1: snapshot -> live ("rollback"), and the entry is re-tagged `newtag` so that the OTHER
+// snapshot sees it as written.  One wave scans 64 tags per trip and copies the dirty leaves logN slots per lane group.
+PMA_KERNEL void k_snap_sync_leaves(Edge *live, uint32_t *live_cnt, Edge *snap, uint32_t *snap_cnt, uint32_t *tag, uint64_t nleaves,
+                                   int sh, uint32_t synced, uint32_t newtag, uint32_t to_live, unsigned long long *copied) {
+  const int lane = wv::lane();
+  const uint32_t logN = 1u << sh;
+  const uint32_t G = logN >= 64u ? 1u : (64u >> sh);  // leaves copied per trip
+  const uint64_t wstride = (uint64_t)wv::grid_dim() * (wv::block_dim() >> 6);
+  unsigned long long mine = 0;
+  for (uint64_t base = ((uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block()) * 64u; base < nleaves; base += wstride * 64u) {
+    const uint64_t l = base + (uint64_t)lane;
+    const uint32_t t = l < nleaves ? wv::load_agent_u32(&tag[l]) : 0u;  // (the tags are set by device-wide atomics)
+    uint64_t m = wv::ballot(l < nleaves && t > synced);
+    mine += (unsigned long long)wv::popc64(m);
+    while (m) {
+      uint64_t myleaf = ~0ull;
+      for (uint32_t gI = 0; gI < G && m; gI++) {
+        const int b = wv::ctz64(m);
+        m &= m - 1ull;
+        if (((uint32_t)lane >> sh) == gI || logN >= 64u) myleaf = base + (uint64_t)b;
+      }
+      if (myleaf != ~0ull) {
+        const uint32_t q = (uint32_t)lane & (logN - 1u);
+        for (uint32_t o = q; o < logN; o += 64u) {  // (logN <= 64: one trip)
+          const uint64_t slot = (myleaf << sh) + o;
+          if (to_live) live[slot] = snap[slot]; else snap[slot] = live[slot];
+        }
+        if (q == 0) {
+          if (to_live) {
+            live_cnt[myleaf] = snap_cnt[myleaf];
+            wv::store_agent_u32(&tag[myleaf], newtag);  // (the tags are only ever touched by device-wide atomics / coherent stores)
+          } else {
+            snap_cnt[myleaf] = live_cnt[myleaf];
+          }
+        }
+      }
+    }
+  }
+  if (copied != nullptr && lane == 0 && mine) wv::atomic_add_u64(copied, mine);
+}
+PMA_KERNEL void k_snap_sync_nodes(Node *live, Node *snap, uint32_t *tag, uint64_t n, uint32_t synced, uint32_t newtag, uint32_t to_live) {
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t u = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); u < n; u += stride) {
+    if (wv::load_agent_u32(&tag[u]) > synced) {
+      if (to_live) {
+        const Node x = snap[u];  // (coherent stores, word by word: see wv::store_agent_u32)
+        wv::store_agent_u32(&live[u].beginning, x.beginning);
+        wv::store_agent_u32(&live[u].end, x.end);
+        wv::store_agent_u32(&live[u].num_neighbors, x.num_neighbors);
+        wv::store_agent_u32(&tag[u], newtag);
+      } else {
+        // (num_neighbors is only ever changed by device-wide atomics, which are carried out at the memory side: a copy of
+        // the line that this XCD's L2 picked up earlier does not follow them)
+        Node x = live[u];
+        x.num_neighbors = wv::load_agent_u32(&live[u].num_neighbors);
+        snap[u] = x;
+      }
+    }
+  }
+}
+PMA_KERNEL void k_fill_u32(uint32_t *p, uint64_t n, uint32_t value) {  // (dirty tags of a window: coherent stores, like every other writer of the tags)
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t i = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); i < n; i += stride) wv::store_agent_u32(&p[i], value);
 }
 
 PMA_KERNEL void k_copy_slots(const Edge *src, Edge *dst, uint64_t len) {
@@ -1679,14 +1771,29 @@ struct OptCtl {
   uint32_t adaptive;     // 1: adapt cur_horizon to the share of a round that commits (see compact_block)
   uint32_t cur_horizon;  // adaptive round width (<= max_horizon): grows while most of the round commits, shrinks otherwise
   unsigned long long gbar[2];  // keyed min index of a K_EXCL update in the horizon
+  unsigned long long sbar[2];  // keyed min index of a SOFT barrier (a planned window close to the exclusive threshold): a word of
+                               // its own — folded into gbar as key + 1 it was indistinguishable from a real K_EXCL key of update
+                               // idx + 1, and o_compact then sent that update to the exclusive executor whatever its kind
   unsigned long long rounds, committed, planned, blocked, failed;
   uint32_t viol_info[8];  // debug: kind, leaf, stamp, what(1=wstamp on W,2=rstamp on W,3=wstamp on R), wleaf_lo, wleaf_hi, index, round
   uint32_t hist[192];  // debug: (horizon << 16 | committed) >> of the first rounds of the epoch
+  // soft barriers with an extent ("zones"): an update whose planned window is close to the exclusive threshold keeps LATER
+  // updates out of the aligned block its window may still grow into — not out of the whole array (a config #4 partition at
+  // critical density had 90 % of its non-commits "behind a barrier" that sat megabytes away from them)
+  uint32_t nzones[2];
+  uint32_t zone_lo[2][8], zone_hi[2][8];  // inclusive leaf range
+  unsigned long long zone_key[2][8];
   // diagnostics (option "diag"): why planned updates did not commit, first reason found per update
   // 0 exclusive kind, 1 behind a barrier (gbar), 2 duplicate-slot conflicts, 3 write leaf reserved by an earlier writer,
   // 4 write leaf read by an earlier update, 5 read leaf written by an earlier update, 6 sentinel located by is moved earlier,
   // 7 sentinel we move is needed earlier, 8 region prefix, 9 growth zone of a deferred reader/writer (pfail), 10 stamp violation
   unsigned long long why[12];
+  // (diag) why chains ended: 0 list exhausted, 1 foreign / barrier / overflow stop index, 2 step limit, 3 exclusive kind, 4 read ranges
+  // beyond the register copy, 5 footprint leaves the region, 6 window for a workgroup, 7 stamps, 8 region under a queued big window,
+  // 9 heads, 10 chain steps
+  uint32_t bk_round;  // the round whose bucket offsets OptArgs::bk_base holds (0: none)
+  unsigned long long chain_why[12];
+  unsigned long long chain_stop[8];  // (diag) which stop index: 1 exclusive, 2 global soft barrier, 3 foreign update (xmin), 4 list overflow, 5 zone
   uint32_t njobs[2];  // big-window rebalances queued by this round's o_apply (by round parity; the next round's entry is reset by o_compact)
   uint32_t jobs_round[2];  // the round that queued them (launches that follow an exclusive / final round must not run them again)
   uint32_t skip;   // stream index the exclusive executor has just run inside this epoch (kMax: none); its slot commits as nothing
@@ -1710,16 +1817,41 @@ struct OptArgs {
   uint32_t diag;
   uint32_t defer_barrier;  // 0: off
   uint32_t soft_barrier;   // slots: see o_plan
+  uint32_t zone_factor;    // 0: a soft barrier holds back every later update; f > 0: only those that touch the aligned block of
+                           // f x its planned window (OptCtl::zone_*)
   // windows above big_min slots are rebalanced by a workgroup of o_big (job queue + one scratch stretch per workgroup)
   uint32_t big_min;
   dev::BigJob *jobs;
   Edge *bigscratch;
   uint32_t bigscratch_stride;  // slots per workgroup
+  // in-round chains (o_chain): the planned updates of a round listed per region.  Regions hash into kChainBuckets buckets;
+  // o_plan counts (its arrival number in the bucket is the update's place in the bucket's list), o_bscan turns the counts into
+  // offsets, o_check writes the horizon slot into its place; after o_apply the wave of the bucket's FIRST arrival sorts the
+  // list by horizon slot (= stream order) and executes what is still pending, one update after the other
+  uint32_t chain;              // 0: off; k: at most k chained updates per bucket and round
+  uint32_t chain_fence;        // (experiments: extra fences between chained updates, see wv::fence_mode)
+  int chshift;                 // chain regions: 2^chshift leaves (1024 slots whatever the region rule's width is)
+  unsigned long long *bk_cnt;  // [kChainBuckets] (round << 32) | updates listed this round
+  uint32_t *bk_base;           // [kChainBuckets] offset of the bucket's list in bk_list
+  uint32_t *bk_list;           // horizon slots, bucket after bucket
+  uint32_t *bk_pos;            // per horizon slot: arrival number in its bucket (kMax: not listed)
+  uint32_t *bk_reg;            // per horizon slot: region of the target slot
+  unsigned long long *xmin;    // per region: keyed min stream index of a PENDING update that touches the region but lives elsewhere
+  // diag >= 2: per update of the batch {rounds it failed in, code of the last failure, stream index of what blocked it,
+  // planned window}: the dependency chains of an epoch can be followed afterwards (tools/diag_chains.py)
+  uint32_t *dg;
 };
+constexpr uint32_t kChainBuckets = 1u << 15;
+constexpr uint32_t kChainList = 256;  // a wave sorts this many listed updates of one bucket in its LDS tile; longer lists run without a chain
+PMA_DEV uint32_t chain_bucket(uint32_t region) { return (region * 0x9E3779B1u) >> 17; }
 constexpr uint32_t kBigJobs = 256;  // capacity of the round's job queue
+constexpr uint32_t kMaxZones = 8;   // soft-barrier zones per round; the ninth barrier of a round is a global one
 constexpr uint32_t kRegionPadLeaves = 2u;
 constexpr uint32_t kGrowLeaves = 8u;
 constexpr uint32_t OS_PASS = 1u, OS_STAMP_BAD = 2u, OS_COMMITTED = 4u;
+// committed by a chain (o_chain): for the compaction as good as OS_COMMITTED, but NOT for the waves of o_chain that look for
+// the head of their region while the chain is running — they must keep seeing the state the launch started with
+constexpr uint32_t OS_CHAINED = OS_COMMITTED | 8u;
 
 
 PMA_DEV bool key_earlier(unsigned long long k, uint32_t tag, uint32_t idx) { return (uint32_t)(k >> 32) == tag && (uint32_t)k < idx; }
@@ -1788,6 +1920,7 @@ PMA_KERNEL void o_plan(OptArgs a) {
       pl->mv_lo = 1;
       pl->mv_hi = 0;
       pl->sleaf_b = pl->sleaf_e = 0;
+      if (a.chain) a.bk_pos[wid] = kMax;
     }
     return;
   }
@@ -1798,6 +1931,7 @@ PMA_KERNEL void o_plan(OptArgs a) {
   const uint32_t kind = pr.kind;
   if (kind == K_EXCL) {
     if (lane == 0) wv::atomic_min_u64(&c->gbar[par], key);
+    if (lane == 0 && a.chain) a.bk_pos[wid] = kMax;
     return;
   }
   if (kind == K_DUP) {
@@ -1810,8 +1944,24 @@ PMA_KERNEL void o_plan(OptArgs a) {
     // ... and so is an update that has ALREADY been deferred at least once and whose window is big (a.defer_barrier
     // slots): its window keeps growing while it waits behind a hot range, and everything committed around it meanwhile
     // is a candidate for a rollback
-    if ((pr.wlen >= a.soft_barrier || (a.defer_barrier && wid < used && pr.wlen >= a.defer_barrier)) && lane == 0)
-      wv::atomic_min_u64(&c->gbar[par], key + 1ull);
+    if ((pr.wlen >= a.soft_barrier || (a.defer_barrier && wid < used && pr.wlen >= a.defer_barrier)) && lane == 0) {
+      uint32_t zslot = kMaxZones;
+      if (a.zone_factor) zslot = wv::atomic_add_u32(&c->nzones[par], 1u);
+      if (zslot < kMaxZones) {
+        const uint32_t nleaves = (uint32_t)(a.v.g.N >> a.v.g.sh);
+        uint64_t zl = (uint64_t)(pr.wlen >> a.v.g.sh) * a.zone_factor;  // leaves in the block (a power of two when the factor is)
+        if (zl > nleaves) zl = nleaves;
+        uint64_t blo = (uint64_t)(pr.wstart >> a.v.g.sh) / zl * zl, bhi = blo + zl - 1u;
+        if (wl < blo) blo = wl;
+        if (wh > bhi) bhi = wh;
+        if (bhi >= nleaves) bhi = nleaves - 1u;
+        c->zone_lo[par][zslot] = (uint32_t)blo;
+        c->zone_hi[par][zslot] = (uint32_t)bhi;
+        c->zone_key[par][zslot] = key;
+      } else {
+        wv::atomic_min_u64(&c->sbar[par], key);
+      }
+    }
     const uint32_t ml = pr.mv_lo, mh = pr.mv_hi;
     for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_min_u64(&a.v.vw[u], key);
   }
@@ -1826,6 +1976,29 @@ PMA_KERNEL void o_plan(OptArgs a) {
     if (lane == 0 && (pr.sdep & 1u)) wv::atomic_min_u64(&a.v.vr[op.src], key);
     if (lane == 1 && (pr.sdep & 2u) && op.src + 1u < a.v.g.n) wv::atomic_min_u64(&a.v.vr[op.src + 1u], key);
   }
+  if (a.chain && lane == 0) {  // list the update under the region of its target slot (arrival order: o_chain sorts)
+    uint32_t region = kMax, pos = kMax;
+    if (kind_real(kind)) {
+      region = (pr.index >> a.v.g.sh) >> a.chshift;
+      const uint32_t b = chain_bucket(region);
+      wv::atomic_max_u64(&a.bk_cnt[b], (unsigned long long)a.round << 32);  // (first of the round: the count restarts at 0)
+      pos = (uint32_t)wv::atomic_add_u64(&a.bk_cnt[b], 1ull);
+    }
+    a.bk_pos[wid] = pos;
+    a.bk_reg[wid] = region;
+  }
+}
+
+// A deferred update tells the regions it touches WITHOUT living there (its window, slide pad, growth block, read ranges or
+// the sentinels it locates its range by reach into them) that somebody earlier is still pending: a chain of that region
+// stops before overtaking it.  [ulo, uhi]: the union of its write range (padded) and growth block, in leaves.
+PMA_DEV void mark_foreign_regions(const OptArgs &a, const PlanHead &h, const Plan *pl, unsigned long long key, uint32_t ulo, uint32_t uhi, int lane) {
+  const uint32_t mine = (h.index >> a.v.g.sh) >> a.chshift;
+  for (uint32_t g = (ulo >> a.chshift) + (uint32_t)lane; g <= (uhi >> a.chshift); g += 64)
+    if (g != mine) wv::atomic_min_u64(&a.xmin[g], key);
+  PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, { if ((leaf >> a.chshift) != mine) wv::atomic_min_u64(&a.xmin[leaf >> a.chshift], key); });
+  if (lane == 0 && (h.sdep & 1u) && (h.sleaf_b >> a.chshift) != mine) wv::atomic_min_u64(&a.xmin[h.sleaf_b >> a.chshift], key);
+  if (lane == 1 && (h.sdep & 2u) && (h.sleaf_e >> a.chshift) != mine) wv::atomic_min_u64(&a.xmin[h.sleaf_e >> a.chshift], key);
 }
 
 PMA_KERNEL void o_check(OptArgs a) {
@@ -1835,7 +2008,7 @@ PMA_KERNEL void o_check(OptArgs a) {
   const int lane = wv::lane();
   const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
   const uint32_t hor = c->hor[par];
-  const unsigned long long gbar = c->gbar[par];
+  const unsigned long long gbar = c->gbar[par], sbar = c->sbar[par];
   const uint32_t idx = a.opidx[wid];
   const Plan *pl = &a.plans[wid];
   const PlanHead h = load_plan_head(pl, lane);
@@ -1844,7 +2017,8 @@ PMA_KERNEL void o_check(OptArgs a) {
   const uint32_t kind = h.kind;
   const unsigned long long key = make_key(a.round, idx);
   const uint32_t tag = (uint32_t)(key >> 32);
-  bool fail = (kind == K_EXCL) || key_earlier(gbar, tag, idx);
+  // (a soft barrier holds back everything AFTER the update that raised it, that update itself may commit)
+  bool fail = (kind == K_EXCL) || key_earlier(gbar, tag, idx) || key_earlier(sbar, tag, idx);
   uint32_t why = (kind == K_EXCL) ? 0u : (fail ? 1u : 99u);  // diagnostics: first reason (lowest code wins below)
   if (fail) {
     // An exclusive update, or one behind this round's barrier: it does not commit now, and neither does anything after it
@@ -1852,14 +2026,50 @@ PMA_KERNEL void o_check(OptArgs a) {
     // its footprint — which, for a climb towards the root, is every leaf of the array (a 3.5 ms walk by one wave, while
     // the rest of the launch waits).  Its stamps are looked at in the round that does check it.
     if (a.diag && lane == 0) wv::atomic_add_u64(&c->why[why], 1ull);
+    if (lane == 0 && a.diag && a.dg != nullptr) {
+      uint32_t *r = a.dg + 4ull * idx;
+      r[0] += 1u;
+      r[1] = why;
+      r[2] = (kind == K_EXCL) ? idx : (uint32_t)(key_earlier(gbar, tag, idx) ? gbar : sbar);
+      r[3] = h.wlen;
+    }
     if (lane == 0) a.status[wid] = 0u;
+    if (a.chain && lane == 0 && c->bk_round == a.round) {
+      const uint32_t pos = a.bk_pos[wid];
+      if (pos != kMax) a.bk_list[a.bk_base[chain_bucket(a.bk_reg[wid])] + pos] = wid;
+    }
     return;
   }
 #define PMA_WHY(code) do { if (a.diag && (code) < why) why = (code); } while (0)
+#define PMA_WHYB(code, bkey) do { if (a.diag && (code) < why) { why = (code); blk = (uint32_t)(bkey); } } while (0)
+  uint32_t blk = kMax;
   bool stamp_bad = false;
   const uint32_t me1 = idx + 1u;  // stamps hold (index + 1) of the latest committed toucher
   const bool writes = kind_writes(kind);
   const bool strong = kind_strong(kind);
+  {  // zones of earlier soft-barrier updates: anything of ours inside one -> deferred (and treated like any other deferred
+     // update below: it keeps later updates out of its own regions)
+    uint32_t nz = c->nzones[par];
+    if (nz > kMaxZones) nz = kMaxZones;
+    for (uint32_t z = 0; z < nz; z++) {
+      if (!key_earlier(c->zone_key[par][z], tag, idx)) continue;
+      const uint32_t zlo = c->zone_lo[par][z], zhi = c->zone_hi[par][z];
+      bool in = false;
+      if (kind_real(kind)) {
+        const uint32_t il = h.index >> a.v.g.sh;
+        if (lane == 0) in = writes ? (h.wleaf_lo <= zhi && h.wleaf_hi >= zlo) : (il >= zlo && il <= zhi);
+        if (lane == 1 && (h.sdep & 1u)) in = h.sleaf_b >= zlo && h.sleaf_b <= zhi;
+        if (lane == 2 && (h.sdep & 2u)) in = h.sleaf_e >= zlo && h.sleaf_e <= zhi;
+      }
+      if (h.nr <= (uint32_t)kHeadRanges && h.nlong == 0u) {
+        if ((uint32_t)lane < h.nr && h.my_lo <= zhi && h.my_hi >= zlo) in = true;
+      } else {
+        for (uint32_t r = (uint32_t)lane; r < h.nr; r += 64)
+          if (pl->rlo[r] <= zhi && pl->rhi[r] >= zlo) in = true;
+      }
+      if (in) { fail = true; PMA_WHYB(1u, c->zone_key[par][z]); }
+    }
+  }
   if (kind == K_DUP) {
     const uint32_t leaf = h.wleaf_lo;
     if (key_earlier(a.v.wres[leaf], tag, idx)) { fail = true; PMA_WHY(2u); }  // an earlier pending update moves slots of this leaf
@@ -1884,9 +2094,9 @@ PMA_KERNEL void o_check(OptArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const uint32_t leaf = base + (uint32_t)q * 64u + (uint32_t)lane;
-        if (kw[q] != key) { fail = true; PMA_WHY(3u); }                   // an earlier pending update writes it
-        if (key_earlier(kd[q], tag, idx)) { fail = true; PMA_WHY(2u); }   // an earlier pending duplicate overwrites a slot here
-        if (key_earlier(kr[q], tag, idx)) { fail = true; PMA_WHY(4u); }   // an earlier pending update reads it
+        if (kw[q] != key) { fail = true; PMA_WHYB(3u, kw[q]); }                   // an earlier pending update writes it
+        if (key_earlier(kd[q], tag, idx)) { fail = true; PMA_WHYB(2u, kd[q]); }   // an earlier pending duplicate overwrites a slot here
+        if (key_earlier(kr[q], tag, idx)) { fail = true; PMA_WHYB(4u, kr[q]); }   // an earlier pending update reads it
         if (sw[q] > me1 || sr[q] > me1) {  // a LATER update already touched it
           stamp_bad = true;
           a.vdbg[4 * wid + 0] = leaf;
@@ -1898,7 +2108,7 @@ PMA_KERNEL void o_check(OptArgs a) {
     }
   }
   PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, {
-    if (key_earlier(a.v.wres[leaf], tag, idx)) { fail = true; PMA_WHY(5u); }  // an earlier pending update writes what we read
+    if (key_earlier(a.v.wres[leaf], tag, idx)) { fail = true; PMA_WHYB(5u, a.v.wres[leaf]); }  // an earlier pending update writes what we read
     if (a.wstamp[leaf] > me1) {                               // a LATER update already wrote what we read
       stamp_bad = true;
       a.vdbg[4 * wid + 0] = leaf;
@@ -1910,7 +2120,7 @@ PMA_KERNEL void o_check(OptArgs a) {
     const uint32_t src = a.ops[idx].src;
     if (src < a.v.g.n && lane < 2 && ((h.sdep >> lane) & 1u) && src + (uint32_t)lane < a.v.g.n) {  // lane 0: sentinel src, lane 1: sentinel src+1
       const uint32_t u = src + (uint32_t)lane;
-      if (key_earlier(a.v.vw[u], tag, idx)) { fail = true; PMA_WHY(6u); }  // an earlier pending update moves a sentinel we located by
+      if (key_earlier(a.v.vw[u], tag, idx)) { fail = true; PMA_WHYB(6u, a.v.vw[u]); }  // an earlier pending update moves a sentinel we located by
       if (a.vws[u] > me1) {                                // a LATER update already moved it
         stamp_bad = true;
         a.vdbg[4 * wid + 0] = u;
@@ -1921,7 +2131,7 @@ PMA_KERNEL void o_check(OptArgs a) {
     if (strong) {
       const uint32_t ml = h.mv_lo, mh = h.mv_hi;
       for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) {
-        if (key_earlier(a.v.vr[u], tag, idx)) { fail = true; PMA_WHY(7u); }  // an earlier pending update still needs the old position
+        if (key_earlier(a.v.vr[u], tag, idx)) { fail = true; PMA_WHYB(7u, a.v.vr[u]); }  // an earlier pending update still needs the old position
         if (a.vrs[u] > me1 || a.vws[u] > me1) {              // a LATER update already used / moved it
           stamp_bad = true;
           a.vdbg[4 * wid + 0] = (uint32_t)u;
@@ -1934,12 +2144,22 @@ PMA_KERNEL void o_check(OptArgs a) {
   const bool anyfail = wv::ballot(fail) != 0;
   const bool anybad = wv::ballot(stamp_bad) != 0;
   if (a.diag && anyfail) {
-    uint32_t w = why;
+    uint32_t w = why, wb = blk;
     for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t y = wv::shfl(w, lane ^ o);
-      w = y < w ? y : w;
+      const uint32_t y = wv::shfl(w, lane ^ o), yb = wv::shfl(wb, lane ^ o);
+      if (y < w || (y == w && yb < wb)) {
+        w = y;
+        wb = yb;
+      }
     }
     if (lane == 0 && w < 12u) wv::atomic_add_u64(&c->why[w], 1ull);
+    if (lane == 0 && a.dg != nullptr) {
+      uint32_t *r = a.dg + 4ull * idx;
+      r[0] += 1u;
+      r[1] = w;
+      r[2] = wb;
+      r[3] = h.wlen;
+    }
   }
   if (anyfail && kind_real(kind)) {
     // a deferred update keeps later updates out of its region(s); its footprint may still creep over a region edge
@@ -1962,8 +2182,16 @@ PMA_KERNEL void o_check(OptArgs a) {
     if (lh > bh) bh = lh;
     if (bh >= nleaves) bh = nleaves - 1u;
     for (uint32_t leaf = bl + (uint32_t)lane; leaf <= bh; leaf += 64) wv::atomic_min_u64(&a.pfail[leaf], key);
+    if (a.chain) {  // (what it reserves NOW; its window may still grow — that is what validation is for)
+      const uint32_t xl = writes ? h.wleaf_lo : (h.index >> a.v.g.sh), xh = writes ? h.wleaf_hi : xl;
+      mark_foreign_regions(a, h, pl, key, xl, xh, lane);
+    }
   }
   if (lane == 0) a.status[wid] = (anyfail ? 0u : OS_PASS) | (anybad ? OS_STAMP_BAD : 0u);
+  if (a.chain && lane == 0 && c->bk_round == a.round) {  // into its place of the bucket's list
+    const uint32_t pos = a.bk_pos[wid];
+    if (pos != kMax) a.bk_list[a.bk_base[chain_bucket(a.bk_reg[wid])] + pos] = wid;
+  }
 }
 
 PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
@@ -1993,8 +2221,12 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
       glo = ghi = (h.index >> a.v.g.sh) >> a.regshift;
     }
     bool blocked = false, blocked_r = false;
+    uint32_t rblk = kMax;
     for (uint32_t g = glo + (uint32_t)lane; g <= ghi; g += 64)
-      if (key_earlier(a.regfail[g], tag, idx)) blocked_r = true;
+      if (key_earlier(a.regfail[g], tag, idx)) {
+        blocked_r = true;
+        rblk = (uint32_t)a.regfail[g];
+      }
     // ... nor may we have READ a leaf an earlier deferred update may still grow over
     PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, { if (key_earlier(a.pfail[leaf], tag, idx)) blocked = true; });
     // ... nor located our range by a sentinel inside the block a deferred earlier update may still grow over
@@ -2002,7 +2234,26 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
     if (lane == 1 && (h.sdep & 2u) && key_earlier(a.pfail[h.sleaf_e], tag, idx)) blocked = true;
     const bool any_r = wv::ballot(blocked_r) != 0, any_p = wv::ballot(blocked) != 0;
     if (a.diag && (any_r || any_p) && lane == 0) wv::atomic_add_u64(&c->why[any_r ? 8 : 9], 1ull);
-    if (any_r || any_p) return;  // an earlier update of this region was deferred: keep stream order inside it
+    if (a.diag && a.dg != nullptr && (any_r || any_p)) {
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t y = wv::shfl(rblk, lane ^ o);
+        rblk = y < rblk ? y : rblk;
+      }
+      if (lane == 0) {
+        uint32_t *r = a.dg + 4ull * idx;
+        r[0] += 1u;
+        r[1] = any_r ? 8u : 9u;
+        r[2] = rblk;
+        r[3] = h.wlen;
+      }
+    }
+    if (any_r || any_p) {  // an earlier update of this region was deferred: keep stream order inside it
+      if (a.chain) {  // (still pending: chains of the other regions it touches must not overtake it)
+        const uint32_t ll = writes ? h.wleaf_lo : (h.index >> a.v.g.sh), lh = writes ? h.wleaf_hi : ll;
+        mark_foreign_regions(a, h, pl, key, ll, lh, lane);
+      }
+      return;
+    }
   }
   if (st & OS_STAMP_BAD) {
     if (a.diag && lane == 0) wv::atomic_add_u64(&c->why[10], 1ull);
@@ -2053,8 +2304,235 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
       for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_max_u32(&a.vws[u], me1);
     }
   }
+  if (a.chain_fence & 512u) wv::fence_mode(128u);  // (experiment: write-back after every commit of o_apply)
   if (lane == 0) a.status[wid] = OS_COMMITTED;  // (the epoch's max committed index is reduced in o_compact: a
                                                 // per-update atomicMax on one word would serialise the whole round)
+}
+
+
+// Offsets of the buckets' lists: exclusive scan of this round's counts (ONE workgroup of 1024 threads, 32 buckets each).
+PMA_KERNEL void o_bscan(OptArgs a) {
+  PMA_SHARED uint32_t wtot[16];
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  const uint32_t tid = wv::thread_idx();
+  const int lane = wv::lane(), w = wv::wave_in_block();
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  (void)par;
+  if (!a.chain || f_done || f_viol || f_excl || f_err) return;
+  constexpr uint32_t kPer = kChainBuckets / 1024u;
+  uint32_t cnt[kPer], mine = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < kPer; q++) {
+    const unsigned long long x = a.bk_cnt[tid * kPer + q];
+    cnt[q] = ((uint32_t)(x >> 32) == a.round) ? (uint32_t)x : 0u;
+    mine += cnt[q];
+  }
+  uint32_t incl = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) wtot[w] = incl;
+  wv::block_sync();
+  uint32_t run = incl - mine;
+  for (int q = 0; q < w; q++) run += wtot[q];
+#pragma unroll
+  for (uint32_t q = 0; q < kPer; q++) {
+    a.bk_base[tid * kPer + q] = run;
+    run += cnt[q];
+  }
+  if (tid == 0) c->bk_round = a.round;
+}
+
+// The two halves of a chained update as CALLED device functions: o_chain with both inlined is an 11 K-instruction kernel
+// whose SGPRs spill into VGPR lanes, and it came out of the compiler wrong in a way that moved with unrelated edits
+// (num_neighbors short by one after some chained updates, bit-exact again with one more `if` in apply_op).  Kept small,
+// the pieces are compiled like everywhere else; the call costs nothing next to the memory round trips of an update.
+PMA_DEV_CALL void chain_plan(const View *v, const Op *op, Plan *plan, uint32_t r0, uint32_t r1, dev::PlanRegs *out) {
+  *out = dev::plan_op_t<true>(*v, *op, plan, r0, r1);
+}
+PMA_DEV_CALL void chain_apply(const View *v, const Op *op, const Plan *plan, uint32_t *lds, StatShard *st) {
+  dev::apply_op(*v, *op, plan, lds, st);
+}
+
+// ---- in-round chains ---------------------------------------------------------------------------------------------------
+// A round commits at most one update per conflict chain: updates of one leaf (or of overlapping small windows) wait for one
+// another, one round each.  Streams that keep hitting the same small neighbourhoods (a few hundred updates of ONE vertex
+// whose range is a handful of leaves) are bound by exactly that: rounds = chain length.  o_chain runs after o_apply: for
+// every region that still holds planned-but-uncommitted updates, the wave of the FIRST of them (stream order) goes on
+// executing them one after the other — plan against the current state, check, apply — as long as
+//   * the update's whole footprint (reads, writes, the sentinels it locates its range by) lies inside the region — updates
+//     of different regions then cannot touch each other, and inside the region the wave itself keeps stream order;
+//   * no EARLIER pending update from elsewhere reaches into the region (OptArgs::xmin, set by every deferred update for the
+//     regions it touches but does not live in), none is exclusive / a barrier;
+//   * no LATER update has already been committed on what it reads or writes (stamps, as everywhere).
+// The first update that fails any of this ends the chain and stays pending, with everything behind it.
+PMA_KERNEL void o_chain(OptArgs a) {
+  PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
+  PMA_SHARED uint32_t chain_lds[4][kChainList];
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
+  const int lane = wv::lane();
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  const uint32_t hor = c->hor[par];
+  const unsigned long long gbar = c->gbar[par], sbar = c->sbar[par];
+  const uint32_t nz = c->nzones[par];
+  if (!a.chain || f_done || f_viol || f_excl || f_err) return;
+  if (wid >= hor || c->bk_round != a.round) return;
+  const int sh = a.v.g.sh;
+  // the wave of the bucket's FIRST arrival owns the bucket for this launch (the lists do not change while the chains run)
+  if (a.bk_pos[wid] != 0u) return;
+  const uint32_t bucket = chain_bucket(a.bk_reg[wid]);
+  const uint32_t n_l = (uint32_t)a.bk_cnt[bucket], l_base = a.bk_base[bucket];
+  if (n_l < 2u && (a.status[wid] & OS_COMMITTED)) return;  // (alone and done: nothing to chain)
+  if (n_l > kChainList) return;                            // (longer than the LDS tile: this bucket runs without a chain)
+  // the list, sorted by horizon slot (= stream order) in this wave's LDS tile
+  uint32_t *ll = chain_lds[wv::wave_in_block()];
+  uint32_t n2 = 64;
+  while (n2 < n_l) n2 <<= 1;
+  for (uint32_t i = (uint32_t)lane; i < n2; i += 64u) ll[i] = i < n_l ? a.bk_list[l_base + i] : kMax;
+  wv::lds_fence();
+  for (uint32_t k = 2; k <= n2; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = (uint32_t)lane; t < (n2 >> 1); t += 64u) {
+        const uint32_t lo = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), hi = lo | j;
+        const bool up = (lo & k) == 0u;
+        const uint32_t x = ll[lo], y = ll[hi];
+        if ((x > y) == up) {
+          ll[lo] = y;
+          ll[hi] = x;
+        }
+      }
+      wv::lds_fence();
+    }
+  const uint32_t tag = (uint32_t)(make_key(a.round, 0) >> 32);
+  const uint32_t nleaves_all = (uint32_t)(a.v.g.N >> sh);
+  // a chain that has ended leaves everything later of ITS region pending; a bucket holds one region unless two hash alike
+  // (two are remembered; a third one ends the bucket's launch)
+#define PMA_CHAIN_END(code)                                                      \
+  {                                                                              \
+    if (a.diag && lane == 0) wv::atomic_add_u64(&c->chain_why[code], 1ull);      \
+    if (dead_a == kMax || dead_a == region) dead_a = region;                     \
+    else if (dead_b == kMax || dead_b == region) dead_b = region;                \
+    else all_dead = true;                                                        \
+    goto next_entry;                                                             \
+  }
+  if (a.diag && lane == 0) wv::atomic_add_u64(&c->chain_why[9], 1ull);
+  StatShard *sts = &a.stats[wv::block_idx() & (kStatShards - 1)];
+  uint32_t steps = 0;
+  uint32_t cur_region = kMax, dead_a = kMax, dead_b = kMax, rlo = 0, rhi = 0, stop = kMax, stop_why = 0;
+  bool all_dead = false;
+  for (uint32_t i = 0; i < n_l && !all_dead; i++) {
+    const uint32_t w = ll[i];  // (horizon slot; ascending = stream order)
+    const uint32_t region = a.bk_reg[w];
+    const uint32_t e_st = a.status[w], nxt = a.opidx[w];
+    if (e_st & OS_COMMITTED) continue;
+    if (region == dead_a || region == dead_b) continue;  // (its chain has ended: everything later of that region stays pending)
+    if (steps >= a.chain) {
+      if (a.diag && lane == 0) wv::atomic_add_u64(&c->chain_why[2], 1ull);
+      break;
+    }
+    if (region != cur_region) {  // (a bucket holds ONE region unless two regions hash alike)
+      cur_region = region;
+      rlo = region << a.chshift;  // first / last leaf of the region
+      rhi = (rlo + (1u << a.chshift) - 1u < nleaves_all) ? rlo + (1u << a.chshift) - 1u : nleaves_all - 1u;
+      // stream index below which nothing foreign is pending: an exclusive update, a global barrier, a soft-barrier zone that
+      // overlaps the region, an earlier update from elsewhere reaching into this region
+      stop = kMax;
+      stop_why = 0;
+      const unsigned long long xm = a.xmin[region];
+      if ((uint32_t)(gbar >> 32) == tag && (uint32_t)gbar < stop) { stop = (uint32_t)gbar; stop_why = 1; }
+      if ((uint32_t)(sbar >> 32) == tag && (uint32_t)sbar + 1u < stop) { stop = (uint32_t)sbar + 1u; stop_why = 2; }  // (the barrier update itself may run)
+      if ((uint32_t)(xm >> 32) == tag && (uint32_t)xm < stop) { stop = (uint32_t)xm; stop_why = 3; }
+      for (uint32_t z = 0; z < nz && z < kMaxZones; z++) {
+        const unsigned long long zk = c->zone_key[par][z];
+        if ((uint32_t)(zk >> 32) == tag && (uint32_t)zk + 1u < stop && c->zone_lo[par][z] <= rhi && c->zone_hi[par][z] >= rlo) {
+          stop = (uint32_t)zk + 1u;
+          stop_why = 5;
+        }
+      }
+      if (a.jobs != nullptr && c->jobs_round[par] == a.round) {
+        // big windows queued by this round's o_apply are rebalanced by the workgroups of o_compact — AFTER this kernel: a region
+        // such a window covers is in the middle of an update (slide and write done, rebalance pending)
+        uint32_t nj = c->njobs[par];
+        if (nj > kBigJobs) nj = kBigJobs;
+        bool hit = false;
+        for (uint32_t j = (uint32_t)lane; j < nj; j += 64) {
+          const dev::BigJob jb = a.jobs[j];
+          const uint32_t jl = jb.wstart >> sh, jh = (jb.wstart + jb.wlen - 1u) >> sh;
+          if (jl <= rhi && jh >= rlo) hit = true;
+        }
+        if (wv::ballot(hit) != 0ull) PMA_CHAIN_END(8)
+      }
+    }
+    if (nxt >= stop) {
+      if (a.diag && lane == 0) wv::atomic_add_u64(&c->chain_stop[stop_why], 1ull);
+      PMA_CHAIN_END(1)
+    }
+    {
+    const Op op = a.ops[nxt];
+    Plan *pl = &a.plans[w];
+    // against the state as it is NOW, and from this region's slots alone (no other region is read while its owner writes it)
+    dev::PlanRegs pr;
+    chain_plan(&a.v, &op, pl, rlo << sh, ((rhi + 1u) << sh) - 1u, &pr);
+    const uint32_t kind = pr.kind;
+    if (kind == K_FOREIGN) PMA_CHAIN_END(5)
+    if (!kind_real(kind) || kind == K_EXCL) PMA_CHAIN_END(3)
+    const bool strong = kind_strong(kind), writes = kind_writes(kind);
+    if (pr.nr > 64u || pr.nlong) PMA_CHAIN_END(4)  // (read ranges beyond the register copy: leave it to the ordinary round)
+    // footprint inside the region?
+    bool out = false;
+    const uint32_t il = pr.index >> sh;
+    if (lane == 0) out = writes ? (pr.wleaf_lo < rlo || pr.wleaf_hi > rhi) : (il < rlo || il > rhi);
+    if ((uint32_t)lane < pr.nr && (pr.my_lo < rlo || pr.my_hi > rhi)) out = true;
+    if (lane == 1 && (pr.sdep & 1u) && (pr.sleaf_b < rlo || pr.sleaf_b > rhi)) out = true;
+    if (lane == 2 && (pr.sdep & 2u) && (pr.sleaf_e < rlo || pr.sleaf_e > rhi)) out = true;
+    if ((a.chain_fence & 2048u) && lane == 3 && (pr.sleaf_b < rlo || pr.sleaf_b > rhi || pr.sleaf_e < rlo || pr.sleaf_e > rhi)) out = true;  // (experiment)
+    if (strong && pr.wlen > a.big_min) PMA_CHAIN_END(6)  // (a window for a workgroup: the ordinary round queues it)
+    if (wv::ballot(out) != 0ull) PMA_CHAIN_END(5)
+    // nothing LATER may have been committed on what this update reads or writes
+    const uint32_t me1 = nxt + 1u;
+    bool bad = false;
+    if (strong) {
+      for (uint32_t leaf = pr.wleaf_lo + (uint32_t)lane; leaf <= pr.wleaf_hi; leaf += 64)
+        if (a.wstamp[leaf] > me1 || a.rstamp[leaf] > me1) bad = true;
+      for (uint64_t u = (uint64_t)pr.mv_lo + (uint64_t)lane; u <= (uint64_t)pr.mv_hi && pr.mv_lo <= pr.mv_hi; u += 64)
+        if (a.vrs[u] > me1 || a.vws[u] > me1) bad = true;
+    } else if (kind == K_DUP) {
+      if (lane == 0 && a.wstamp[pr.wleaf_lo] > me1) bad = true;
+    }
+    if ((uint32_t)lane < pr.nr)
+      for (uint32_t leaf = pr.my_lo; leaf <= pr.my_hi; leaf++)
+        if (a.wstamp[leaf] > me1) bad = true;
+    if (op.src < a.v.g.n && lane < 2 && ((pr.sdep >> lane) & 1u) && op.src + (uint32_t)lane < a.v.g.n && a.vws[op.src + (uint32_t)lane] > me1) bad = true;
+    if (wv::ballot(bad) != 0ull) PMA_CHAIN_END(7)  // (the ordinary round meets the same stamps and raises the violation)
+    wv::fence();  // the plan record (lane 0's stores) before apply_op reads it back
+#if defined(PPCSR_SIM)
+    if (lane == 0 && getenv("PPCSR_TRACE"))
+      fprintf(stderr, "R%u chain idx=%u op=(%u,%u,%u) kind=%u index=%u win=(%u,%u) wleaf=[%u,%u] nr=%u\n", a.round, nxt, op.src, op.dst, op.op, kind,
+              pr.index, pr.wstart, pr.wlen, pr.wleaf_lo, pr.wleaf_hi, pr.nr);
+#endif
+    chain_apply(&a.v, &op, pl, lds[wv::wave_in_block()], sts);
+    if (strong) {
+      for (uint32_t leaf = pr.wleaf_lo + (uint32_t)lane; leaf <= pr.wleaf_hi; leaf += 64) wv::atomic_max_u32(&a.wstamp[leaf], me1);
+      for (uint64_t u = (uint64_t)pr.mv_lo + (uint64_t)lane; u <= (uint64_t)pr.mv_hi && pr.mv_lo <= pr.mv_hi; u += 64) wv::atomic_max_u32(&a.vws[u], me1);
+    }
+    if ((uint32_t)lane < pr.nr)
+      for (uint32_t leaf = pr.my_lo; leaf <= pr.my_hi; leaf++) wv::atomic_max_u32(&a.rstamp[leaf], me1);
+    if (op.src < a.v.g.n && lane < 2 && ((pr.sdep >> lane) & 1u) && op.src + (uint32_t)lane < a.v.g.n) wv::atomic_max_u32(&a.vrs[op.src + (uint32_t)lane], me1);
+    if (lane == 0) {
+      a.status[w] = OS_CHAINED;
+      wv::atomic_add_u64(&sts->chained, 1ull);
+    }
+      steps++;
+      if (a.diag && lane == 0) wv::atomic_add_u64(&c->chain_why[10], 1ull);
+      wv::fence_mode(a.chain_fence & 255u);  // this update's stores before the next one's loads
+    }
+  next_entry:;
+  }
+#undef PMA_CHAIN_END
 }
 
 // stable compaction of the deferred updates into the next carry list + next round's bookkeeping
@@ -2099,16 +2577,16 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
     for (uint32_t q = 0; q < kC; q++) {
       if (q >= cpw) break;  // (wave-uniform)
       const bool in = wbase + q * 64u + (uint32_t)lane < hor;
-      wkeep += (uint32_t)wv::popc64(wv::ballot(in && st[q] != OS_COMMITTED));
-      if (in && st[q] == OS_COMMITTED && oi[q] + 1u > mymaxc) mymaxc = oi[q] + 1u;
+      wkeep += (uint32_t)wv::popc64(wv::ballot(in && !(st[q] & OS_COMMITTED)));
+      if (in && (st[q] & OS_COMMITTED) && oi[q] + 1u > mymaxc) mymaxc = oi[q] + 1u;
     }
   } else {
     for (uint32_t q = 0; q < cpw; q++) {
       const uint32_t sl = wbase + q * 64u + (uint32_t)lane;
       const bool in = sl < hor;
       const uint32_t s1 = in ? a.status[sl] : OS_COMMITTED, x = in ? a.opidx[sl] : 0u;
-      wkeep += (uint32_t)wv::popc64(wv::ballot(in && s1 != OS_COMMITTED));
-      if (in && s1 == OS_COMMITTED && x + 1u > mymaxc) mymaxc = x + 1u;
+      wkeep += (uint32_t)wv::popc64(wv::ballot(in && !(s1 & OS_COMMITTED)));
+      if (in && (s1 & OS_COMMITTED) && x + 1u > mymaxc) mymaxc = x + 1u;
     }
   }
   if (lane == 0) wsum[w] = wkeep;
@@ -2124,7 +2602,7 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
 #pragma unroll
     for (uint32_t q = 0; q < kC; q++) {
       if (q >= cpw) break;
-      const bool keep = wbase + q * 64u + (uint32_t)lane < hor && st[q] != OS_COMMITTED;
+      const bool keep = wbase + q * 64u + (uint32_t)lane < hor && !(st[q] & OS_COMMITTED);
       const uint64_t m = wv::ballot(keep);
       if (keep) {
         const uint32_t pos = o + (uint32_t)wv::popc64(m & lt);
@@ -2138,7 +2616,7 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
       const uint32_t sl = wbase + q * 64u + (uint32_t)lane;
       const bool in = sl < hor;
       const uint32_t s1 = in ? a.status[sl] : OS_COMMITTED, x = in ? a.opidx[sl] : 0u;
-      const bool keep = in && s1 != OS_COMMITTED;
+      const bool keep = in && !(s1 & OS_COMMITTED);
       const uint64_t m = wv::ballot(keep);
       if (keep) {
         const uint32_t pos = o + (uint32_t)wv::popc64(m & lt);
@@ -2202,6 +2680,10 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
     c->hor[par ^ 1u] = nh;
     c->gbar[par ^ 1u] = ~0ull;
     c->gbar[par] = ~0ull;
+    c->sbar[par ^ 1u] = ~0ull;
+    c->sbar[par] = ~0ull;
+    c->nzones[par ^ 1u] = 0u;
+    c->nzones[par] = 0u;
     c->njobs[par ^ 1u] = 0;
     c->skip = kMax;
     const bool done = (new_cn == 0 && new_nf == e1);

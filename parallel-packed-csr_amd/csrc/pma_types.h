@@ -65,6 +65,7 @@ enum Kind : uint32_t {
   K_NOTFOUND = 4,  // delete of a missing edge: only num_neighbors-- (PCSR.cpp:747-754)
   K_EXCL = 5,      // must run alone through the exclusive executor (global path, resize, big window)
   K_SKIP = 6,      // already executed by the exclusive executor inside this epoch: commits as nothing
+  K_FOREIGN = 7,   // (region-local planning only) the update cannot be located from the region's own slots
 };
 
 constexpr int kMaxR = 72;  // read-leaf ranges recorded per op (search certificate + one or two per level of the density climb + a few)

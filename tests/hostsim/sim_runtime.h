@@ -12,6 +12,7 @@
 #include <functional>
 
 #define PMA_DEV inline
+#define PMA_DEV_CALL inline
 #define PMA_KERNEL
 #define PMA_LAUNCH_BOUNDS(threads, waves_per_simd)
 #define PMA_SHARED static
@@ -56,9 +57,15 @@ inline unsigned long long atomic_min_u64(unsigned long long *p, unsigned long lo
 inline uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 inline unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline uint32_t atomic_max_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
+inline unsigned long long atomic_max_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomic_exch_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
 inline uint32_t atomic_cas_u32(uint32_t *p, uint32_t expect, uint32_t v) { uint32_t o = *p; if (o == expect) *p = v; return o; }
+inline void wait_loads() {}
+inline void fence_heavy() { (void)sim::shfl64(0, 0); }
+inline void fence_mode(uint32_t) { (void)sim::shfl64(0, 0); }
 inline void flag_publish(uint32_t *p, uint32_t v) { *p = v; }
+inline void store_agent_u32(uint32_t *p, uint32_t v) { *p = v; }
+inline uint32_t load_agent_u32(const uint32_t *p) { return *(const volatile uint32_t *)p; }
 inline uint32_t flag_read(const uint32_t *p) { return *(const volatile uint32_t *)p; }
 inline void flag_acquire() {}
 inline uint32_t xcc_id() { return (uint32_t)sim::cur_block() & 7u; }

@@ -119,6 +119,34 @@ def test_sim_big_windows_inside_the_round(sim, big_min, big_window):
     assert st["exclusive_ops"] > 0
 
 
+@pytest.mark.parametrize("soft", [64, 128, 1 << 30])
+def test_sim_soft_barrier_with_ignored_adds(sim, soft):
+    """A soft barrier (planned window >= soft_barrier slots) used to be published as key + 1 in the word that carries the
+    K_EXCL barrier: when it and everything before it committed, the NEXT update was sent to the exclusive executor whatever
+    its kind — and an add with src >= n (accepted input, silently ignored: PCSR.cpp:1375) then indexed nodes[] out of bounds.
+    Hub stream (windows climb past the small barrier) with every 2nd op such an add."""
+    n = 60
+    m = 3000
+    hub = np.stack([np.full(m, 3, np.uint32), 1 + (np.arange(m, dtype=np.uint32) * 7919) % 100003, np.ones(m, np.uint32)], 1)
+    junk = np.stack([np.full(m, n + 7, np.uint32), np.arange(m, dtype=np.uint32), np.ones(m, np.uint32)], 1)
+    ops = np.empty((2 * m, 3), np.uint32)
+    ops[0::2] = hub
+    ops[1::2] = junk
+    e = sim(n, True, mode=1, opt_horizon=8, epoch_ops=4096, region_slots=64)
+    e.set_option("soft_barrier", soft)
+    o = Oracle(n)
+    e.apply(ops)
+    o.apply(ops)
+    _same(e, o)
+    se = e.stats()
+    assert se["noops"] == m
+    if soft < (1 << 30):  # a barrier alone never makes an update exclusive
+        e2 = sim(n, True, mode=1, opt_horizon=8, epoch_ops=4096, region_slots=64)
+        e2.set_option("soft_barrier", 1 << 30)
+        e2.apply(ops)
+        assert se["exclusive_ops"] == e2.stats()["exclusive_ops"]
+
+
 def test_sim_speculative_stats_survive_rollback(sim, streams):
     ops = streams.random_stream(1000, 12000, seed=5, p_delete=0.2)
     e, o = sim(1000, mode=1, opt_horizon=256, epoch_ops=2048, region_slots=32), Oracle(1000)
