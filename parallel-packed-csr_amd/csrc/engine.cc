@@ -164,13 +164,13 @@ struct Engine::Impl {
   uint32_t soft_barrier = 0;
   uint32_t defer_barrier = 0;  // slots; a deferred update with a window at least this big lets nothing later overtake it (0: off)
   // a soft barrier holds back later updates only inside the aligned block of zone_factor x its planned window (0: everywhere)
-  uint32_t zone_factor = 8;
+  uint32_t zone_factor = 0;
   uint32_t diag = 0;     // count, per epoch, why planned updates did not commit (printed to stderr at the end of the epoch)
   // in-round chains (o_chain): 0 never, 1 when the rounds commit little of what they plan (conflict chains), 2 always
-  uint32_t chain = 1, chain_steps = 8, chain_fence = 0;
+  uint32_t chain = 0, chain_steps = 32, chain_fence = 0, chain_grid = 2048;
   bool chain_on = false;  // the regime the last round chunk was in (kept across epochs and batches)
   unsigned long long *d_bk_cnt = nullptr, *d_xmin = nullptr;
-  uint32_t *d_bk_base = nullptr, *d_bk_list = nullptr, *d_bk_pos = nullptr, *d_bk_reg = nullptr;
+  uint32_t *d_bk_base = nullptr, *d_bk_list = nullptr, *d_bk_pos = nullptr, *d_bk_reg = nullptr, *d_owners = nullptr, *d_bk_flag = nullptr;
   uint64_t bk_cap = 0;
   uint64_t xmin_cap = 0;
   uint32_t *d_dg = nullptr;  // diag >= 2: per-update trace of the batch (OptArgs::dg)
@@ -199,6 +199,7 @@ static int ensure_plans(Engine::Impl &p) {
 static int reset_chain_tags(Engine::Impl &p) {
   int e;
   if (p.d_bk_cnt && (e = gpu::dset(p.d_bk_cnt, 0, (uint64_t)kChainBuckets * sizeof(unsigned long long), p.stream))) return e;
+  if (p.d_bk_flag && (e = gpu::dset(p.d_bk_flag, 0, (uint64_t)kChainBuckets * sizeof(uint32_t), p.stream))) return e;
   if (p.d_xmin && (e = gpu::dset(p.d_xmin, 0xFF, p.xmin_cap * sizeof(unsigned long long), p.stream))) return e;
   return 0;
 }
@@ -465,6 +466,8 @@ Engine::~Engine() {
   if (p.d_bk_list) GPU_DFREE(p.d_bk_list);
   if (p.d_bk_pos) GPU_DFREE(p.d_bk_pos);
   if (p.d_bk_reg) GPU_DFREE(p.d_bk_reg);
+  if (p.d_owners) GPU_DFREE(p.d_owners);
+  if (p.d_bk_flag) GPU_DFREE(p.d_bk_flag);
   if (p.d_dg) GPU_DFREE(p.d_dg);
   for (Impl::Snap *sp : {&p.snap, &p.esnap}) {
     if (sp->v.items) GPU_DFREE(sp->v.items);
@@ -650,6 +653,10 @@ int Engine::set_option(const char *key, int64_t value) {
   if (k == "chain") {
     if (value < 0 || value > 2) return fail(PPCSR_EINVAL, "chain must be 0 (off), 1 (auto) or 2 (always)");
     p.chain = (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "chain_grid") {
+    p.chain_grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 1 << 16));
     return PPCSR_OK;
   }
   if (k == "chain_fence") {
@@ -887,10 +894,10 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     }
   }
   if (p.chain && p.bk_cap < (uint64_t)p.opt_horizon + 8) {  // per-region lists of the in-round chains
-    for (void *q : {(void *)p.d_bk_cnt, (void *)p.d_bk_base, (void *)p.d_bk_list, (void *)p.d_bk_pos, (void *)p.d_bk_reg})
+    for (void *q : {(void *)p.d_bk_cnt, (void *)p.d_bk_base, (void *)p.d_bk_list, (void *)p.d_bk_pos, (void *)p.d_bk_reg, (void *)p.d_owners, (void *)p.d_bk_flag})
       if (q) gpu::dfree(q);
     p.d_bk_cnt = nullptr;
-    p.d_bk_base = p.d_bk_list = p.d_bk_pos = p.d_bk_reg = nullptr;
+    p.d_bk_base = p.d_bk_list = p.d_bk_pos = p.d_bk_reg = p.d_owners = p.d_bk_flag = nullptr;
     p.bk_cap = 0;
     const uint64_t cap = (uint64_t)p.opt_horizon + 8;
     GCHK(gpu::dmalloc((void **)&p.d_bk_cnt, (uint64_t)kChainBuckets * sizeof(unsigned long long)));
@@ -898,6 +905,9 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     GCHK(gpu::dmalloc((void **)&p.d_bk_list, cap * sizeof(uint32_t)));
     GCHK(gpu::dmalloc((void **)&p.d_bk_pos, cap * sizeof(uint32_t)));
     GCHK(gpu::dmalloc((void **)&p.d_bk_reg, cap * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_owners, 8 * cap * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_bk_flag, (uint64_t)kChainBuckets * sizeof(uint32_t)));
+    GCHK(gpu::dset(p.d_bk_flag, 0, (uint64_t)kChainBuckets * sizeof(uint32_t), p.stream));
     p.bk_cap = cap;
     GCHK(gpu::dset(p.d_bk_cnt, 0, (uint64_t)kChainBuckets * sizeof(unsigned long long), p.stream));
     GCHK(gpu::dset(p.d_bk_pos, 0xFF, cap * sizeof(uint32_t), p.stream));
@@ -1015,6 +1025,9 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       a.bk_list = p.d_bk_list;
       a.bk_pos = p.d_bk_pos;
       a.bk_reg = p.d_bk_reg;
+      a.owners = p.d_owners;
+      a.owners_cap = (uint32_t)p.bk_cap;
+      a.bk_flag = p.d_bk_flag;
       a.xmin = p.d_xmin;
       a.dg = p.diag >= 2 ? p.d_dg : (uint32_t *)nullptr;
       a.soft_barrier = p.soft_barrier ? p.soft_barrier : a.v.big_window / 2u;
@@ -1059,7 +1072,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         GPU_LAUNCH(p.stream, o_check, blocks, 256, a);
         if (p.profile) p.events[5 * r + 2].record(p.stream);
         GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
-        if (use_chain) GPU_LAUNCH(p.stream, o_chain, blocks, 256, a);  // (profile: counted with o_apply)
+        if (use_chain) GPU_LAUNCH(p.stream, o_chain, p.chain_grid, 64, a);  // one wave per workgroup; (profile: counted with o_apply)
         if (p.profile) p.events[5 * r + 3].record(p.stream);
         GPU_LAUNCH(p.stream, o_compact, 1u + (use_big ? p.big_grid : 0u), 1024, a);  // workgroup 0 compacts, the others rebalance big windows
         if (p.profile) p.events[5 * r + 4].record(p.stream);

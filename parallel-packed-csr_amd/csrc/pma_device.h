@@ -32,6 +32,10 @@ struct View {
   uint32_t *ldirty;  // per leaf
   uint32_t *vdirty;  // per vertex (node record: beginning, end, num_neighbors)
   uint32_t serial;
+  // exclusive bound of the gap search to the right (0: the end of the array).  The in-round chains work on a copy of ONE region
+  // held in LDS (items / leafcnt then point into that copy, biased so that absolute slot / leaf numbers index it): nothing beyond
+  // the region may be touched, and a gap that is not found inside it counts as "none" (the update is not for the chain)
+  uint64_t gap_end;
   Geometry g;
   // largest rebalance window a round accepts (larger ones make the update exclusive).  Strict rounds: kBigWindow (one
   // wave rebalances it); speculative rounds: up to kBigLeaves leaves, rebalanced by a workgroup (o_big)
@@ -90,16 +94,16 @@ PMA_DEV void fix_sentinel(const View &v, const Edge &e, uint32_t in) {
   if (vid == kMax) {
     vid = 0;
   } else {
-    wv::store_agent_u32(&v.nodes[vid - 1].end, in);
-    wv::atomic_max_u32(&v.vdirty[vid - 1], v.serial);
+    v.nodes[vid - 1].end = in;
+    v.vdirty[vid - 1] = v.serial;
   }
-  wv::store_agent_u32(&v.nodes[vid].beginning, in);
-  wv::atomic_max_u32(&v.vdirty[vid], v.serial);
-  if (vid == v.g.n - 1) wv::store_agent_u32(&v.nodes[vid].end, (uint32_t)(v.g.N - 1));
+  v.nodes[vid].beginning = in;
+  v.vdirty[vid] = v.serial;
+  if (vid == v.g.n - 1) v.nodes[vid].end = (uint32_t)(v.g.N - 1);
 }
 // dirty tags of the leaves [lo, hi] (whole wave)
 PMA_DEV void mark_leaves(const View &v, uint64_t lo, uint64_t hi) {
-  for (uint64_t leaf = lo + (uint64_t)wv::lane(); leaf <= hi; leaf += 64) wv::atomic_max_u32(&v.ldirty[leaf], v.serial);
+  for (uint64_t leaf = lo + (uint64_t)wv::lane(); leaf <= hi; leaf += 64) v.ldirty[leaf] = v.serial;
 }
 
 constexpr uint32_t kLongRange = 8;  // read ranges spanning more leaves are walked by the whole wave
@@ -323,7 +327,7 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
 // pre / pre_nul / pre_w: the caller has already loaded the first pre_w slots (lane l < pre_w: slot from + l is null)
 PMA_DEV uint32_t find_gap_right(const View &v, uint32_t from, uint32_t limit, bool pre = false, bool pre_nul = false, uint32_t pre_w = 64) {
   const int lane = wv::lane();
-  const uint64_t N = v.g.N;
+  const uint64_t N = v.gap_end ? v.gap_end : v.g.N;
   for (uint64_t base = from; base < N; base += 64) {
     if (base - from > limit) return kMax;
     const uint64_t s = base + (uint64_t)lane;
@@ -333,7 +337,7 @@ PMA_DEV uint32_t find_gap_right(const View &v, uint32_t from, uint32_t limit, bo
     const uint64_t m = wv::ballot(nul);
     if (m) return (uint32_t)(base + (uint64_t)wv::ctz64(m));
   }
-  return (uint32_t)N;
+  return (uint32_t)v.g.N;
 }
 
 enum PlanStatus : int { PS_OK = 0, PS_GLOBAL_NOINFO = 1, PS_GLOBAL_DOUBLE = 2, PS_SLIDE_OFF_END = 3, PS_SLIDE_LONG = 4 };
@@ -957,7 +961,6 @@ PMA_DEV PlanRegs plan_op_t(const View &v, const Op op, Plan *plan, uint32_t r0 =
         } else located = false;
         if (located && s_end <= s_start) located = false;  // (cannot happen in a sorted neighbourhood)
       }
-      if ((uint64_t)r1 + 1u >= g.N) located = false;  // (the array's last region: slot N-1 has rules of its own)
     }
   }
   if (op.src < g.n && !located) {
@@ -982,7 +985,7 @@ PMA_DEV PlanRegs plan_op_t(const View &v, const Op op, Plan *plan, uint32_t r0 =
     constexpr uint32_t kGapPre = 16;  // slots of the gap search requested with this batch (a null within 16 slots in 99.7 % of the cases at density 0.7)
     if (op.op != 0 && (uint32_t)lane < kGapPre) {
       const uint64_t g0 = (uint64_t)index + 1ull + (uint64_t)lane;
-      if (g0 < g.N) nul0 = (v.items[g0].value == 0);
+      if (g0 < (v.gap_end ? v.gap_end : g.N)) nul0 = (v.items[g0].value == 0);
     }
     const bool occupied = !is_null(at);
     if (op.op != 0) {
@@ -1258,24 +1261,24 @@ PMA_DEV void apply_op(const View &v, const Op op, const Plan *plan, uint32_t *ld
   if (kind == K_DUP) {
     if (lane == 0) {
       v.items[index].value = op.op;
-      wv::atomic_max_u32(&v.ldirty[index >> g.sh], v.serial);
-      wv::atomic_max_u32(&v.vdirty[op.src], v.serial);
-      wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 1u);
+      v.ldirty[index >> g.sh] = v.serial;
+      v.vdirty[op.src] = v.serial;
+      wv::atomic_add_nn(&v.nodes[op.src].num_neighbors, 1u);
       wv::atomic_add_u64(&st->duplicates, 1ull);
     }
     return;
   }
   if (kind == K_NOTFOUND) {
     if (lane == 0) {
-      wv::atomic_max_u32(&v.vdirty[op.src], v.serial);
-      wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
+      v.vdirty[op.src] = v.serial;
+      wv::atomic_add_nn(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
       wv::atomic_add_u64(&st->not_found, 1ull);
     }
     return;
   }
   if (kind == K_INSERT || kind == K_REMOVE) {  // everything this update writes lies in [wleaf_lo, wleaf_hi] (slide + window)
     mark_leaves(v, plan->wleaf_lo, plan->wleaf_hi);
-    if (lane == 0) wv::atomic_max_u32(&v.vdirty[op.src], v.serial);
+    if (lane == 0) v.vdirty[op.src] = v.serial;
   }
   if (kind == K_INSERT) {
     const uint32_t gap = plan->gap;
@@ -1286,7 +1289,7 @@ PMA_DEV void apply_op(const View &v, const Op op, const Plan *plan, uint32_t *ld
     if (lane == 0) {
       v.items[index] = Edge{op.src, op.dst, op.op};
       if (gap_outside) v.leafcnt[gap >> g.sh] += 1u;  // (a slide moves one element over every leaf boundary it crosses: only the gap's leaf gains)
-      wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 1u);
+      wv::atomic_add_nn(&v.nodes[op.src].num_neighbors, 1u);
       wv::atomic_add_u64(&st->redistribute_calls, (unsigned long long)plan->alg_calls);
       wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)plan->alg_slots);
       wv::atomic_add_u64(&st->slide_slots, (unsigned long long)(gap - index));
@@ -1302,7 +1305,7 @@ PMA_DEV void apply_op(const View &v, const Op op, const Plan *plan, uint32_t *ld
       v.items[index].dest = 0;
       if (defer || (uint64_t)index < (uint64_t)plan->wstart || (uint64_t)index >= (uint64_t)plan->wstart + plan->wlen)
         v.leafcnt[index >> g.sh] -= 1u;  // (in-wave: never — the window contains the slot and its leaves are recounted below)
-      wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
+      wv::atomic_add_nn(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
       wv::atomic_add_u64(&st->redistribute_calls, (unsigned long long)plan->alg_calls);
       wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)plan->alg_slots);
       if (defer) *defer = BigJob{plan->wstart, plan->wlen};

@@ -282,8 +282,8 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
       dev::SearchHit hit_;
       index = dev::pma_search(v, op.dst, nd.beginning + 1, nd.end, rr, &hit_);
       if (!(flags & XF_SKIP_COUNT) && lane == 0) {
-        wv::atomic_max_u32(&v.vdirty[op.src], v.serial);
-        wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 1u);
+        v.vdirty[op.src] = v.serial;
+        wv::atomic_add_nn(&v.nodes[op.src].num_neighbors, 1u);
       }
     }
     const Edge at = v.items[index];
@@ -293,7 +293,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
       if (xv_bad_reads(v, xv, rr, op.src) || xv_bad_writes(v, xv, index >> sh, index >> sh)) PMA_X_VIOLATION();
       if (lane == 0) {
         v.items[index].value = elem.value;
-        wv::atomic_max_u32(&v.ldirty[index >> sh], v.serial);
+        v.ldirty[index >> sh] = v.serial;
         wv::atomic_add_u64(&st->duplicates, 1ull);
       }
     } else if (occupied && (uint64_t)index == g.N - 1) {  // PCSR.cpp:533-540
@@ -444,8 +444,8 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
       dev::SearchHit hit_;
       const uint32_t index = dev::pma_search(v, op.dst, nd.beginning + 1, nd.end, rr, &hit_);
       if (!(flags & XF_SKIP_COUNT) && lane == 0) {
-        wv::atomic_max_u32(&v.vdirty[op.src], v.serial);
-        wv::atomic_add_u32(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
+        v.vdirty[op.src] = v.serial;
+        wv::atomic_add_nn(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
       }
       const Edge at = v.items[index];
       wv::fence();
@@ -460,7 +460,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
           PMA_X_VIOLATION();
         wv::fence();  // planning reads are complete in every lane before the state is modified
         if (!rp.half) dev::mark_leaves(v, rp.wstart >> sh, (rp.wstart + rp.wlen - 1) >> sh);
-        if (lane == 0) wv::atomic_max_u32(&v.ldirty[index >> sh], v.serial);
+        if (lane == 0) v.ldirty[index >> sh] = v.serial;
         if (lane == 0) {
           v.items[index].value = 0;
           v.items[index].dest = 0;
@@ -907,7 +907,7 @@ PMA_KERNEL void k_rb_tilesums(uint32_t *cnt, uint64_t nleaves, uint32_t tile_lea
   const uint64_t l = b * tile_leaves + wv::thread_idx();
   const bool mine = wv::thread_idx() < tile_leaves && l < nleaves;
   uint32_t s = mine ? cnt[l] : 0u;
-  if (dirty != nullptr && mine) wv::atomic_max_u32(&dirty[l], serial);  // (a window of the live array is about to be rewritten: dirty tags)
+  if (dirty != nullptr && mine) dirty[l] = serial;  // (a window of the live array is about to be rewritten: dirty tags)
   if (copy_out != nullptr && mine) {  // in-place window: park the source counts, clear them for the rebuild
     copy_out[l] = s;
     cnt[l] = 0u;
@@ -1170,7 +1170,7 @@ PMA_KERNEL void k_snap_sync_leaves(Edge *live, uint32_t *live_cnt, Edge *snap, u
   unsigned long long mine = 0;
   for (uint64_t base = ((uint64_t)wv::block_idx() * (wv::block_dim() >> 6) + wv::wave_in_block()) * 64u; base < nleaves; base += wstride * 64u) {
     const uint64_t l = base + (uint64_t)lane;
-    const uint32_t t = l < nleaves ? wv::load_agent_u32(&tag[l]) : 0u;  // (the tags are set by device-wide atomics)
+    const uint32_t t = l < nleaves ? tag[l] : 0u;
     uint64_t m = wv::ballot(l < nleaves && t > synced);
     mine += (unsigned long long)wv::popc64(m);
     while (m) {
@@ -1189,7 +1189,7 @@ PMA_KERNEL void k_snap_sync_leaves(Edge *live, uint32_t *live_cnt, Edge *snap, u
         if (q == 0) {
           if (to_live) {
             live_cnt[myleaf] = snap_cnt[myleaf];
-            wv::store_agent_u32(&tag[myleaf], newtag);  // (the tags are only ever touched by device-wide atomics / coherent stores)
+            tag[myleaf] = newtag;
           } else {
             snap_cnt[myleaf] = live_cnt[myleaf];
           }
@@ -1202,26 +1202,19 @@ PMA_KERNEL void k_snap_sync_leaves(Edge *live, uint32_t *live_cnt, Edge *snap, u
 PMA_KERNEL void k_snap_sync_nodes(Node *live, Node *snap, uint32_t *tag, uint64_t n, uint32_t synced, uint32_t newtag, uint32_t to_live) {
   const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
   for (uint64_t u = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); u < n; u += stride) {
-    if (wv::load_agent_u32(&tag[u]) > synced) {
+    if (tag[u] > synced) {
       if (to_live) {
-        const Node x = snap[u];  // (coherent stores, word by word: see wv::store_agent_u32)
-        wv::store_agent_u32(&live[u].beginning, x.beginning);
-        wv::store_agent_u32(&live[u].end, x.end);
-        wv::store_agent_u32(&live[u].num_neighbors, x.num_neighbors);
-        wv::store_agent_u32(&tag[u], newtag);
+        live[u] = snap[u];
+        tag[u] = newtag;
       } else {
-        // (num_neighbors is only ever changed by device-wide atomics, which are carried out at the memory side: a copy of
-        // the line that this XCD's L2 picked up earlier does not follow them)
-        Node x = live[u];
-        x.num_neighbors = wv::load_agent_u32(&live[u].num_neighbors);
-        snap[u] = x;
+        snap[u] = live[u];
       }
     }
   }
 }
-PMA_KERNEL void k_fill_u32(uint32_t *p, uint64_t n, uint32_t value) {  // (dirty tags of a window: coherent stores, like every other writer of the tags)
+PMA_KERNEL void k_fill_u32(uint32_t *p, uint64_t n, uint32_t value) {
   const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
-  for (uint64_t i = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); i < n; i += stride) wv::store_agent_u32(&p[i], value);
+  for (uint64_t i = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); i < n; i += stride) p[i] = value;
 }
 
 PMA_KERNEL void k_copy_slots(const Edge *src, Edge *dst, uint64_t len) {
@@ -1792,6 +1785,8 @@ struct OptCtl {
   // beyond the register copy, 5 footprint leaves the region, 6 window for a workgroup, 7 stamps, 8 region under a queued big window,
   // 9 heads, 10 chain steps
   uint32_t bk_round;  // the round whose bucket offsets OptArgs::bk_base holds (0: none)
+  uint32_t nown[2][8];  // buckets with something to chain this round (OptArgs::owners: 8 sub-lists, so that the appends do not
+                        // all hit one counter), by round parity
   unsigned long long chain_why[12];
   unsigned long long chain_stop[8];  // (diag) which stop index: 1 exclusive, 2 global soft barrier, 3 foreign update (xmin), 4 list overflow, 5 zone
   uint32_t njobs[2];  // big-window rebalances queued by this round's o_apply (by round parity; the next round's entry is reset by o_compact)
@@ -1836,12 +1831,16 @@ struct OptArgs {
   uint32_t *bk_list;           // horizon slots, bucket after bucket
   uint32_t *bk_pos;            // per horizon slot: arrival number in its bucket (kMax: not listed)
   uint32_t *bk_reg;            // per horizon slot: region of the target slot
+  uint32_t *owners;            // 8 sub-lists of owners_cap entries: a horizon slot of every bucket that has something to chain
+  uint32_t owners_cap;
+  uint32_t *bk_flag;           // [kChainBuckets] the round in which the bucket entered the work list
   unsigned long long *xmin;    // per region: keyed min stream index of a PENDING update that touches the region but lives elsewhere
   // diag >= 2: per update of the batch {rounds it failed in, code of the last failure, stream index of what blocked it,
   // planned window}: the dependency chains of an epoch can be followed afterwards (tools/diag_chains.py)
   uint32_t *dg;
 };
 constexpr uint32_t kChainBuckets = 1u << 15;
+constexpr uint32_t kChainRegionSlots = 1024;  // chain regions are at most this many slots (12 KB of LDS)
 constexpr uint32_t kChainList = 256;  // a wave sorts this many listed updates of one bucket in its LDS tile; longer lists run without a chain
 PMA_DEV uint32_t chain_bucket(uint32_t region) { return (region * 0x9E3779B1u) >> 17; }
 constexpr uint32_t kBigJobs = 256;  // capacity of the round's job queue
@@ -2001,6 +2000,22 @@ PMA_DEV void mark_foreign_regions(const OptArgs &a, const PlanHead &h, const Pla
   if (lane == 1 && (h.sdep & 2u) && (h.sleaf_e >> a.chshift) != mine) wv::atomic_min_u64(&a.xmin[h.sleaf_e >> a.chshift], key);
 }
 
+// o_check's part of the chain lists: the update's horizon slot goes to its place in the bucket's list, and the first update
+// of a bucket that FAILS its check enters the bucket in the round's work list (a bucket whose updates all pass has nothing
+// left to chain)
+PMA_DEV void chain_list_entry(const OptArgs &a, OptCtl *c, uint32_t par, uint32_t wid, bool passed) {
+  if (c->bk_round != a.round) return;
+  const uint32_t pos = a.bk_pos[wid];
+  if (pos == kMax) return;
+  const uint32_t b = chain_bucket(a.bk_reg[wid]);
+  a.bk_list[a.bk_base[b] + pos] = wid;
+  if (!passed && wv::atomic_exch_u32(&a.bk_flag[b], a.round) != a.round) {
+    const uint32_t sub = wid & 7u;
+    const uint32_t at = wv::atomic_add_u32(&c->nown[par][sub], 1u);
+    if (at < a.owners_cap) a.owners[(uint64_t)sub * a.owners_cap + at] = wid;
+  }
+}
+
 PMA_KERNEL void o_check(OptArgs a) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
@@ -2034,10 +2049,7 @@ PMA_KERNEL void o_check(OptArgs a) {
       r[3] = h.wlen;
     }
     if (lane == 0) a.status[wid] = 0u;
-    if (a.chain && lane == 0 && c->bk_round == a.round) {
-      const uint32_t pos = a.bk_pos[wid];
-      if (pos != kMax) a.bk_list[a.bk_base[chain_bucket(a.bk_reg[wid])] + pos] = wid;
-    }
+    if (a.chain && lane == 0) chain_list_entry(a, c, par, wid, false);
     return;
   }
 #define PMA_WHY(code) do { if (a.diag && (code) < why) why = (code); } while (0)
@@ -2188,10 +2200,7 @@ PMA_KERNEL void o_check(OptArgs a) {
     }
   }
   if (lane == 0) a.status[wid] = (anyfail ? 0u : OS_PASS) | (anybad ? OS_STAMP_BAD : 0u);
-  if (a.chain && lane == 0 && c->bk_round == a.round) {  // into its place of the bucket's list
-    const uint32_t pos = a.bk_pos[wid];
-    if (pos != kMax) a.bk_list[a.bk_base[chain_bucket(a.bk_reg[wid])] + pos] = wid;
-  }
+  if (a.chain && lane == 0) chain_list_entry(a, c, par, wid, !anyfail);
 }
 
 PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
@@ -2368,28 +2377,35 @@ PMA_DEV_CALL void chain_apply(const View *v, const Op *op, const Plan *plan, uin
 //     regions it touches but does not live in), none is exclusive / a barrier;
 //   * no LATER update has already been committed on what it reads or writes (stamps, as everywhere).
 // The first update that fails any of this ends the chain and stays pending, with everything behind it.
-PMA_KERNEL void o_chain(OptArgs a) {
-  PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
-  PMA_SHARED uint32_t chain_lds[4][kChainList];
+PMA_KERNEL void PMA_LAUNCH_BOUNDS(64, 1) o_chain(OptArgs a) {  // (launched with ONE wave per workgroup: all the registers a wave can have)
+  PMA_SHARED uint32_t lds[1][3 * kLdsWindow];
+  PMA_SHARED uint32_t chain_lds[1][kChainList];
+  // the region being chained, staged in LDS: every chained update searches, slides and rebalances THERE (a step is a handful of
+  // dependent accesses: in HBM / L2 that is ~4 us per update, and the updates of one region are sequential by definition)
+  PMA_SHARED Edge reg_items[kChainRegionSlots];
+  PMA_SHARED uint32_t reg_cnt[kChainRegionSlots / 2];
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
-  const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
+  const uint32_t gw = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();  // this wave among the grid's
+  const uint32_t gwaves = wv::grid_dim() * (wv::block_dim() >> 6);
   const int lane = wv::lane();
   const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
-  const uint32_t hor = c->hor[par];
   const unsigned long long gbar = c->gbar[par], sbar = c->sbar[par];
   const uint32_t nz = c->nzones[par];
+  const uint32_t sub = gw & 7u;
+  uint32_t nown = c->nown[par][sub];
+  if (nown > a.owners_cap) nown = a.owners_cap;
   if (!a.chain || f_done || f_viol || f_excl || f_err) return;
-  if (wid >= hor || c->bk_round != a.round) return;
+  if (c->bk_round != a.round) return;
   const int sh = a.v.g.sh;
-  // the wave of the bucket's FIRST arrival owns the bucket for this launch (the lists do not change while the chains run)
-  if (a.bk_pos[wid] != 0u) return;
+  // the round's work list: one entry per bucket that has something to chain; the waves of the (small, fixed) grid share it
+  for (uint32_t own = gw >> 3; own < nown; own += (gwaves >> 3)) {
+  const uint32_t wid = a.owners[(uint64_t)sub * a.owners_cap + own];
   const uint32_t bucket = chain_bucket(a.bk_reg[wid]);
   const uint32_t n_l = (uint32_t)a.bk_cnt[bucket], l_base = a.bk_base[bucket];
-  if (n_l < 2u && (a.status[wid] & OS_COMMITTED)) return;  // (alone and done: nothing to chain)
-  if (n_l > kChainList) return;                            // (longer than the LDS tile: this bucket runs without a chain)
+  if (n_l > kChainList) continue;  // (longer than the LDS tile: this bucket runs without a chain)
   // the list, sorted by horizon slot (= stream order) in this wave's LDS tile
-  uint32_t *ll = chain_lds[wv::wave_in_block()];
+  uint32_t *ll = chain_lds[0];
   uint32_t n2 = 64;
   while (n2 < n_l) n2 <<= 1;
   for (uint32_t i = (uint32_t)lane; i < n2; i += 64u) ll[i] = i < n_l ? a.bk_list[l_base + i] : kMax;
@@ -2422,8 +2438,9 @@ PMA_KERNEL void o_chain(OptArgs a) {
   if (a.diag && lane == 0) wv::atomic_add_u64(&c->chain_why[9], 1ull);
   StatShard *sts = &a.stats[wv::block_idx() & (kStatShards - 1)];
   uint32_t steps = 0;
-  uint32_t cur_region = kMax, dead_a = kMax, dead_b = kMax, rlo = 0, rhi = 0, stop = kMax, stop_why = 0;
-  bool all_dead = false;
+  uint32_t cur_region = kMax, dead_a = kMax, dead_b = kMax, rlo = 0, rhi = 0, rslots = 0, stop = kMax, stop_why = 0;
+  bool all_dead = false, staged = false;
+  View lv = a.v;
   for (uint32_t i = 0; i < n_l && !all_dead; i++) {
     const uint32_t w = ll[i];  // (horizon slot; ascending = stream order)
     const uint32_t region = a.bk_reg[w];
@@ -2435,9 +2452,17 @@ PMA_KERNEL void o_chain(OptArgs a) {
       break;
     }
     if (region != cur_region) {  // (a bucket holds ONE region unless two regions hash alike)
+      if (staged) {  // the region worked on so far goes back to the array
+        for (uint32_t q = (uint32_t)lane; q < rslots; q += 64u) a.v.items[(uint64_t)(rlo << sh) + q] = reg_items[q];
+        for (uint32_t q = (uint32_t)lane; q <= rhi - rlo; q += 64u) a.v.leafcnt[rlo + q] = reg_cnt[q];
+        staged = false;
+        wv::fence();
+      }
       cur_region = region;
       rlo = region << a.chshift;  // first / last leaf of the region
       rhi = (rlo + (1u << a.chshift) - 1u < nleaves_all) ? rlo + (1u << a.chshift) - 1u : nleaves_all - 1u;
+      rslots = (rhi - rlo + 1u) << sh;
+      if (rhi + 1u >= nleaves_all || rslots > kChainRegionSlots) PMA_CHAIN_END(5)  // (the array's last region: slot N-1 has rules of its own)
       // stream index below which nothing foreign is pending: an exclusive update, a global barrier, a soft-barrier zone that
       // overlaps the region, an earlier update from elsewhere reaching into this region
       stop = kMax;
@@ -2471,12 +2496,23 @@ PMA_KERNEL void o_chain(OptArgs a) {
       if (a.diag && lane == 0) wv::atomic_add_u64(&c->chain_stop[stop_why], 1ull);
       PMA_CHAIN_END(1)
     }
+    if (!staged) {  // stage the region (the first update of the region that gets this far pays for it)
+      for (uint32_t q = (uint32_t)lane; q < rslots; q += 64u) reg_items[q] = a.v.items[(uint64_t)(rlo << sh) + q];
+      for (uint32_t q = (uint32_t)lane; q <= rhi - rlo; q += 64u) reg_cnt[q] = a.v.leafcnt[rlo + q];
+      wv::lds_fence();
+      lv = a.v;
+      lv.items = wv::opaque_ptr((Edge *)reg_items) - (uint64_t)(rlo << sh);  // (absolute slot / leaf numbers index the staged copy)
+      lv.leafcnt = wv::opaque_ptr((uint32_t *)reg_cnt) - (uint64_t)rlo;
+      lv.gap_end = (uint64_t)((rhi + 1u) << sh);
+      if (lv.big_window > rslots) lv.big_window = rslots;  // (no climb may look at a sibling block outside the region)
+      staged = true;
+    }
     {
     const Op op = a.ops[nxt];
     Plan *pl = &a.plans[w];
     // against the state as it is NOW, and from this region's slots alone (no other region is read while its owner writes it)
     dev::PlanRegs pr;
-    chain_plan(&a.v, &op, pl, rlo << sh, ((rhi + 1u) << sh) - 1u, &pr);
+    chain_plan(&lv, &op, pl, rlo << sh, ((rhi + 1u) << sh) - 1u, &pr);
     const uint32_t kind = pr.kind;
     if (kind == K_FOREIGN) PMA_CHAIN_END(5)
     if (!kind_real(kind) || kind == K_EXCL) PMA_CHAIN_END(3)
@@ -2514,7 +2550,7 @@ PMA_KERNEL void o_chain(OptArgs a) {
       fprintf(stderr, "R%u chain idx=%u op=(%u,%u,%u) kind=%u index=%u win=(%u,%u) wleaf=[%u,%u] nr=%u\n", a.round, nxt, op.src, op.dst, op.op, kind,
               pr.index, pr.wstart, pr.wlen, pr.wleaf_lo, pr.wleaf_hi, pr.nr);
 #endif
-    chain_apply(&a.v, &op, pl, lds[wv::wave_in_block()], sts);
+    chain_apply(&lv, &op, pl, lds[0], sts);
     if (strong) {
       for (uint32_t leaf = pr.wleaf_lo + (uint32_t)lane; leaf <= pr.wleaf_hi; leaf += 64) wv::atomic_max_u32(&a.wstamp[leaf], me1);
       for (uint64_t u = (uint64_t)pr.mv_lo + (uint64_t)lane; u <= (uint64_t)pr.mv_hi && pr.mv_lo <= pr.mv_hi; u += 64) wv::atomic_max_u32(&a.vws[u], me1);
@@ -2533,6 +2569,12 @@ PMA_KERNEL void o_chain(OptArgs a) {
   next_entry:;
   }
 #undef PMA_CHAIN_END
+  if (staged) {
+    for (uint32_t q = (uint32_t)lane; q < rslots; q += 64u) a.v.items[(uint64_t)(rlo << sh) + q] = reg_items[q];
+    for (uint32_t q = (uint32_t)lane; q <= rhi - rlo; q += 64u) a.v.leafcnt[rlo + q] = reg_cnt[q];
+  }
+  wv::fence();  // (the list tile and the staged region are reused by this wave's next bucket)
+  }
 }
 
 // stable compaction of the deferred updates into the next carry list + next round's bookkeeping
@@ -2684,6 +2726,7 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
     c->sbar[par] = ~0ull;
     c->nzones[par ^ 1u] = 0u;
     c->nzones[par] = 0u;
+    for (int q = 0; q < 8; q++) c->nown[par ^ 1u][q] = c->nown[par][q] = 0u;
     c->njobs[par ^ 1u] = 0;
     c->skip = kMax;
     const bool done = (new_cn == 0 && new_nf == e1);

@@ -9,7 +9,11 @@
 #else
 #include <hip/hip_runtime.h>
 #define PMA_DEV __device__ __forceinline__
+#if defined(PPCSR_CHAIN_INLINE)
+#define PMA_DEV_CALL __device__ __forceinline__
+#else
 #define PMA_DEV_CALL __device__ __noinline__
+#endif
 #define PMA_KERNEL __global__
 #define PMA_LAUNCH_BOUNDS(threads, waves_per_simd) __launch_bounds__(threads, waves_per_simd)
 #define PMA_SHARED __shared__
@@ -36,6 +40,15 @@ PMA_DEV void block_sync() { __syncthreads(); }
 PMA_DEV uint32_t atomic_min_u32(uint32_t *p, uint32_t v) { return atomicMin(p, v); }
 PMA_DEV unsigned long long atomic_min_u64(unsigned long long *p, unsigned long long v) { return atomicMin(p, v); }
 PMA_DEV uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+// num_neighbors: the one word of nodes[] that device-wide atomics change
+PMA_DEV void atomic_add_nn(uint32_t *p, uint32_t v) {
+#if defined(PPCSR_NN_RETURNING)
+  const uint32_t old = atomicAdd(p, v);
+  asm volatile("" ::"v"(old));  // (the returning form of the instruction)
+#else
+  (void)atomicAdd(p, v);
+#endif
+}
 PMA_DEV unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 PMA_DEV uint32_t atomic_max_u32(uint32_t *p, uint32_t v) { return atomicMax(p, v); }
 PMA_DEV unsigned long long atomic_max_u64(unsigned long long *p, unsigned long long v) { return atomicMax(p, v); }
@@ -62,6 +75,14 @@ PMA_DEV void fence_mode(uint32_t mode) {  // (experiment: which part of fence_he
   if (mode & 32u) for (int i = 0; i < 40; i++) __builtin_amdgcn_s_sleep(127);  // (a pure delay of a few microseconds)
   if (mode & 64u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (mode & 128u) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+}
+// hides where a pointer came from: a pointer to LDS that is about to be biased (so that absolute slot numbers index a staged
+// copy) must stay a 64-bit generic pointer — if the compiler keeps it as a 32-bit LDS offset, the biased value wraps and its
+// conversion back to a generic address lands outside every aperture
+template <class T>
+PMA_DEV T *opaque_ptr(T *p) {
+  asm volatile("" : "+v"(p));
+  return p;
 }
 // every global load this wave has issued has returned (a workgroup barrier alone does not wait for vmcnt)
 PMA_DEV void wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

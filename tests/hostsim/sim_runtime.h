@@ -55,11 +55,14 @@ inline void block_sync() { sim::block_sync(); }
 inline uint32_t atomic_min_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v < o) *p = v; return o; }
 inline unsigned long long atomic_min_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
 inline uint32_t atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+inline void atomic_add_nn(uint32_t *p, uint32_t v) { *p += v; }
 inline unsigned long long atomic_add_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline uint32_t atomic_max_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 inline unsigned long long atomic_max_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomic_exch_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
 inline uint32_t atomic_cas_u32(uint32_t *p, uint32_t expect, uint32_t v) { uint32_t o = *p; if (o == expect) *p = v; return o; }
+template <class T>
+inline T *opaque_ptr(T *p) { return p; }
 inline void wait_loads() {}
 inline void fence_heavy() { (void)sim::shfl64(0, 0); }
 inline void fence_mode(uint32_t) { (void)sim::shfl64(0, 0); }

@@ -24,6 +24,9 @@ MODES = {
     "speculative": dict(mode=1, small_batch=0),  # (small_batch=0: even tiny batches go through the speculative rounds)
     "speculative-small": dict(mode=1, opt_horizon=1024, epoch_ops=4096, region_slots=256, small_batch=0),
     "default": dict(),  # engine defaults: speculative rounds, batches of <= 256 updates through the strict rounds
+    # round 3: in-round chains forced on (a region's waiting updates executed by one wave from an LDS copy of the region) and
+    # soft barriers with an extent (zones); both are off by default
+    "chains+zones": dict(mode=1, small_batch=0, chain=2, chain_steps=16, zone_factor=8, epoch_ops=8192),
 }
 
 
@@ -104,6 +107,66 @@ def test_random_mixed_vs_oracle(mk, streams, seed, n, lock):
         o.apply(ops[lo:lo + 25000])
         _same(eng, o, f"seed {seed} after {lo + 25000}")
     _stats_match(eng, o)
+
+
+@pytest.mark.parametrize("steps", [2, 16, 64])
+def test_chains_hot_vertices_and_rmat_load(pkg, streams, steps):
+    """in-round chains (option chain=2): hub streams whose updates pile up on a few regions, and an RMAT load from an empty
+    graph (doublings, rollbacks); num_neighbors is compared too — it is the one word only atomics touch, and the one a
+    miscompiled o_chain got wrong while edges[] stayed right"""
+    for n, K, hubs in [(1000, 3000, 4), (64, 2500, 3), (20000, 30000, 50)]:
+        rng = np.random.default_rng(n + K)
+        src = np.where(rng.random(K) < 0.7, rng.integers(0, hubs, K), rng.integers(0, n, K)).astype(np.uint32)
+        ops = np.stack([src, rng.integers(0, 5000, K).astype(np.uint32), (rng.random(K) >= 0.1).astype(np.uint32)], 1).astype(np.uint32)
+        e, o = pkg.PCSR(n), Oracle(n)
+        for k, v in dict(chain=2, chain_steps=steps, small_batch=0).items():
+            e.set_option(k, v)
+        e.apply(ops)
+        o.apply(ops)
+        _same(e, o, f"hub stream n={n} steps={steps}")
+        assert e.stats()["chained"] > 0
+        _stats_match(e, o)
+    s, d = streams.rmat_edges(14, 60000, seed=1)
+    core = streams.adds(s, d)
+    e, o = pkg.PCSR(1 << 14), Oracle(1 << 14)
+    for k, v in dict(chain=2, chain_steps=steps).items():
+        e.set_option(k, v)
+    for lo in range(0, len(core), 20000):
+        e.apply(core[lo:lo + 20000])
+        o.apply(core[lo:lo + 20000])
+        _same(e, o, f"rmat-14 load, chunk {lo}, steps={steps}")
+    assert e.stats()["chained"] > 1000 and e.stats()["rollbacks"] > 0
+
+
+@pytest.mark.parametrize("chain", [0, 2])
+def test_snapshot_restore_incremental(pkg, streams, chain):
+    """snapshot() / restore() and the epoch rollback point are kept in step with the live state through dirty tags (only
+    what was written since is copied): restore after batches with rollbacks and doublings, then continue"""
+    for seed in range(3):
+        rng = np.random.default_rng(seed)
+        n = int(rng.choice([40, 300, 5000]))
+        core = streams.random_stream(n, 4000, seed=seed + 100, p_delete=0.1)
+        m = 6000
+        src = np.where(rng.random(m) < 0.5, rng.integers(0, 4, m), rng.integers(0, n, m)).astype(np.uint32)
+        upd = np.stack([src, rng.integers(0, 100000, m).astype(np.uint32), (rng.random(m) >= 0.1).astype(np.uint32)], 1).astype(np.uint32)
+        upd2 = streams.random_stream(n, 1500, seed=seed + 7, p_delete=0.5)
+        e, o = pkg.PCSR(n), Oracle(n)
+        for k, v in dict(chain=chain, small_batch=0, epoch_ops=1024, opt_horizon=1024, region_slots=256).items():
+            e.set_option(k, v)
+        e.apply(core)
+        o.apply(core)
+        e.snapshot()
+        g0 = e.geometry()
+        for rep in range(3):
+            e.restore()
+            assert e.geometry() == g0
+            _same(e, o, f"seed {seed} rep {rep}: after restore")
+            which = upd if rep != 1 else upd2
+            e.apply(which)
+            o2 = o.clone()
+            o2.apply(which)
+            _same(e, o2, f"seed {seed} rep {rep}: after the batch")
+            o2.close()
 
 
 def test_horizon_options_changed_between_batches(pkg, streams):

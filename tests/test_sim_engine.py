@@ -147,6 +147,53 @@ def test_sim_soft_barrier_with_ignored_adds(sim, soft):
         assert se["exclusive_ops"] == e2.stats()["exclusive_ops"]
 
 
+@pytest.mark.parametrize("seed", [0, 5, 9, 14])
+def test_sim_in_round_chains(sim, seed):
+    """in-round chains (o_chain, option chain=2): hot-vertex mixes with deletes; every chunk bit-exact incl. num_neighbors"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([30, 200, 1000]))
+    m = int(rng.choice([3000, 6000]))
+    src = np.where(rng.random(m) < 0.6, rng.integers(0, min(n, 8), m), rng.integers(0, n, m)).astype(np.uint32)
+    ops = np.stack([src, rng.integers(0, 5000, m).astype(np.uint32), (rng.random(m) >= 0.2).astype(np.uint32)], 1).astype(np.uint32)
+    opts = dict(chain_steps=int(rng.choice([1, 3, 8, 16])), region_slots=int(rng.choice([64, 128, 256])), opt_horizon=int(rng.choice([64, 256])),
+                zone_factor=int(rng.choice([0, 2, 8])), soft_barrier=int(rng.choice([0, 128, 512])), epoch_ops=int(rng.choice([512, 4096])))
+    e = sim(n, True, mode=1, opt_horizon=opts["opt_horizon"], epoch_ops=opts["epoch_ops"], region_slots=opts["region_slots"])
+    for k in ("chain_steps", "zone_factor", "soft_barrier"):
+        e.set_option(k, opts[k])
+    e.set_option("chain", 2)
+    o = Oracle(n)
+    for lo in range(0, m, 2000):
+        e.apply(ops[lo:lo + 2000])
+        o.apply(ops[lo:lo + 2000])
+        _same(e, o, f"seed {seed} {opts} after {lo + 2000}")
+    assert e.stats()["chained"] > 0
+
+
+def test_sim_snapshot_restore_incremental(sim, streams):
+    """snapshot() / restore() through dirty tags across batches with rollbacks and doublings (see the GPU test of the same name)"""
+    n = 40
+    core = streams.random_stream(n, 1500, seed=100, p_delete=0.1)
+    rng = np.random.default_rng(0)
+    m = 2500
+    src = np.where(rng.random(m) < 0.5, rng.integers(0, 4, m), rng.integers(0, n, m)).astype(np.uint32)
+    upd = np.stack([src, rng.integers(0, 100000, m).astype(np.uint32), (rng.random(m) >= 0.1).astype(np.uint32)], 1).astype(np.uint32)
+    upd2 = streams.random_stream(n, 1500, seed=7, p_delete=0.5)
+    e, o = sim(n, True, mode=1, opt_horizon=256, epoch_ops=1024, region_slots=64), Oracle(n)
+    e.apply(core)
+    o.apply(core)
+    e.snapshot()
+    for rep in range(3):
+        e.restore()
+        _same(e, o, f"rep {rep}: after restore")
+        which = upd if rep != 1 else upd2
+        e.apply(which)
+        o2 = o.clone()
+        o2.apply(which)
+        _same(e, o2, f"rep {rep}: after the batch")
+        o2.close()
+    assert e.stats()["rollbacks"] > 0 and e.stats()["double_calls"] > 0
+
+
 def test_sim_speculative_stats_survive_rollback(sim, streams):
     ops = streams.random_stream(1000, 12000, seed=5, p_delete=0.2)
     e, o = sim(1000, mode=1, opt_horizon=256, epoch_ops=2048, region_slots=32), Oracle(1000)
