@@ -80,6 +80,49 @@ def consumers_case():
     r.close()
 
 
+def pppcsr_case():
+    # (8) PPPCSR P = 8 on n = 1000: per-partition state after the partition's subsequence
+    L = ref_lib()
+    ops = streams.random_stream(1000, 30000, seed=29, p_delete=0.2)
+    hp = L.refp_create(1000, 1000, 1, 1, 8)
+    part = np.array([L.refp_get_partition(hp, int(v)) for v in range(1000)], np.int64)
+    L.refp_destroy(hp)
+    starts = np.array([np.nonzero(part == k)[0][0] for k in range(8)], np.int64)
+    sizes = np.array([(part == k).sum() for k in range(8)], np.int64)
+    digs, part_nodes = [], []
+    for k in range(8):
+        sub = ops[part[ops[:, 0]] == k].copy()
+        sub[:, 0] -= np.uint32(starts[k])
+        r = RefPCSR(int(sizes[k]))
+        r.apply(sub)
+        items, nodes = r.state()
+        digs.append(digest(items, nodes, r.geometry()))
+        part_nodes.append(np.asarray(nodes, np.uint32).reshape(-1, 3))
+        r.close()
+    # the same stream through the reference's own forwarding (PPPCSR::add_edge / remove_edge, PPPCSR.cpp:46-52): `partitions`
+    # is private there, so the state is read back through the public surface — getNode (partition-local beginning / end /
+    # num_neighbors of every vertex, which pins every sentinel position) and get_neighbourhood (which pins every edge)
+    hp = L.refp_create(1000, 1000, 1, 1, 8)
+    buf = np.ascontiguousarray(ops, np.uint32)
+    L.refp_apply(hp, buf.ctypes.data, len(buf))
+    fwd_nodes = np.zeros((1000, 3), np.uint32)
+    adj, ptr = [], [0]
+    tmp = np.zeros(4096, np.int32)
+    for v in range(1000):
+        L.refp_get_node(hp, v, fwd_nodes[v].ctypes.data)
+        m = L.refp_get_neighbourhood(hp, v, tmp.ctypes.data, len(tmp))
+        assert m <= len(tmp)
+        adj.append(tmp[:m].copy())
+        ptr.append(ptr[-1] + int(m))
+    assert L.refp_get_n(hp) == 1000
+    L.refp_destroy(hp)
+    np.testing.assert_array_equal(fwd_nodes, np.concatenate(part_nodes))  # forwarding == per-partition subsequences
+    np.savez_compressed(os.path.join(HERE, "pppcsr_p8_n1000.npz"), n=np.int64(1000), ops=ops, part_of_vertex=part,
+                        starts=starts, sizes=sizes, digests=np.array(digs), fwd_nodes=fwd_nodes,
+                        fwd_adj_ptr=np.array(ptr, np.int64), fwd_adj=np.concatenate(adj).astype(np.int32))
+    print("pppcsr_p8_n1000: partitions", sizes.tolist())
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "consumers":  # only the consumer fixture (the others are unchanged)
         consumers_case()
@@ -119,27 +162,11 @@ def main():
             r.add_node()
     ops = streams.random_stream(5, 300, seed=23, p_delete=0.2)
     run_case("add_node_empty_then_edges", 0, ops, pre=pre, checkpoints=3)
-    # (8) PPPCSR P = 8 on n = 1000: per-partition state after the partition's subsequence
-    L = ref_lib()
-    ops = streams.random_stream(1000, 30000, seed=29, p_delete=0.2)
-    hp = L.refp_create(1000, 1000, 1, 1, 8)
-    part = np.array([L.refp_get_partition(hp, int(v)) for v in range(1000)], np.int64)
-    L.refp_destroy(hp)
-    starts = np.array([np.nonzero(part == k)[0][0] for k in range(8)], np.int64)
-    sizes = np.array([(part == k).sum() for k in range(8)], np.int64)
-    digs = []
-    for k in range(8):
-        sub = ops[part[ops[:, 0]] == k].copy()
-        sub[:, 0] -= np.uint32(starts[k])
-        r = RefPCSR(int(sizes[k]))
-        r.apply(sub)
-        items, nodes = r.state()
-        digs.append(digest(items, nodes, r.geometry()))
-        r.close()
-    np.savez_compressed(os.path.join(HERE, "pppcsr_p8_n1000.npz"), n=np.int64(1000), ops=ops, part_of_vertex=part,
-                        starts=starts, sizes=sizes, digests=np.array(digs))
-    print("pppcsr_p8_n1000: partitions", sizes.tolist())
+    pppcsr_case()
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["pppcsr"]:  # only case 8 (the other archives stay byte-identical)
+        pppcsr_case()
+    else:
+        main()

@@ -93,6 +93,12 @@ def test_pppcsr_golden(pkg):
         items, nodes = p.state()
         assert digest(items, nodes, p.geometry()) == str(g["digests"][k]), f"partition {k}"
     assert pp.get_n() == 1000
+    # the state the reference's forwarding calls (PPPCSR.cpp:46-52) produced, through the same public calls here
+    for v in range(1000):
+        np.testing.assert_array_equal(np.asarray(pp.getNode(v), np.uint32), g["fwd_nodes"][v])
+    for v in range(0, 1000, 3):
+        a, b = g["fwd_adj_ptr"][v], g["fwd_adj_ptr"][v + 1]
+        np.testing.assert_array_equal(pp.get_neighbourhood(v), g["fwd_adj"][a:b])
 
 
 @pytest.mark.parametrize("seed,n", [(0, 30), (1, 300), (2, 3000), (3, 20000), (4, 100000)])
