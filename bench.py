@@ -21,6 +21,8 @@ Prints ONE JSON line on rank 0 (DESIGN.md section 6 defines the fields).  Unless
 engines is compared slot by slot with the reference / oracle after the timed region (`parity_checked`).
 """
 import argparse
+import glob
+import hashlib
 import importlib.util
 import json
 import os
@@ -47,6 +49,17 @@ def _load(name, path, pkg=False):
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 T_BENCH0 = time.time()
+
+
+def csrc_sha256():
+    """identity of the kernel sources a PMC record belongs to (the GPU box has no .git): sha256 over csrc/'s sources"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "parallel-packed-csr_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".cc", ".hip", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def log(rank, *a):
@@ -326,18 +339,26 @@ def main():
             avg_ms = kern[dom] / max(launches, 1)
             achieved = (alg_bytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02_roofline.json")
-            if cfg == 2 and N == 1 and os.path.exists(tpath):
+            if cfg == 2 and N == 1:
                 # HBM bytes per launch of the timed rounds, from the committed rocprofv3 --pmc passes of THIS command
-                # (tools/roofline_profile.sh); tagged with the commit it was measured at
-                try:
-                    pj = json.load(open(tpath))
-                    traffic = pj["timed_rounds"][names[dom]]["hbm_bytes_per_launch"]
-                    tsrc = {"file": "profiles/r02_roofline.json", "commit": pj.get("commit"), "command": pj.get("command")}
-                except Exception:
-                    traffic = None
+                # (tools/roofline_profile.sh).  Only a record taken on exactly these kernel sources counts: the record
+                # carries the sha256 of csrc/ it was measured on; anything else reports null and says which record is stale.
+                here = csrc_sha256()
+                for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline.json")), reverse=True):
+                    try:
+                        pj = json.load(open(tpath))
+                        rel = os.path.relpath(tpath, ROOT)
+                        if pj.get("csrc_sha256") == here:
+                            traffic = pj["timed_rounds"][names[dom]]["hbm_bytes_per_launch"]
+                            tsrc = {"file": rel, "commit": pj.get("commit"), "csrc_sha256": here, "command": pj.get("command")}
+                            break
+                        tsrc = tsrc or {"stale": rel, "reason": "record was measured on other kernel sources",
+                                        "record_csrc_sha256": pj.get("csrc_sha256"), "csrc_sha256": here}
+                    except Exception:
+                        continue
             res["roofline"] = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                               "csrc_sha256": csrc_sha256(),
                                "launches": int(launches), "avg_launch_us": avg_ms * 1e3,
                                "alg_bytes_per_launch": alg_bytes / max(launches, 1),
                                "alg_bytes_per_update": alg_bytes / max(d["ops_applied"], 1),

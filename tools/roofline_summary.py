@@ -119,7 +119,8 @@ def main():
         commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
     except Exception:
         pass
-    out = OrderedDict([("command", cmd), ("commit", commit or os.environ.get("PPCSR_COMMIT")), ("workload", bj["config"]["workload"]),
+    out = OrderedDict([("command", cmd), ("commit", commit or os.environ.get("PPCSR_COMMIT")),
+                       ("csrc_sha256", (bj.get("roofline") or {}).get("csrc_sha256")), ("workload", bj["config"]["workload"]),
                        ("units", "durations from the --kernel-trace pass; FETCH_SIZE (x2, gfx950) and WRITE_SIZE from separate --pmc passes, KiB -> bytes"),
                        ("derived", derived), ("sections", res)])
     # bench.py reads timed_rounds[kernel].hbm_bytes_per_launch
