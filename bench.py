@@ -144,9 +144,11 @@ def main():
     ap.add_argument("--mode", type=int, default=-1, help="0 strict prefix rounds, 1 speculative rounds (engine default)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     ap.add_argument("--markers", action="store_true", help="launch marker kernels around the timed region / isolated kernels (tools/roofline_profile.sh)")
-    ap.add_argument("--exchange", choices=["torch", "native"], default="torch",
-                    help="carrier of the owner exchange for N > 1: torch.distributed all_to_all_single (RCCL inside PyTorch; default) or "
-                         "the engine library's own RCCL send/recv (pppcsr_exchange_apply; no torch in the data path)")
+    ap.add_argument("--exchange", choices=["auto", "torch", "native"], default="auto",
+                    help="carrier of the owner exchange for N > 1: the engine library's own RCCL send/recv (pppcsr_exchange_apply; no torch "
+                         "in the data path; default) or torch.distributed all_to_all_single (RCCL inside PyTorch).  auto = native after a "
+                         "preflight that runs small ragged blocks through BOTH carriers and compares the partitions bit for bit; if the "
+                         "native carrier errs or disagrees, the run says so and continues on the torch carrier")
     ap.add_argument("--backend", default="nccl", help="process-group backend; 'gloo' only for functional tests of the N > 1 path on one GPU")
     args = ap.parse_args()
 
@@ -204,6 +206,67 @@ def main():
     def to_dev(a):
         return torch.from_numpy(a.view(np.int32)).to(xdev if N > 1 else dev)
 
+    # ---- carrier of the exchange (N > 1) ---------------------------------------------------------------------------
+    carrier = {"use_native": False, "note": None}
+
+    def new_uid():
+        uid = [pkg.PPPCSR.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)  # (bootstrap only: 128 bytes)
+        return uid[0]
+
+    def torch_exchange_apply(pp_, ops_dev, n_, cap=None):
+        parts, cnts = exch.exchange_parts(ops_dev, n_, P, N, dist.group.WORLD, cap=cap)
+        parts = [t.to(dev) for t in parts]
+        torch.cuda.current_stream().synchronize()  # the exchange ran on torch's stream; the engines apply on their own
+        pp_.apply_parts_device(rank * ppr, [t.data_ptr() for t in parts], cnts)
+        return parts
+
+    def preflight_native():
+        """ragged blocks (one of them a single row) through both carriers into two small PPPCSRs; True when every local partition
+        agrees bit for bit on every rank"""
+        n_small = 512 * P
+        ok, why = 1, ""
+        try:
+            a = pkg.PPPCSR(n_small, numDomain=N, partitionsPerDomain=ppr, local=(rank * ppr, ppr, dev_id))
+            b = pkg.PPPCSR(n_small, numDomain=N, partitionsPerDomain=ppr, local=(rank * ppr, ppr, dev_id))
+            a.comm_create(new_uid(), N, rank, dev_id)
+            for k in range(3):
+                m = [4096, 1 if (rank + k) % 2 else 3000, 257][k]
+                blk = streams.random_stream(n_small, m, seed=1000 + 17 * k + rank, p_delete=0.3)
+                t = to_dev(blk)
+                torch.cuda.synchronize()
+                a.exchange_apply(t.data_ptr(), m)
+                keep = torch_exchange_apply(b, t, n_small, cap=4096)
+                del keep
+            for q in range(ppr):
+                ea, eb = a.partition(rank * ppr + q), b.partition(rank * ppr + q)
+                sa, sb = ea.state(), eb.state()
+                if ea.geometry() != eb.geometry() or not (np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])):
+                    ok, why = 0, f"partition {rank * ppr + q} differs between the carriers"
+            a.close()
+            b.close()
+        except Exception as ex:  # noqa: BLE001 — any failure of the native carrier selects the other one
+            ok, why = 0, f"{type(ex).__name__}: {ex}"
+        flag = torch.tensor([ok], dtype=torch.int32, device=xdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item()), why
+
+    if N > 1 and args.exchange != "torch":
+        if args.backend != "nccl":
+            carrier["note"] = "torch carrier: the native exchange needs one GPU per rank (RCCL), this is a gloo functional run"
+            if args.exchange == "native":
+                raise SystemExit("--exchange native needs --backend nccl")
+        elif args.exchange == "native":
+            carrier["use_native"] = True
+        else:
+            good, why = preflight_native()
+            carrier["use_native"] = good
+            if not good:
+                carrier["note"] = "native carrier failed its preflight on some rank, torch carrier used" + (f" (this rank: {why})" if why else "")
+                log(0 if why else rank, "WARNING: " + carrier["note"])
+            else:
+                log(rank, "exchange preflight: native RCCL carrier == torch carrier on every rank, bit for bit")
+
     # ---- engines -------------------------------------------------------------------------------------------------
     def make_engines():
         if single:
@@ -213,10 +276,8 @@ def main():
         else:
             pp = pkg.PPPCSR(n_global, numDomain=N, partitionsPerDomain=ppr, local=(rank * ppr, ppr, dev_id))
             es = [pp.partition(rank * ppr + q) for q in range(ppr)]
-            if N > 1 and args.exchange == "native":
-                uid = [pkg.PPPCSR.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(uid, src=0)  # (bootstrap only: 128 bytes)
-                pp.comm_create(uid[0], N, rank, dev_id)
+            if N > 1 and carrier["use_native"]:
+                pp.comm_create(new_uid(), N, rank, dev_id)
         for e in es:
             if args.mode >= 0:
                 e.set_option("mode", args.mode)
@@ -244,13 +305,10 @@ def main():
         if N == 1:
             pp.apply_device(ops_dev.data_ptr(), ops_dev.shape[0])  # device bucketing + all partitions concurrently
             return
-        if args.exchange == "native":
-            pp.exchange_apply(ops_dev.data_ptr(), ops_dev.shape[0], max(my_core, my_batch))
+        if carrier["use_native"]:
+            pp.exchange_apply(ops_dev.data_ptr(), ops_dev.shape[0])
             return
-        parts, cnts = exch.exchange_parts(ops_dev, n_global, P, N, dist.group.WORLD)
-        parts = [t.to(dev) for t in parts]
-        torch.cuda.current_stream().synchronize()  # the exchange ran on torch's stream; the engines apply on their own
-        pp.apply_parts_device(rank * ppr, [t.data_ptr() for t in parts], cnts)
+        torch_exchange_apply(pp, ops_dev, n_global)
 
     def run_workload(wl_, label, steps, warmup, want_profile):
         """core load (untimed), snapshot, warm-up, timed steps [, profiled replay]; returns a result dict"""
@@ -608,11 +666,12 @@ def main():
             "scaling": scaling, "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": wl.name(P, N), "vertices": n_global, "core_edges": core_edges, "updates_per_step": batch,
                        "parallelism": f"{P} partition(s), {ppr} per GPU x {N} GPU(s)"
-                                      + ("" if N == 1 else (", native RCCL send/recv (pppcsr_exchange_apply)" if args.exchange == "native" else
+                                      + ("" if N == 1 else (", native RCCL send/recv (pppcsr_exchange_apply)" if carrier["use_native"] else
                                                              f", {'RCCL' if args.backend == 'nccl' else args.backend} all-to-all (torch.distributed)")),
                        "N_slots": headline["N_slots"], "logN": headline["logN"],
                        "distinct_update_batches": max(1, min(args.distinct_batches, args.warmup + args.steps)),
-                       "semantics": "sequential stream order (bit-exact vs reference -threads=1)"},
+                       "semantics": "sequential stream order (bit-exact vs reference -threads=1)",
+                       **({"exchange_note": carrier["note"]} if carrier["note"] else {})},
             "roofline": roofline, "cpu_baseline": cpu, "engine": headline["engine"], **extra,
         }
         print(json.dumps(out), flush=True)

@@ -183,18 +183,58 @@ int pppcsr_bucket_ops(uint32_t init_n, uint64_t n_parts, const ppcsr_op *ops, ui
 int pppcsr_bucket_ops_device(uint32_t init_n, uint64_t n_parts, const ppcsr_op *d_ops, uint64_t n, ppcsr_op *d_bucketed,
                              uint64_t *d_counts, void *stream);
 
-/* ---- native multi-GPU exchange: what replaces ThreadPoolPPPCSR::submit_* (thread_pool_pppcsr.cpp:96-118) across processes ----
- * One process per GPU; each holds the partitions of its domain (pppcsr_create_local) and a contiguous block of the global
- * stream in HBM.  pppcsr_exchange_apply buckets the block by owner (stable), packs one fixed-capacity chunk per peer,
- * swaps the chunks with grouped ncclSend / ncclRecv on a HIP stream (RCCL over xGMI; ONE collective step with static
- * sizes), unpacks what it received in source-rank order (= global stream order per partition) and applies every local
- * partition's subsequence concurrently.  `capacity` = the largest block any rank passes (agreed beforehand).
+/* ---- multi-GPU owner exchange: what replaces ThreadPoolPPPCSR::submit_* (thread_pool_pppcsr.cpp:96-118) across processes ----
+ * One process per GPU; each holds the contiguous partition range [rank * P / ranks, (rank + 1) * P / ranks) of the global
+ * layout (pppcsr_create_local) and a contiguous block of the global stream in HBM.  The exchange has three steps:
+ *   pack      stable device-side bucketing of the block by owner partition (src made partition-local, PPPCSR.cpp:46-52).
+ *             The bucketed block IS the send buffer: ranks hold ascending partition ranges, so the rows for peer r are
+ *             the contiguous run of its partitions' buckets — nothing is padded, only `counts` rows travel.
+ *   transport first the bucket sizes (ppr numbers to and from every peer), then the rows: segment (source r, partition q)
+ *             lands directly where the stream of partition q wants it (partition-major, source-rank-minor = global
+ *             stream order per partition) — no unpack pass.
+ *   apply     every local partition applies its stream concurrently (pppcsr_apply_parts_device).
+ * pppcsr_exchange_apply runs all three with RCCL as the carrier (grouped ncclSend / ncclRecv on a HIP stream, bound at run
+ * time by dlopen of librccl.so; two small collective steps per batch).  The pppcsr_xchg_* calls expose the same pack /
+ * layout / apply code with the transport left to the caller (another carrier, or the tests' gloo transport between two
+ * CPU-emulator processes).  pppcsr_xchg_create fails unless P is a multiple of n_ranks and the partitions resident in `h`
+ * are exactly this rank's range, on one device.
  * The 128-byte unique id comes from rank 0 (pppcsr_comm_unique_id) and is handed to the other ranks by the host program
- * (any bootstrap: a file, MPI, torch.distributed's store).  RCCL is bound at run time (dlopen of librccl.so). */
+ * (any bootstrap: a file, MPI, torch.distributed's store).  Every rank must call pppcsr_exchange_apply for every batch, also
+ * with an empty block.  A rank whose bucketing fails tells its peers through the counts, and no rank exchanges rows. */
+typedef struct pppcsr_xchg *pppcsr_xchg_t; /* staging of one rank's side of the exchange */
+int pppcsr_xchg_create(pppcsr_t h, int n_ranks, int rank, pppcsr_xchg_t *out);
+int pppcsr_xchg_destroy(pppcsr_xchg_t x);
+/* send_counts[P] (host, may be NULL): rows per partition; partition p's rows start at *d_send + sum(send_counts[0..p)) */
+int pppcsr_xchg_pack(pppcsr_xchg_t x, const ppcsr_op *d_ops, uint64_t n, uint64_t *send_counts, const ppcsr_op **d_send);
+/* recv_counts[r * ppr + q] = rows source rank r holds for my q-th partition (ppr = P / n_ranks); d_dst[r * ppr + q]
+ * (may be NULL) = device address that segment must be written to before pppcsr_xchg_apply */
+int pppcsr_xchg_layout(pppcsr_xchg_t x, const uint64_t *recv_counts, ppcsr_op **d_dst);
+int pppcsr_xchg_apply(pppcsr_xchg_t x);
+int pppcsr_xchg_set_num_neighbors(pppcsr_xchg_t x); /* the routed records are (vertex, num_neighbors, *): see pppcsr_repartition_export */
 int pppcsr_comm_unique_id(void *id_out_128_bytes);
 int pppcsr_comm_create(const void *id_128_bytes, int n_ranks, int rank, int device, pppcsr_comm_t *out);
 int pppcsr_comm_destroy(pppcsr_comm_t c);
-int pppcsr_exchange_apply(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_ops, uint64_t n, uint64_t capacity);
+int pppcsr_exchange_apply(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_ops, uint64_t n);
+int pppcsr_exchange_set_num_neighbors(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_recs, uint64_t n);
+
+/* ---- repartitioning.  The reference only sketches it (PCSR.h:91-112 is commented out), so there
+ * is no reference behaviour to match; the rule here is deterministic and the tests rebuild it with the oracle:
+ * new_starts[P] = first global vertex of every partition (new_starts[0] = 0, non-decreasing).  A partition whose vertex
+ * range is unchanged keeps its array as it is.  A partition whose range changes is recreated empty at its new size, and
+ * the edges of all such partitions are returned as adds of the global stream — (global src, dest, value), ascending
+ * (src, dest) — in device memory owned by the handle (valid until the next call): route them like any batch
+ * (pppcsr_apply_batch_device in one process, pppcsr_exchange_apply across ranks; every rank calls with the same
+ * new_starts).  num_neighbors is a counter of calls, not the degree (duplicate adds and deletes of missing edges move
+ * it, PCSR.cpp:1380/1409), so it travels beside the edges: d_nn holds one record (global vertex, num_neighbors, 1) per
+ * vertex of the changed partitions, to be routed the same way AFTER the adds (pppcsr_set_num_neighbors_device /
+ * pppcsr_exchange_set_num_neighbors / pppcsr_xchg_set_num_neighbors).  pppcsr_repartition does all of it when every
+ * partition is resident in this process.
+ * pppcsr_balanced_starts proposes starts of about equal weight, weight(v) = num_neighbors(v) + 1. */
+int pppcsr_repartition_export(pppcsr_t h, const uint64_t *new_starts, const ppcsr_op **d_ops, uint64_t *n, const ppcsr_op **d_nn,
+                              uint64_t *n_nn);
+int pppcsr_set_num_neighbors_device(pppcsr_t h, const ppcsr_op *d_recs, uint64_t n);
+int pppcsr_repartition(pppcsr_t h, const uint64_t *new_starts);
+int pppcsr_balanced_starts(pppcsr_t h, uint64_t *starts_out);
 
 #ifdef __cplusplus
 }

@@ -537,6 +537,8 @@ uint64_t po_get_neighbourhood(const po_pcsr *p, int src, int *out, uint64_t cap)
 }
 /* test hook: run the reference's redistribute() on an arbitrary aligned window */
 void po_debug_redistribute(po_pcsr *p, uint64_t index, uint64_t len) { po_redistribute(p, (int64_t)index, (int64_t)len); }
+/* test hook for the repartitioning tests (no reference equivalent): overwrite a vertex's call counter */
+void po_set_num_neighbors(po_pcsr *p, uint32_t v, uint32_t nn) { if (v < p->n) p->nodes[v].num_neighbors = nn; }
 void po_get_stats(const po_pcsr *p, po_stats *out) { *out = p->st; }
 void po_reset_stats(po_pcsr *p) { memset(&p->st, 0, sizeof(p->st)); }
 

@@ -47,6 +47,9 @@ EXPORTED = [
     "pppcsr_apply_batch", "pppcsr_bucket_ops", "pppcsr_bucket_ops_device",
     "pppcsr_create_local", "pppcsr_apply_batch_device", "pppcsr_apply_parts_device",
     "pppcsr_comm_unique_id", "pppcsr_comm_create", "pppcsr_comm_destroy", "pppcsr_exchange_apply",
+    "pppcsr_xchg_create", "pppcsr_xchg_destroy", "pppcsr_xchg_pack", "pppcsr_xchg_layout", "pppcsr_xchg_apply",
+    "pppcsr_repartition_export", "pppcsr_repartition", "pppcsr_balanced_starts", "pppcsr_set_num_neighbors_device",
+    "pppcsr_xchg_set_num_neighbors", "pppcsr_exchange_set_num_neighbors",
 ]
 
 _LIBS = {}
@@ -135,7 +138,18 @@ def load_library(path=None):
     L.pppcsr_comm_unique_id.argtypes = [c_vp]
     L.pppcsr_comm_create.argtypes = [c_vp, c_int, c_int, c_int, ctypes.POINTER(c_vp)]
     L.pppcsr_comm_destroy.argtypes = [c_vp]
-    L.pppcsr_exchange_apply.argtypes = [c_vp, c_vp, c_vp, c_u64, c_u64]
+    L.pppcsr_exchange_apply.argtypes = [c_vp, c_vp, c_vp, c_u64]
+    L.pppcsr_xchg_create.argtypes = [c_vp, c_int, c_int, ctypes.POINTER(c_vp)]
+    L.pppcsr_xchg_destroy.argtypes = [c_vp]
+    L.pppcsr_xchg_pack.argtypes = [c_vp, c_vp, c_u64, c_vp, ctypes.POINTER(c_vp)]
+    L.pppcsr_xchg_layout.argtypes = [c_vp, c_vp, c_vp]
+    L.pppcsr_xchg_apply.argtypes = [c_vp]
+    L.pppcsr_repartition_export.argtypes = [c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_u64), ctypes.POINTER(c_vp), ctypes.POINTER(c_u64)]
+    L.pppcsr_set_num_neighbors_device.argtypes = [c_vp, c_vp, c_u64]
+    L.pppcsr_xchg_set_num_neighbors.argtypes = [c_vp]
+    L.pppcsr_exchange_set_num_neighbors.argtypes = [c_vp, c_vp, c_vp, c_u64]
+    L.pppcsr_repartition.argtypes = [c_vp, c_vp]
+    L.pppcsr_balanced_starts.argtypes = [c_vp, c_vp]
     _LIBS[path] = L
     return L
 
@@ -313,6 +327,9 @@ class PPPCSR:
         if getattr(self, "comm", None) is not None and self.comm.value:
             self.L.pppcsr_comm_destroy(self.comm)
             self.comm = None
+        if getattr(self, "xchg", None) is not None and self.xchg.value:
+            self.L.pppcsr_xchg_destroy(self.xchg)
+            self.xchg = None
         if getattr(self, "h", None) and self.h.value:
             self.L.pppcsr_destroy(self.h)
         self.h = None
@@ -393,9 +410,62 @@ class PPPCSR:
         self.comm = c_vp()
         self._chk(self.L.pppcsr_comm_create(ctypes.c_char_p(unique_id), n_ranks, rank, device, ctypes.byref(self.comm)))
 
-    def exchange_apply(self, dev_ptr, n, capacity):
+    def exchange_apply(self, dev_ptr, n):
         """this rank's block of the global stream (device pointer, n updates): route through RCCL + apply the local partitions"""
-        self._chk(self.L.pppcsr_exchange_apply(self.h, self.comm, dev_ptr, n, capacity))
+        self._chk(self.L.pppcsr_exchange_apply(self.h, self.comm, dev_ptr, n))
+
+    # the same exchange with the transport left to the caller (pack -> [carrier of your choice] -> layout -> apply)
+    def xchg_create(self, n_ranks, rank):
+        self.xchg = c_vp()
+        self._chk(self.L.pppcsr_xchg_create(self.h, n_ranks, rank, ctypes.byref(self.xchg)))
+        self._xchg_shape = (n_ranks, self.num_partitions() // n_ranks)
+
+    def xchg_pack(self, dev_ptr, n):
+        """-> (send_counts[P], device address of the bucketed block); partition p's rows start at sum(send_counts[:p])"""
+        counts = np.zeros(self.num_partitions(), np.uint64)
+        d_send = c_vp()
+        self._chk(self.L.pppcsr_xchg_pack(self.xchg, dev_ptr, n, counts.ctypes.data, ctypes.byref(d_send)))
+        return counts, d_send.value or 0
+
+    def xchg_layout(self, recv_counts):
+        """recv_counts[r * ppr + q] -> device addresses the segments (source r, local partition q) must be written to"""
+        rc = np.ascontiguousarray(recv_counts, np.uint64)
+        assert rc.size == self._xchg_shape[0] * self._xchg_shape[1]
+        dst = (c_vp * rc.size)()
+        self._chk(self.L.pppcsr_xchg_layout(self.xchg, rc.ctypes.data, dst))
+        return [int(x or 0) for x in dst]
+
+    def xchg_apply(self):
+        self._chk(self.L.pppcsr_xchg_apply(self.xchg))
+
+    def xchg_set_num_neighbors(self):
+        self._chk(self.L.pppcsr_xchg_set_num_neighbors(self.xchg))
+
+    def exchange_set_num_neighbors(self, dev_ptr, n):
+        self._chk(self.L.pppcsr_exchange_set_num_neighbors(self.h, self.comm, dev_ptr, n))
+
+    def set_num_neighbors_device(self, dev_ptr, n):
+        self._chk(self.L.pppcsr_set_num_neighbors_device(self.h, dev_ptr, n))
+
+    # repartitioning (include/ppcsr.h; no reference equivalent: PCSR.h:91-112 is a sketch)
+    def repartition(self, new_starts):
+        st = np.ascontiguousarray(new_starts, np.uint64)
+        assert st.size == self.num_partitions()
+        self._chk(self.L.pppcsr_repartition(self.h, st.ctypes.data))
+
+    def repartition_export(self, new_starts):
+        """-> ((device address, n) of the edges on the move as adds of the global stream, (device address, n) of the
+        num_neighbors records); route the first like any batch, then the second through the set_num_neighbors calls"""
+        st = np.ascontiguousarray(new_starts, np.uint64)
+        assert st.size == self.num_partitions()
+        d, n, dn, nn = c_vp(), c_u64(), c_vp(), c_u64()
+        self._chk(self.L.pppcsr_repartition_export(self.h, st.ctypes.data, ctypes.byref(d), ctypes.byref(n), ctypes.byref(dn), ctypes.byref(nn)))
+        return (d.value or 0, n.value), (dn.value or 0, nn.value)
+
+    def balanced_starts(self):
+        st = np.zeros(self.num_partitions(), np.uint64)
+        self._chk(self.L.pppcsr_balanced_starts(self.h, st.ctypes.data))
+        return st
 
     def apply_parts_device(self, first_part, dev_ptrs, counts):
         """already routed device-resident subsequences, one per partition of [first_part, first_part + len(counts))"""

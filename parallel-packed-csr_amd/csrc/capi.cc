@@ -18,13 +18,15 @@ int capi_set_device(int d);
 int capi_dev_alloc(void **p, size_t bytes);
 int capi_dev_free(void *p);
 int capi_d2h_sync(void *dst, const void *src, size_t bytes);  // on the NULL stream, after whatever it holds
+int capi_dev_memset(void *p, int byte, size_t bytes, void *stream);
 #if !defined(PPCSR_SIM)
 struct ppcsr_xchg;
 int capi_xchg_unique_id(void *out128, std::string *err);
 int capi_xchg_create(const void *id128, int nranks, int rank, int device, ppcsr_xchg **out, std::string *err);
 int capi_xchg_destroy(ppcsr_xchg *x);
-int capi_xchg_route(ppcsr_xchg *x, uint32_t init_n, uint32_t n_parts, const ppcsr::Op *d_ops, uint64_t n, uint64_t cap, const ppcsr::Op **out_ptrs,
-                    uint64_t *out_counts);
+int capi_xchg_ranks(ppcsr_xchg *x, int *nranks, int *rank, int *device, void **stream);
+int capi_xchg_sendrecv(ppcsr_xchg *x, uint64_t nseg, const void *const *sptr, const uint64_t *sbytes, const int *speer, void *const *rptr,
+                       const uint64_t *rbytes, const int *rpeer);
 const char *capi_xchg_error(ppcsr_xchg *x);
 #endif
 
@@ -178,6 +180,11 @@ struct pppcsr_engine {
   std::vector<uint64_t> distribution;  // first vertex of each partition (PPPCSR.h:57)
   std::vector<int> device;             // device of each resident partition
   uint32_t init_n;
+  uint64_t total_n = 0;  // vertices over all partitions (init_n + add_node calls)
+  int lock_search = 1;
+  // edges on the move of pppcsr_repartition_export
+  ppcsr_op *d_moved = nullptr;
+  uint64_t moved_cap = 0;
   // device-resident routing scratch of pppcsr_apply_batch_device (bucketed copy of the batch + bucket sizes)
   ppcsr_op *d_bucketed = nullptr;
   uint64_t bucketed_cap = 0;
@@ -213,6 +220,8 @@ static int create_parts(uint32_t init_n, int lock_search, int num_domains, int p
   if (first + n_local > P) return bad("local partition range exceeds the layout");
   std::unique_ptr<pppcsr_engine> pp(new pppcsr_engine());
   pp->init_n = init_n;
+  pp->total_n = init_n;
+  pp->lock_search = lock_search;
   std::vector<uint64_t> sizes;
   partition_layout(init_n, P, &pp->distribution, &sizes);
   pp->parts.assign(P, nullptr);
@@ -247,6 +256,7 @@ int pppcsr_destroy(pppcsr_t h) {
   for (auto *q : h->parts) ppcsr_destroy(q);
   if (h->d_bucketed) capi_dev_free(h->d_bucketed);
   if (h->d_counts) capi_dev_free(h->d_counts);
+  if (h->d_moved) capi_dev_free(h->d_moved);
   delete h;
   return 0;
 }
@@ -307,12 +317,24 @@ int pppcsr_get_n(pppcsr_t h, uint64_t *n) {
   *n = t;
   return 0;
 }
-int pppcsr_add_node(pppcsr_t h) { PP_CHECK(); PP_PART(h->parts.size() - 1); return ppcsr_add_node(h->parts.back()); }  // PPPCSR.cpp:44
+// PPPCSR.cpp:44: the new vertex joins the last partition.  Every rank calls this (the vertex count is part of the layout
+// pppcsr_repartition works from); only the rank that holds the last partition has an engine to grow.
+int pppcsr_add_node(pppcsr_t h) {
+  PP_CHECK();
+  h->total_n++;
+  if (!h->parts.back()) return 0;
+  return ppcsr_add_node(h->parts.back());
+}
 
+static int bucket_host(const std::vector<uint64_t> &dist, const ppcsr_op *ops, uint64_t n, ppcsr_op *bucketed, uint64_t *counts);
 int pppcsr_bucket_ops(uint32_t init_n, uint64_t n_parts, const ppcsr_op *ops, uint64_t n, ppcsr_op *bucketed, uint64_t *counts) {
   if (n_parts < 1 || (!ops && n) || !bucketed || !counts) return bad("bad arguments");
   std::vector<uint64_t> dist, sizes;
   partition_layout(init_n, n_parts, &dist, &sizes);
+  return bucket_host(dist, ops, n, bucketed, counts);
+}
+static int bucket_host(const std::vector<uint64_t> &dist, const ppcsr_op *ops, uint64_t n, ppcsr_op *bucketed, uint64_t *counts) {
+  const uint64_t n_parts = dist.size();
   std::vector<uint64_t> off(n_parts + 1, 0);
   for (uint64_t k = 0; k < n_parts; k++) counts[k] = 0;
   std::vector<uint32_t> owner(n);
@@ -330,27 +352,40 @@ int pppcsr_bucket_ops(uint32_t init_n, uint64_t n_parts, const ppcsr_op *ops, ui
   return 0;
 }
 
-int pppcsr_bucket_ops_device(uint32_t init_n, uint64_t n_parts, const ppcsr_op *d_ops, uint64_t n, ppcsr_op *d_bucketed,
-                             uint64_t *d_counts, void *stream) {
+static int bucket_device(const std::vector<uint64_t> &dist, const ppcsr_op *d_ops, uint64_t n, ppcsr_op *d_bucketed, uint64_t *d_counts,
+                         void *stream) {
+  const uint64_t n_parts = dist.size();
   if (n_parts < 1 || n_parts > 64 || (!d_ops && n) || !d_bucketed || !d_counts) return bad("bad arguments");
+  std::vector<uint32_t> starts(n_parts);
+  for (uint64_t k = 0; k < n_parts; k++) starts[k] = (uint32_t)dist[k];
   std::string msg;
-  int rc = ppcsr::bucket_ops_device(init_n, (uint32_t)n_parts, reinterpret_cast<const ppcsr::Op *>(d_ops), n,
+  int rc = ppcsr::bucket_ops_device(starts.data(), (uint32_t)n_parts, reinterpret_cast<const ppcsr::Op *>(d_ops), n,
                                     reinterpret_cast<ppcsr::Op *>(d_bucketed), reinterpret_cast<unsigned long long *>(d_counts), stream, &msg);
   if (rc != 0) g_last_error = msg;
   return rc;
+}
+int pppcsr_bucket_ops_device(uint32_t init_n, uint64_t n_parts, const ppcsr_op *d_ops, uint64_t n, ppcsr_op *d_bucketed,
+                             uint64_t *d_counts, void *stream) {
+  if (n_parts < 1 || n_parts > 64) return bad("bad arguments");
+  std::vector<uint64_t> dist, sizes;
+  partition_layout(init_n, n_parts, &dist, &sizes);
+  return bucket_device(dist, d_ops, n, d_bucketed, d_counts, stream);
 }
 
 // Partitions are independent engines with their own streams (PPPCSR.h:54): host threads drive them side by side — the
 // reference runs every domain's workers concurrently (thread_pool_pppcsr.cpp:121-156) — so the latency-bound round
 // kernels of different partitions overlap on the GPU(s).  Each partition still applies its own subsequence in stream order.
 // ops[i] / counts[i] belong to partition first + i; `device_resident` selects the entry point.
-static int apply_parts(pppcsr_t h, uint64_t first, uint64_t np, const ppcsr_op *const *ops, const uint64_t *counts, bool device_resident) {
+enum { PARTS_HOST = 0, PARTS_DEVICE = 1, PARTS_SET_NN = 2 };  // what the routed records are: updates (host / HBM) or num_neighbors records
+static int apply_parts(pppcsr_t h, uint64_t first, uint64_t np, const ppcsr_op *const *ops, const uint64_t *counts, int kind) {
   for (uint64_t i = 0; i < np; i++)
     if (counts[i] && (first + i >= h->parts.size() || !h->parts[first + i])) return bad("partition not resident in this process");
   auto one = [&](uint64_t i) -> int {
     if (!counts[i]) return 0;
-    return device_resident ? ppcsr_apply_batch_device(h->parts[first + i], ops[i], counts[i])
-                           : ppcsr_apply_batch(h->parts[first + i], ops[i], counts[i]);
+    if (kind == PARTS_SET_NN)
+      return ret(h->parts[first + i]->e, h->parts[first + i]->e->set_num_neighbors_device(reinterpret_cast<const ppcsr::Op *>(ops[i]), counts[i]));
+    return kind == PARTS_DEVICE ? ppcsr_apply_batch_device(h->parts[first + i], ops[i], counts[i])
+                                : ppcsr_apply_batch(h->parts[first + i], ops[i], counts[i]);
   };
 #if defined(PPCSR_SIM)
   for (uint64_t i = 0; i < np; i++) {  // (the CPU emulator is single-threaded)
@@ -403,7 +438,8 @@ int pppcsr_apply_batch(pppcsr_t h, const ppcsr_op *ops, uint64_t n) {
   const uint64_t P = h->parts.size();
   std::vector<ppcsr_op> b(n);
   std::vector<uint64_t> counts(P);
-  int rc = pppcsr_bucket_ops(h->init_n, P, ops, n, b.data(), counts.data());
+  if (!ops) return bad("null ops");
+  int rc = bucket_host(h->distribution, ops, n, b.data(), counts.data());
   if (rc != 0) return rc;
   std::vector<const ppcsr_op *> ptrs(P);
   uint64_t off = 0;
@@ -411,16 +447,16 @@ int pppcsr_apply_batch(pppcsr_t h, const ppcsr_op *ops, uint64_t n) {
     ptrs[k] = b.data() + off;
     off += counts[k];
   }
-  return apply_parts(h, 0, P, ptrs.data(), counts.data(), false);
+  return apply_parts(h, 0, P, ptrs.data(), counts.data(), PARTS_HOST);
 }
 
 int pppcsr_apply_parts_device(pppcsr_t h, uint64_t first_part, uint64_t n_parts, const ppcsr_op *const *d_ops, const uint64_t *counts) {
   PP_CHECK();
   if (!d_ops || !counts) return bad("null argument");
-  return apply_parts(h, first_part, n_parts, d_ops, counts, true);
+  return apply_parts(h, first_part, n_parts, d_ops, counts, PARTS_DEVICE);
 }
 
-int pppcsr_apply_batch_device(pppcsr_t h, const ppcsr_op *d_ops, uint64_t n) {
+static int route_device(pppcsr_t h, const ppcsr_op *d_ops, uint64_t n, int kind) {
   PP_CHECK();
   if (n == 0) return 0;
   const uint64_t P = h->parts.size();
@@ -437,7 +473,7 @@ int pppcsr_apply_batch_device(pppcsr_t h, const ppcsr_op *d_ops, uint64_t n) {
     h->bucketed_cap = n;
   }
   if (!h->d_counts && capi_dev_alloc((void **)&h->d_counts, 64 * sizeof(uint64_t)) != 0) return bad("pppcsr_apply_batch_device: out of device memory");
-  rc = pppcsr_bucket_ops_device(h->init_n, P, d_ops, n, h->d_bucketed, h->d_counts, nullptr);
+  rc = bucket_device(h->distribution, d_ops, n, h->d_bucketed, h->d_counts, nullptr);
   if (rc != 0) return rc;
   std::vector<uint64_t> counts(P);
   if (capi_d2h_sync(counts.data(), h->d_counts, P * sizeof(uint64_t)) != 0) return bad("pppcsr_apply_batch_device: device-to-host copy failed");
@@ -447,11 +483,159 @@ int pppcsr_apply_batch_device(pppcsr_t h, const ppcsr_op *d_ops, uint64_t n) {
     ptrs[k] = h->d_bucketed + off;
     off += counts[k];
   }
-  return apply_parts(h, 0, P, ptrs.data(), counts.data(), true);
+  return apply_parts(h, 0, P, ptrs.data(), counts.data(), kind);
 }
+int pppcsr_apply_batch_device(pppcsr_t h, const ppcsr_op *d_ops, uint64_t n) { return route_device(h, d_ops, n, PARTS_DEVICE); }
+int pppcsr_set_num_neighbors_device(pppcsr_t h, const ppcsr_op *d_recs, uint64_t n) { return route_device(h, d_recs, n, PARTS_SET_NN); }
 
-// ---- native exchange: RCCL send/recv on a HIP stream, no torch in the data path (thread_pool_pppcsr.cpp:96-118 replaced) ----
+// ---- owner exchange in three steps: pack -> transport -> apply (thread_pool_pppcsr.cpp:96-118 replaced across processes) ----
+// The staging object below knows nothing about the carrier: pppcsr_exchange_apply moves the bytes with RCCL, the tests move
+// them with gloo between two CPU-emulator processes — pack, layout and apply are the same code in both.
+}  // extern "C"
+struct pppcsr_xchg {
+  pppcsr_engine *h = nullptr;
+  int nranks = 1, rank = 0, device = 0;
+  uint64_t ppr = 0, first = 0;           // this rank's partitions: [first, first + ppr)
+  ppcsr_op *d_send = nullptr;            // the block, stably bucketed by owner partition (= by peer: ranks hold ascending ranges)
+  uint64_t send_cap = 0;
+  uint64_t *d_counts = nullptr;          // [P] rows per partition of d_send (device)
+  uint64_t *d_rcounts = nullptr;         // [nranks * ppr] rows each source rank holds for my partitions (device; RCCL carrier)
+  ppcsr_op *d_out = nullptr;             // per-partition streams, partition-major, source-rank-minor
+  uint64_t out_cap = 0;
+  std::vector<uint64_t> send_counts, send_off, recv_counts, part_first, part_count;
+  std::vector<ppcsr_op *> dst;           // [nranks * ppr] where the segment (source r, local partition q) lands: dst[r * ppr + q]
+  int stage = 0;                         // 0 idle, 1 packed, 2 laid out
+};
+static void xchg_free(pppcsr_xchg *x) {
+  if (!x) return;
+  capi_set_device(x->device);
+  for (void *q : {(void *)x->d_send, (void *)x->d_counts, (void *)x->d_rcounts, (void *)x->d_out})
+    if (q) capi_dev_free(q);
+  delete x;
+}
+// bucketing only, asynchronous on `stream` (the RCCL carrier ships d_counts without reading it back first)
+static int xchg_pack_async(pppcsr_xchg *x, const ppcsr_op *d_ops, uint64_t n, void *stream) {
+  if (!d_ops && n) return bad("null ops");
+  int rc = capi_set_device(x->device);
+  if (rc != 0) return rc;
+  if (x->send_cap < std::max<uint64_t>(n, 1)) {
+    if (x->d_send) capi_dev_free(x->d_send);
+    x->d_send = nullptr;
+    x->send_cap = 0;
+    if (capi_dev_alloc((void **)&x->d_send, std::max<uint64_t>(n, 1) * sizeof(ppcsr_op)) != 0) return bad("out of device memory (exchange send block)");
+    x->send_cap = std::max<uint64_t>(n, 1);
+  }
+  x->stage = 0;
+  return bucket_device(x->h->distribution, d_ops, n, x->d_send, x->d_counts, stream);
+}
+static void xchg_set_send_counts(pppcsr_xchg *x) {
+  const uint64_t P = x->h->parts.size();
+  x->send_off.assign(P + 1, 0);
+  for (uint64_t k = 0; k < P; k++) x->send_off[k + 1] = x->send_off[k] + x->send_counts[k];
+  x->stage = 1;
+}
+extern "C" {
+int pppcsr_xchg_create(pppcsr_t h, int n_ranks, int rank, pppcsr_xchg_t *out) {
+  PP_CHECK();
+  if (!out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return bad("bad rank arguments");
+  *out = nullptr;
+  const uint64_t P = h->parts.size();
+  if (P > 64 || P % (uint64_t)n_ranks) return bad("partitions must be a multiple of the ranks (and at most 64)");
+  const uint64_t ppr = P / (uint64_t)n_ranks, first = (uint64_t)rank * ppr;
+  // this rank must hold exactly the contiguous range [rank * ppr, (rank + 1) * ppr) of the global layout, on one device
+  for (uint64_t k = 0; k < P; k++) {
+    const bool mine = k >= first && k < first + ppr;
+    if (mine != (h->parts[k] != nullptr)) return bad("the resident partitions are not this rank's range [rank * P / ranks, (rank + 1) * P / ranks)");
+    if (mine && h->device[k] != h->device[first]) return bad("a rank's partitions must live on one device");
+  }
+  std::unique_ptr<pppcsr_xchg> x(new pppcsr_xchg());
+  x->h = h;
+  x->nranks = n_ranks;
+  x->rank = rank;
+  x->ppr = ppr;
+  x->first = first;
+  x->device = h->device[first];
+  int rc = capi_set_device(x->device);
+  if (rc != 0) return rc;
+  if (capi_dev_alloc((void **)&x->d_counts, 64 * sizeof(uint64_t)) != 0 || capi_dev_alloc((void **)&x->d_rcounts, 64 * sizeof(uint64_t)) != 0) {
+    xchg_free(x.release());
+    return bad("out of device memory");
+  }
+  x->send_counts.assign(P, 0);
+  x->recv_counts.assign((uint64_t)n_ranks * ppr, 0);
+  x->part_first.assign(ppr, 0);
+  x->part_count.assign(ppr, 0);
+  x->dst.assign((uint64_t)n_ranks * ppr, nullptr);
+  *out = x.release();
+  return 0;
+}
+int pppcsr_xchg_destroy(pppcsr_xchg_t x) {
+  xchg_free(x);
+  return 0;
+}
+int pppcsr_xchg_pack(pppcsr_xchg_t x, const ppcsr_op *d_ops, uint64_t n, uint64_t *send_counts, const ppcsr_op **d_send) {
+  if (!x) return bad("null exchange");
+  int rc = xchg_pack_async(x, d_ops, n, nullptr);
+  if (rc != 0) return rc;
+  const uint64_t P = x->h->parts.size();
+  if (capi_d2h_sync(x->send_counts.data(), x->d_counts, P * sizeof(uint64_t)) != 0) return bad("pppcsr_xchg_pack: device-to-host copy failed");
+  xchg_set_send_counts(x);
+  if (send_counts) memcpy(send_counts, x->send_counts.data(), P * sizeof(uint64_t));
+  if (d_send) *d_send = x->d_send;
+  return 0;
+}
+int pppcsr_xchg_layout(pppcsr_xchg_t x, const uint64_t *recv_counts, ppcsr_op **d_dst) {
+  if (!x || !recv_counts) return bad("null argument");
+  if (x->stage < 1) return bad("pppcsr_xchg_layout before pppcsr_xchg_pack");
+  const uint64_t W = (uint64_t)x->nranks, ppr = x->ppr;
+  for (uint64_t q = 0; q < ppr; q++)  // what a rank sends to itself it knows already: a carrier that disagrees is broken
+    if (recv_counts[(uint64_t)x->rank * ppr + q] != x->send_counts[x->first + q]) return bad("pppcsr_xchg_layout: own segment sizes do not match the packed block");
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < W * ppr; i++) {
+    x->recv_counts[i] = recv_counts[i];
+    total += recv_counts[i];
+  }
+  int rc = capi_set_device(x->device);
+  if (rc != 0) return rc;
+  if (x->out_cap < std::max<uint64_t>(total, 1)) {
+    if (x->d_out) capi_dev_free(x->d_out);
+    x->d_out = nullptr;
+    x->out_cap = 0;
+    if (capi_dev_alloc((void **)&x->d_out, std::max<uint64_t>(total, 1) * sizeof(ppcsr_op)) != 0) return bad("out of device memory (exchange streams)");
+    x->out_cap = std::max<uint64_t>(total, 1);
+  }
+  uint64_t run = 0;
+  for (uint64_t q = 0; q < ppr; q++) {  // partition-major, source-minor: sources in rank order = global stream order
+    x->part_first[q] = run;
+    for (uint64_t r = 0; r < W; r++) {
+      x->dst[r * ppr + q] = x->d_out + run;
+      run += recv_counts[r * ppr + q];
+    }
+    x->part_count[q] = run - x->part_first[q];
+  }
+  if (d_dst) memcpy(d_dst, x->dst.data(), W * ppr * sizeof(ppcsr_op *));
+  x->stage = 2;
+  return 0;
+}
+static int xchg_finish(pppcsr_xchg_t x, int kind) {
+  if (!x) return bad("null exchange");
+  if (x->stage != 2) return bad("pppcsr_xchg_apply before pppcsr_xchg_layout");
+  x->stage = 0;
+  std::vector<const ppcsr_op *> ptrs(x->ppr);
+  for (uint64_t q = 0; q < x->ppr; q++) ptrs[q] = x->d_out + x->part_first[q];
+  return apply_parts(x->h, x->first, x->ppr, ptrs.data(), x->part_count.data(), kind);
+}
+int pppcsr_xchg_apply(pppcsr_xchg_t x) { return xchg_finish(x, PARTS_DEVICE); }
+int pppcsr_xchg_set_num_neighbors(pppcsr_xchg_t x) { return xchg_finish(x, PARTS_SET_NN); }
+}  // extern "C"
+
+// ---- the RCCL carrier: grouped ncclSend / ncclRecv on a HIP stream, no torch in the data path ----
 #if !defined(PPCSR_SIM)
+struct pppcsr_comm {
+  ppcsr_xchg *t = nullptr;     // communicator + stream (engine.cc)
+  pppcsr_xchg *x = nullptr;    // staging for the PPPCSR it was last used with
+};
+extern "C" {
 int pppcsr_comm_unique_id(void *id_out_128_bytes) {
   if (!id_out_128_bytes) return bad("null output");
   std::string msg;
@@ -463,42 +647,225 @@ int pppcsr_comm_create(const void *id_128_bytes, int n_ranks, int rank, int devi
   if (!id_128_bytes || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return bad("bad communicator arguments");
   *out = nullptr;
   std::string msg;
-  ppcsr_xchg *x = nullptr;
-  const int rc = capi_xchg_create(id_128_bytes, n_ranks, rank, device, &x, &msg);
+  ppcsr_xchg *t = nullptr;
+  const int rc = capi_xchg_create(id_128_bytes, n_ranks, rank, device, &t, &msg);
   if (rc != 0) {
     g_last_error = msg;
     return rc;
   }
-  *out = reinterpret_cast<pppcsr_comm_t>(x);
+  pppcsr_comm *c = new pppcsr_comm();
+  c->t = t;
+  *out = c;
   return 0;
 }
-int pppcsr_comm_destroy(pppcsr_comm_t c) { return capi_xchg_destroy(reinterpret_cast<ppcsr_xchg *>(c)); }
-int pppcsr_exchange_apply(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_ops, uint64_t n, uint64_t capacity) {
+int pppcsr_comm_destroy(pppcsr_comm_t c) {
+  if (!c) return 0;
+  xchg_free(c->x);
+  capi_xchg_destroy(c->t);
+  delete c;
+  return 0;
+}
+static int exchange_run(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_ops, uint64_t n, int kind) {
   PP_CHECK();
   if (!c) return bad("null communicator");
-  ppcsr_xchg *x = reinterpret_cast<ppcsr_xchg *>(c);
-  const uint64_t P = h->parts.size();
-  uint64_t first = P, nlocal = 0;
-  for (uint64_t k = 0; k < P; k++)
-    if (h->parts[k]) {
-      if (first == P) first = k;
-      nlocal++;
-    }
-  if (nlocal == 0 || nlocal > 64) return bad("no resident partitions");
-  std::vector<const ppcsr::Op *> ptrs(nlocal);
-  std::vector<uint64_t> counts(nlocal);
-  int rc = capi_xchg_route(x, h->init_n, (uint32_t)P, reinterpret_cast<const ppcsr::Op *>(d_ops), n, capacity, ptrs.data(), counts.data());
+  int W = 0, rank = 0, dev = 0;
+  void *stream = nullptr;
+  if (capi_xchg_ranks(c->t, &W, &rank, &dev, &stream) != 0) return bad("bad communicator");
+  if (!c->x || c->x->h != h) {  // (the layout checks against the communicator's ranks happen here)
+    xchg_free(c->x);
+    c->x = nullptr;
+    int rc = pppcsr_xchg_create(h, W, rank, &c->x);
+    if (rc != 0) return rc;
+  }
+  pppcsr_xchg *x = c->x;
+  if (x->device != dev) return bad("the communicator's device does not hold this rank's partitions");
+  const uint64_t P = h->parts.size(), ppr = x->ppr, nseg = (uint64_t)W * ppr;
+  // Every rank runs the counts step whatever happened to its own block — the transfers are collective.  A rank whose
+  // bucketing failed poisons its counts (all ones), so that ALL ranks skip the row transfers and report the failure.
+  int failed = xchg_pack_async(x, d_ops, n, stream);
+  const std::string first_msg = failed != 0 ? g_last_error : std::string();
+  if (failed != 0 && capi_dev_memset(x->d_counts, 0xFF, 64 * sizeof(uint64_t), stream) != 0) return bad("pppcsr_exchange_apply: device memset failed");
+  std::vector<const void *> sp(nseg);
+  std::vector<void *> rp(nseg);
+  std::vector<uint64_t> sb(nseg), rb(nseg);
+  std::vector<int> peer(nseg);
+  // (1) the counts: ppr numbers to and from every peer, straight from the bucketing kernels' output
+  for (int r = 0; r < W; r++) {
+    sp[r] = x->d_counts + (uint64_t)r * ppr;
+    rp[r] = x->d_rcounts + (uint64_t)r * ppr;
+    sb[r] = rb[r] = ppr * sizeof(uint64_t);
+    peer[r] = r;
+  }
+  int rc = capi_xchg_sendrecv(c->t, (uint64_t)W, sp.data(), sb.data(), peer.data(), rp.data(), rb.data(), peer.data());
   if (rc != 0) {
-    g_last_error = capi_xchg_error(x);
+    g_last_error = capi_xchg_error(c->t);
+    return rc;  // the carrier itself is broken: nothing collective can follow
+  }
+  std::vector<uint64_t> rcounts(nseg, 0);
+  if (capi_d2h_sync(x->send_counts.data(), x->d_counts, P * sizeof(uint64_t)) != 0 ||
+      capi_d2h_sync(rcounts.data(), x->d_rcounts, nseg * sizeof(uint64_t)) != 0)
+    return bad("pppcsr_exchange_apply: device-to-host copy failed");
+  if (failed != 0) {
+    g_last_error = first_msg;
+    return failed;
+  }
+  for (uint64_t i = 0; i < nseg; i++)
+    if (rcounts[i] == ~0ull) return bad("pppcsr_exchange_apply: a peer rank failed to bucket its block; no rows were exchanged");
+  xchg_set_send_counts(x);
+  rc = pppcsr_xchg_layout(x, rcounts.data(), nullptr);
+  if (rc != 0) return rc;  // (out of device memory for the received streams: fatal for the job, the peers are already sending)
+  // (2) the rows: segment (peer r, partition q) leaves from the bucketed block and lands where the stream of q wants it
+  for (int r = 0; r < W; r++)
+    for (uint64_t q = 0; q < ppr; q++) {
+      const uint64_t i = (uint64_t)r * ppr + q;
+      sp[i] = x->d_send + x->send_off[i];
+      sb[i] = x->send_counts[i] * sizeof(ppcsr_op);
+      rp[i] = x->dst[i];
+      rb[i] = rcounts[i] * sizeof(ppcsr_op);
+      peer[i] = r;
+    }
+  rc = capi_xchg_sendrecv(c->t, nseg, sp.data(), sb.data(), peer.data(), rp.data(), rb.data(), peer.data());
+  if (rc != 0) {
+    g_last_error = capi_xchg_error(c->t);
     return rc;
   }
-  return apply_parts(h, first, nlocal, reinterpret_cast<const ppcsr_op *const *>(ptrs.data()), counts.data(), true);
+  return xchg_finish(x, kind);
 }
+int pppcsr_exchange_apply(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_ops, uint64_t n) { return exchange_run(h, c, d_ops, n, PARTS_DEVICE); }
+int pppcsr_exchange_set_num_neighbors(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_recs, uint64_t n) {
+  return exchange_run(h, c, d_recs, n, PARTS_SET_NN);
+}
+}  // extern "C"
 #else
+extern "C" {
 int pppcsr_comm_unique_id(void *) { return bad("no RCCL in the CPU emulator build"); }
 int pppcsr_comm_create(const void *, int, int, int, pppcsr_comm_t *) { return bad("no RCCL in the CPU emulator build"); }
 int pppcsr_comm_destroy(pppcsr_comm_t) { return 0; }
-int pppcsr_exchange_apply(pppcsr_t, pppcsr_comm_t, const ppcsr_op *, uint64_t, uint64_t) { return bad("no RCCL in the CPU emulator build"); }
+int pppcsr_exchange_apply(pppcsr_t, pppcsr_comm_t, const ppcsr_op *, uint64_t) { return bad("no RCCL in the CPU emulator build"); }
+int pppcsr_exchange_set_num_neighbors(pppcsr_t, pppcsr_comm_t, const ppcsr_op *, uint64_t) { return bad("no RCCL in the CPU emulator build"); }
+}  // extern "C"
 #endif
 
+extern "C" {
+// ---- repartitioning (the reference only sketches it: PCSR.h:91-112 was never implemented) ----
+// The vertex ranges move; the edges of every partition whose range changes leave it as adds of the global stream
+// (src global, array order = ascending (src, dest)), the partition is recreated empty at its new size, and the caller
+// routes the adds with the ordinary machinery — pppcsr_apply_batch_device in one process, pppcsr_exchange_apply across
+// ranks (ranks hold ascending ranges, so per-partition order stays ascending).  Partitions whose range stays keep their
+// array untouched.  Scheduler options set on a recreated partition's engine return to their defaults.
+int pppcsr_repartition_export(pppcsr_t h, const uint64_t *new_starts, const ppcsr_op **d_ops, uint64_t *n_out, const ppcsr_op **d_nn,
+                              uint64_t *n_nn) {
+  PP_CHECK();
+  if (!new_starts || !d_ops || !n_out || !d_nn || !n_nn) return bad("null argument");
+  *d_ops = *d_nn = nullptr;
+  *n_out = *n_nn = 0;
+  const uint64_t P = h->parts.size();
+  if (new_starts[0] != 0) return bad("pppcsr_repartition: the first partition starts at vertex 0");
+  for (uint64_t k = 1; k < P; k++)
+    if (new_starts[k] < new_starts[k - 1]) return bad("pppcsr_repartition: starts must not decrease");
+  if (new_starts[P - 1] > h->total_n) return bad("pppcsr_repartition: a partition starts past the last vertex");
+  int dev = -1;
+  for (uint64_t k = 0; k < P; k++)
+    if (h->parts[k]) {
+      if (dev < 0) dev = h->device[k];
+      if (h->device[k] != dev) return bad("pppcsr_repartition: this process's partitions must live on one device");
+    }
+  auto end_of = [&](const uint64_t *st, uint64_t k) { return k + 1 < P ? st[k + 1] : h->total_n; };
+  std::vector<uint64_t> cnt(P, 0), nk(P, 0);
+  std::vector<char> changed(P, 0);
+  uint64_t total = 0, total_nn = 0;
+  for (uint64_t k = 0; k < P; k++) {
+    if (!h->parts[k]) continue;
+    changed[k] = h->distribution[k] != new_starts[k] || end_of(h->distribution.data(), k) != end_of(new_starts, k);
+    if (!changed[k]) continue;
+    int rc = ret(h->parts[k]->e, h->parts[k]->e->export_triples_device(0, nullptr, 0, &cnt[k]));
+    if (rc != 0) return rc;
+    total += cnt[k];
+    ppcsr_get_n(h->parts[k], &nk[k]);
+    total_nn += nk[k];
+  }
+  if (dev >= 0) {
+    int rc = capi_set_device(dev);
+    if (rc != 0) return rc;
+  }
+  if (total + total_nn > h->moved_cap) {  // [edges | num_neighbors records]
+    if (h->d_moved) capi_dev_free(h->d_moved);
+    h->d_moved = nullptr;
+    h->moved_cap = 0;
+    if (capi_dev_alloc((void **)&h->d_moved, (total + total_nn) * sizeof(ppcsr_op)) != 0) return bad("pppcsr_repartition: out of device memory");
+    h->moved_cap = total + total_nn;
+  }
+  uint64_t off = 0, noff = total;
+  for (uint64_t k = 0; k < P; k++) {
+    if (!changed[k]) continue;
+    uint64_t t = 0;
+    int rc = ret(h->parts[k]->e, h->parts[k]->e->export_triples_device((uint32_t)h->distribution[k], reinterpret_cast<ppcsr::Op *>(h->d_moved) + off,
+                                                                       cnt[k], &t));
+    if (rc != 0) return rc;
+    off += cnt[k];
+    rc = ret(h->parts[k]->e, h->parts[k]->e->export_num_neighbors_device((uint32_t)h->distribution[k], reinterpret_cast<ppcsr::Op *>(h->d_moved) + noff));
+    if (rc != 0) return rc;
+    noff += nk[k];
+  }
+  for (uint64_t k = 0; k < P; k++) {
+    if (!changed[k]) continue;
+    const uint64_t size = end_of(new_starts, k) - new_starts[k];
+    ppcsr_t fresh = nullptr;
+    int rc = ppcsr_create((uint32_t)size, (uint32_t)size, h->lock_search, h->device[k], &fresh);
+    if (rc != 0) return rc;  // (the old partition is still in place: the graph is intact, the layout unchanged)
+    ppcsr_destroy(h->parts[k]);
+    h->parts[k] = fresh;
+  }
+  for (uint64_t k = 0; k < P; k++) h->distribution[k] = new_starts[k];
+  *d_ops = h->d_moved;
+  *n_out = total;
+  *d_nn = h->d_moved + total;
+  *n_nn = total_nn;
+  return 0;
+}
+int pppcsr_repartition(pppcsr_t h, const uint64_t *new_starts) {
+  PP_CHECK();
+  for (auto *q : h->parts)
+    if (!q) return bad("pppcsr_repartition: not every partition is resident here (use pppcsr_repartition_export + pppcsr_exchange_apply)");
+  const ppcsr_op *d = nullptr, *dn = nullptr;
+  uint64_t n = 0, nn = 0;
+  int rc = pppcsr_repartition_export(h, new_starts, &d, &n, &dn, &nn);
+  if (rc != 0) return rc;
+  rc = pppcsr_apply_batch_device(h, d, n);
+  if (rc != 0) return rc;
+  return pppcsr_set_num_neighbors_device(h, dn, nn);
+}
+// starts of P contiguous vertex ranges of about equal weight, weight(v) = num_neighbors(v) + 1 (edges are what updates
+// cost; the + 1 keeps empty stretches from collapsing into one partition).  All partitions resident.
+int pppcsr_balanced_starts(pppcsr_t h, uint64_t *starts_out) {
+  PP_CHECK();
+  if (!starts_out) return bad("null output");
+  const uint64_t P = h->parts.size();
+  std::vector<uint64_t> w;
+  w.reserve(h->total_n);
+  for (uint64_t k = 0; k < P; k++) {
+    if (!h->parts[k]) return bad("pppcsr_balanced_starts: not every partition is resident here");
+    uint64_t nk = 0;
+    ppcsr_get_n(h->parts[k], &nk);
+    std::vector<ppcsr_node> nodes(nk);
+    if (nk) {
+      int rc = ppcsr_export_state(h->parts[k], nullptr, nodes.data());
+      if (rc != 0) return rc;
+    }
+    for (uint64_t v = 0; v < nk; v++) {
+      const int32_t nn = (int32_t)nodes[v].num_neighbors;  // (a delete of a missing edge can leave it below zero: PCSR.cpp:1409)
+      w.push_back((uint64_t)(nn > 0 ? nn : 0) + 1);
+    }
+  }
+  uint64_t total = 0;
+  for (uint64_t x : w) total += x;
+  uint64_t run = 0, v = 0;
+  starts_out[0] = 0;
+  for (uint64_t k = 1; k < P; k++) {
+    const uint64_t goal = (total * k) / P;  // cumulative weight the first k partitions should reach
+    while (v < w.size() && run + w[v] / 2 < goal) run += w[v++];
+    starts_out[k] = v;
+  }
+  return 0;
+}
 }  // extern "C"

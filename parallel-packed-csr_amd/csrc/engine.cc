@@ -1681,7 +1681,8 @@ int Engine::read_neighbourhood(int src) {
 // the edge array), exclusive scan, then ONE streaming pass that writes dests (array order == CSR order) and row offsets.
 // (A single-kernel decoupled look-back variant was tried and measured slower on MI355X — 110 us vs 85 us at N = 2^24,
 //  1.5 K polling workgroups disturb the streaming loads — and was removed; see the git history, "one-pass bulk neighbour scan".)
-int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap, const float *d_values, float *d_contrib) {
+int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap, const float *d_values, float *d_contrib, Op *d_triples,
+                        uint32_t src_base) {
   Impl &p = *p_;
   const uint64_t N = p.v.g.N, nchunks = (N + 63) / 64;
   bool fresh_state = (p.scan_nchunks != nchunks);  // the sentinel counts are laid out (and left zeroed) per array size
@@ -1705,8 +1706,53 @@ int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap, co
   GPU_LAUNCH(p.stream, k_chunk_counts, ntiles, 256, p.v, d_cs, d_cc, tile, p.d_tiles);
   GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, (ChainTable *)nullptr, (uint64_t)0, (uint64_t)0, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
   GPU_LAUNCH(p.stream, k_scan_write, ntiles, 256, p.v, (const uint32_t *)d_cc, tile, (const uint32_t *)p.d_tiles, d_rows, d_dst, cap,
-             d_values, d_contrib);
+             d_values, d_contrib, d_triples, src_base);
   return PPCSR_OK;
+}
+
+// every edge as (src + src_base, dest, value) in array order (= ascending src, then ascending dest) into d_out (device memory,
+// room for `cap` records; nullptr / 0 only counts).  *total = edges held.  What pppcsr_repartition ships between partitions.
+int Engine::export_num_neighbors_device(uint32_t base, Op *d_out) {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  if (n() == 0) return PPCSR_OK;
+  GPU_LAUNCH(p.stream, k_nn_export, grid_for(n(), 256), 256, p.v, base, d_out);
+  GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
+  return PPCSR_OK;
+}
+int Engine::set_num_neighbors_device(const Op *d_recs, uint64_t cnt) {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  if (cnt == 0) return PPCSR_OK;
+  GPU_LAUNCH(p.stream, k_nn_set, grid_for(cnt, 256), 256, p.v, d_recs, cnt);
+  GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
+  return PPCSR_OK;
+}
+int Engine::export_triples_device(uint32_t src_base, Op *d_out, uint64_t cap, uint64_t *total) {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  int rc = scan_launch(nullptr, nullptr, d_out ? cap : 0, nullptr, nullptr, d_out, src_base);
+  if (rc != PPCSR_OK) return rc;
+  GCHK(gpu::d2h(p.h_total, p.d_total, sizeof(unsigned long long), p.stream));
+  // the last slot belongs to no neighbourhood (the last vertex's `end` is N - 1, PCSR.cpp:87) and the scan leaves it out,
+  // but it can hold an edge (a slide can push one there; the next insert at it doubles the array, PCSR.cpp:992-997)
+  Edge last = null_edge();
+  GCHK(gpu::d2h(&last, p.v.items + (p.v.g.N - 1), sizeof(Edge), p.stream));
+  GCHK(gpu::sync(p.stream));
+  GCHK(gpu::last_error());
+  uint64_t tot = *p.h_total;
+  if (last.value != 0 && !is_sentinel(last)) {
+    if (d_out && tot < cap) {
+      const Op o{last.src + src_base, last.dest, last.value};
+      GCHK(gpu::h2d(d_out + tot, &o, sizeof(Op), p.stream));
+      GCHK(gpu::sync(p.stream));
+    }
+    tot++;
+  }
+  if (total) *total = tot;
+  return (d_out && tot > cap) ? PPCSR_ERANGE : PPCSR_OK;
 }
 
 // ---- bulk build (kernels k_bb_*) -----------------------------------------------------------------------
@@ -2234,7 +2280,7 @@ int Engine::rebalance_bench(uint64_t wlen, int iters, double *ms_per_call) {
   return inplace_fault_check();
 }
 
-int bucket_ops_device(uint32_t init_n, uint32_t n_parts, const Op *d_ops, uint64_t n, Op *d_out, unsigned long long *d_counts,
+int bucket_ops_device(const uint32_t *starts, uint32_t n_parts, const Op *d_ops, uint64_t n, Op *d_out, unsigned long long *d_counts,
                       void *stream, std::string *errmsg) {
   static thread_local uint32_t *d_hist = nullptr;  // per-thread scratch (one rank = one process = one device)
   static thread_local uint64_t hist_cap = 0;
@@ -2253,14 +2299,15 @@ int bucket_ops_device(uint32_t init_n, uint32_t n_parts, const Op *d_ops, uint64
     if (e) return failm("hipMalloc", e);
     hist_cap = need;
   }
-  const uint32_t ps = init_n / n_parts;
+  PartTable tab;
+  for (uint32_t k = 0; k < kMaxParts; k++) tab.start[k] = k < n_parts ? starts[k] : 0xFFFFFFFFu;
   if (n == 0) {
     int e = gpu::dset(d_counts, 0, n_parts * sizeof(unsigned long long), st);
     return e ? failm("hipMemsetAsync", e) : (int)PPCSR_OK;
   }
-  GPU_LAUNCH(st, k_bucket_hist, ntiles, 256, d_ops, n, ps, n_parts, d_hist);
+  GPU_LAUNCH(st, k_bucket_hist, ntiles, 256, d_ops, n, tab, n_parts, d_hist);
   GPU_LAUNCH(st, k_bucket_scan, 1, 64, d_hist, ntiles, n_parts, d_counts);
-  GPU_LAUNCH(st, k_bucket_scatter, ntiles, 256, d_ops, n, ps, n_parts, (const uint32_t *)d_hist, d_out);
+  GPU_LAUNCH(st, k_bucket_scatter, ntiles, 256, d_ops, n, tab, n_parts, (const uint32_t *)d_hist, d_out);
   int e = gpu::last_error();
   return e ? failm("bucket kernels", e) : (int)PPCSR_OK;
 }
@@ -2306,15 +2353,10 @@ Rccl &rccl() {
   return r;
 }
 }  // namespace
-struct ppcsr_xchg {  // one communicator + its stream and staging buffers
+struct ppcsr_xchg {  // one communicator and the stream its transfers run on
   ncclComm_t comm = nullptr;
   int nranks = 0, rank = 0, device = 0;
   gpu::stream_t stream{};
-  ppcsr::Op *d_bucketed = nullptr, *d_send = nullptr, *d_recv = nullptr, *d_out = nullptr;
-  unsigned long long *d_counts = nullptr, *d_seg = nullptr;
-  uint64_t cap_rows = 0, out_cap = 0, bucket_cap = 0;
-  ppcsr::Op *h_hdr = nullptr;            // pinned: the received headers
-  unsigned long long *h_seg = nullptr;  // pinned: segment table for the unpack kernel
   std::string err;
 };
 int capi_xchg_unique_id(void *out128, std::string *err) {
@@ -2347,92 +2389,35 @@ int capi_xchg_destroy(ppcsr_xchg *x) {
   gpu::set_device(x->device);
   gpu::sync(x->stream);
   if (x->comm) rccl().CommDestroy(x->comm);
-  for (void *p : {(void *)x->d_bucketed, (void *)x->d_send, (void *)x->d_recv, (void *)x->d_out, (void *)x->d_counts, (void *)x->d_seg})
-    if (p) gpu::dfree(p);
-  if (x->h_hdr) gpu::hfree(x->h_hdr);
-  if (x->h_seg) gpu::hfree(x->h_seg);
   gpu::stream_destroy(x->stream);
   delete x;
   return 0;
 }
-// bucket this rank's block by owner partition, pack one fixed-capacity chunk per peer, swap the chunks with grouped
-// ncclSend / ncclRecv on the exchange stream (ONE collective step, static sizes, nothing read back before it), read the
-// received headers, unpack into one contiguous stream per local partition (source ranks in order).  out_ptrs / out_counts
-// (ppr entries) describe the result, which stays valid until the next call.
-int capi_xchg_route(ppcsr_xchg *x, uint32_t init_n, uint32_t n_parts, const ppcsr::Op *d_ops, uint64_t n, uint64_t cap,
-                    const ppcsr::Op **out_ptrs, uint64_t *out_counts) {
-  using namespace ppcsr;
+int capi_xchg_ranks(ppcsr_xchg *x, int *nranks, int *rank, int *device, void **stream) {
+  if (!x) return ppcsr::PPCSR_EINVAL;
+  *nranks = x->nranks;
+  *rank = x->rank;
+  *device = x->device;
+  *stream = (void *)x->stream;
+  return 0;
+}
+// The transport step of the owner exchange: ONE grouped set of ncclSend / ncclRecv on the communicator's stream, then a
+// stream sync.  Segment i goes to / comes from peer[i]; empty segments are skipped on both sides (sender and receiver both
+// know the size: the counts were exchanged first), and between one pair of ranks sends and receives match in issue order.
+int capi_xchg_sendrecv(ppcsr_xchg *x, uint64_t nseg, const void *const *sptr, const uint64_t *sbytes, const int *speer, void *const *rptr,
+                       const uint64_t *rbytes, const int *rpeer) {
   Rccl &r = rccl();
-  auto failm = [&](const std::string &m) { x->err = m; return (int)PPCSR_EHIP; };
-  const uint32_t world = (uint32_t)x->nranks;
-  if (n_parts % world || n_parts > kMaxParts) return failm("partitions must be a multiple of the ranks (and at most 64)");
-  const uint32_t ppr = n_parts / world, hrows = (ppr + 2) / 3;
-  if (n > cap) return failm("block larger than the agreed capacity");
-  const uint64_t rows = cap + hrows;
+  auto failm = [&](const std::string &m) { x->err = m; return (int)ppcsr::PPCSR_EHIP; };
   if (gpu::set_device(x->device)) return failm("hipSetDevice failed");
-  if (x->cap_rows < rows) {
-    for (void *p : {(void *)x->d_send, (void *)x->d_recv}) if (p) gpu::dfree(p);
-    x->d_send = x->d_recv = nullptr;
-    x->cap_rows = 0;
-    if (gpu::dmalloc((void **)&x->d_send, (uint64_t)world * rows * sizeof(Op)) || gpu::dmalloc((void **)&x->d_recv, (uint64_t)world * rows * sizeof(Op)))
-      return failm("out of device memory (exchange chunks)");
-    x->cap_rows = rows;
-  }
-  if (x->bucket_cap < std::max<uint64_t>(n, 1)) {
-    if (x->d_bucketed) gpu::dfree(x->d_bucketed);
-    x->d_bucketed = nullptr;
-    if (gpu::dmalloc((void **)&x->d_bucketed, std::max<uint64_t>(n, 1) * sizeof(Op))) return failm("out of device memory");
-    x->bucket_cap = std::max<uint64_t>(n, 1);
-  }
-  if (!x->d_counts && gpu::dmalloc((void **)&x->d_counts, kMaxParts * sizeof(unsigned long long))) return failm("out of device memory");
-  if (!x->d_seg && gpu::dmalloc((void **)&x->d_seg, 3ull * kMaxParts * kMaxParts * sizeof(unsigned long long))) return failm("out of device memory");
-  if (!x->h_hdr && gpu::hmalloc((void **)&x->h_hdr, (uint64_t)kMaxParts * 32 * sizeof(Op))) return failm("out of pinned memory");
-  if (!x->h_seg && gpu::hmalloc((void **)&x->h_seg, 3ull * kMaxParts * kMaxParts * sizeof(unsigned long long))) return failm("out of pinned memory");
-  std::string msg;
-  int rc = bucket_ops_device(init_n, n_parts, d_ops, n, x->d_bucketed, x->d_counts, (void *)x->stream, &msg);
-  if (rc != PPCSR_OK) return failm(msg);
-  GPU_LAUNCH(x->stream, k_xchg_pack, std::max<uint64_t>(1, std::min<uint64_t>(2048, (n + 255) / 256)), 256, (const Op *)x->d_bucketed,
-             (const unsigned long long *)x->d_counts, n, n_parts, ppr, rows, hrows, x->d_send);
   ncclResult_t e = r.GroupStart();
-  for (uint32_t peer = 0; peer < world && e == ncclSuccess; peer++) {
-    e = r.Send(x->d_send + (uint64_t)peer * rows, rows * sizeof(Op), ncclChar, (int)peer, x->comm, x->stream);
-    if (e == ncclSuccess) e = r.Recv(x->d_recv + (uint64_t)peer * rows, rows * sizeof(Op), ncclChar, (int)peer, x->comm, x->stream);
+  for (uint64_t i = 0; i < nseg && e == ncclSuccess; i++) {
+    if (sbytes[i]) e = r.Send(sptr[i], sbytes[i], ncclChar, speer[i], x->comm, x->stream);
+    if (e == ncclSuccess && rbytes[i]) e = r.Recv(rptr[i], rbytes[i], ncclChar, rpeer[i], x->comm, x->stream);
   }
   const ncclResult_t e2 = r.GroupEnd();
   if (e != ncclSuccess || e2 != ncclSuccess) return failm(std::string("RCCL send/recv: ") + r.GetErrorString(e != ncclSuccess ? e : e2));
-  for (uint32_t src = 0; src < world; src++)  // the headers: world x hrows rows of 12 B
-    if (gpu::d2h(x->h_hdr + (uint64_t)src * hrows, x->d_recv + (uint64_t)src * rows, hrows * sizeof(Op), x->stream)) return failm("header copy failed");
   if (gpu::sync(x->stream)) return failm("exchange stream failed");
-  // segment table: partition-major, source-minor
-  unsigned long long total = 0;
-  unsigned long long *ssrc = x->h_seg, *sdst = x->h_seg + kMaxParts * kMaxParts, *slen = x->h_seg + 2 * kMaxParts * kMaxParts;
-  std::vector<unsigned long long> part_first(ppr, 0);
-  for (uint32_t q = 0; q < ppr; q++) {
-    part_first[q] = total;
-    for (uint32_t src = 0; src < world; src++) {
-      const uint32_t *hdr = reinterpret_cast<const uint32_t *>(x->h_hdr + (uint64_t)src * hrows);
-      unsigned long long before = 0;
-      for (uint32_t q2 = 0; q2 < q; q2++) before += hdr[q2];
-      const uint32_t sgi = q * world + src;
-      ssrc[sgi] = (unsigned long long)src * rows + hrows + before;
-      sdst[sgi] = total;
-      slen[sgi] = hdr[q];
-      total += hdr[q];
-    }
-    out_counts[q] = total - part_first[q];
-  }
-  if (x->out_cap < std::max<unsigned long long>(total, 1)) {
-    if (x->d_out) gpu::dfree(x->d_out);
-    x->d_out = nullptr;
-    if (gpu::dmalloc((void **)&x->d_out, std::max<unsigned long long>(total, 1) * sizeof(Op))) return failm("out of device memory");
-    x->out_cap = std::max<unsigned long long>(total, 1);
-  }
-  if (gpu::h2d(x->d_seg, x->h_seg, 3ull * kMaxParts * kMaxParts * sizeof(unsigned long long), x->stream)) return failm("segment table copy failed");
-  GPU_LAUNCH(x->stream, k_xchg_unpack, world * ppr, 1024, (const Op *)x->d_recv, rows, hrows, world, ppr, (const unsigned long long *)x->d_seg,
-             (const unsigned long long *)(x->d_seg + kMaxParts * kMaxParts), (const unsigned long long *)(x->d_seg + 2 * kMaxParts * kMaxParts), x->d_out);
-  if (gpu::sync(x->stream)) return failm("exchange stream failed");
-  if (gpu::last_error()) return failm("exchange kernels failed");
-  for (uint32_t q = 0; q < ppr; q++) out_ptrs[q] = x->d_out + part_first[q];
+  if (gpu::last_error()) return failm("exchange transfers failed");
   return 0;
 }
 const char *capi_xchg_error(ppcsr_xchg *x) { return x ? x->err.c_str() : ""; }
@@ -2442,6 +2427,7 @@ int gpu_device_count_for_capi(int *n) { return gpu::device_count(n); }
 int capi_set_device(int d) { return gpu::set_device(d) ? ppcsr::PPCSR_EHIP : 0; }
 int capi_dev_alloc(void **p, size_t bytes) { return gpu::dmalloc(p, bytes); }
 int capi_dev_free(void *p) { return gpu::dfree(p); }
+int capi_dev_memset(void *p, int byte, size_t bytes, void *stream) { return gpu::dset(p, byte, bytes, gpu::stream_from_ptr(stream)); }
 int capi_d2h_sync(void *dst, const void *src, size_t bytes) {
   gpu::stream_t st = gpu::stream_from_ptr(nullptr);
   int e = gpu::d2h(dst, src, bytes, st);

@@ -47,6 +47,9 @@ class Engine {
   int get_neighbourhood(int src, int *out, uint64_t cap, uint64_t *count);
   int read_neighbourhood(int src);
   int scan_all(uint64_t *row_offsets, int *dests, uint64_t cap, uint64_t *total);
+  int export_triples_device(uint32_t src_base, Op *d_out, uint64_t cap, uint64_t *total);  // edges as adds of the global stream
+  int export_num_neighbors_device(uint32_t base, Op *d_out);       // n records (vertex + base, num_neighbors, 1)
+  int set_num_neighbors_device(const Op *d_recs, uint64_t cnt);    // records (local vertex, num_neighbors, *)
   int scan_all_device(double *ms, uint64_t *total);  // device-only timing of the bulk scan (bench)
   // graph-algorithm consumers over the gapped array (reference: src/utility/bfs.h, src/utility/pagerank.h)
   int bulk_build(const Op *host_ops, uint64_t m, double *device_ms);  // non-parity fast path
@@ -88,7 +91,8 @@ class Engine {
   int run_speculative(const Op *d_ops, uint64_t n);
   int rebalance_fused(const View &nv, const Edge *src_items, uint64_t src_lo, uint64_t src_len, int src_sh, uint32_t *src_cnt,
                       bool inplace, uint64_t tb_index, uint64_t tb_len, Edge *dst, uint64_t dst_bias, uint32_t *dst_cnt, uint64_t dst_nleaves);
-  int scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap, const float *d_values = nullptr, float *d_contrib = nullptr);
+  int scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap, const float *d_values = nullptr, float *d_contrib = nullptr,
+                  Op *d_triples = nullptr, uint32_t src_base = 0);
 
  public:
   struct Impl;
@@ -101,7 +105,8 @@ class Engine {
 
 const char *error_string(int code);
 // stable owner bucketing of a device-resident block of the stream (multi-GPU exchange); runs on `stream`
-int bucket_ops_device(uint32_t init_n, uint32_t n_parts, const Op *d_ops, uint64_t n, Op *d_out, unsigned long long *d_counts,
+// (starts: the first global vertex of each of the n_parts <= 64 partitions, host memory)
+int bucket_ops_device(const uint32_t *starts, uint32_t n_parts, const Op *d_ops, uint64_t n, Op *d_out, unsigned long long *d_counts,
                       void *stream, std::string *errmsg);
 }  // namespace ppcsr
 int gpu_device_count_for_capi(int *n);

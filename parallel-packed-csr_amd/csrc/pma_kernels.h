@@ -1217,6 +1217,25 @@ PMA_KERNEL void k_fill_u32(uint32_t *p, uint64_t n, uint32_t value) {
   for (uint64_t i = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); i < n; i += stride) p[i] = value;
 }
 
+// pppcsr_repartition: num_neighbors travels beside the edges (it is a counter of calls, not the degree: duplicate adds and
+// deletes of missing edges move it, PCSR.cpp:1380/1409).  One record (vertex + base, num_neighbors, 1) per vertex out, and
+// the setter for the records a partition receives (vertex partition-local again after the routing).
+PMA_KERNEL void k_nn_export(View v, uint32_t base, Op *out) {
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t i = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); i < v.g.n; i += stride)
+    out[i] = Op{(uint32_t)i + base, v.nodes[i].num_neighbors, 1u};
+}
+PMA_KERNEL void k_nn_set(View v, const Op *recs, uint64_t n) {
+  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
+  for (uint64_t i = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx(); i < n; i += stride) {
+    const Op r = recs[i];
+    if (r.src < v.g.n) {
+      v.nodes[r.src].num_neighbors = r.dst;
+      v.vdirty[r.src] = v.serial;
+    }
+  }
+}
+
 PMA_KERNEL void k_copy_slots(const Edge *src, Edge *dst, uint64_t len) {
   const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
   uint32_t *d = reinterpret_cast<uint32_t *>(dst);
@@ -1376,10 +1395,11 @@ PMA_KERNEL void k_chunk_counts(View v, uint32_t *chunk_sent, uint32_t *chunkcnt,
 // bulk neighbour scan (CSR export), final streaming pass: one workgroup per tile of chunks.  The tile's chunk counts are
 // scanned in LDS (offset = scanned tile sum + in-tile prefix), then every wave streams its chunks — four in flight —
 // writing dests in array order == CSR order and the row offsets at the sentinels.
-// (contrib != nullptr: also emit, per edge, node_values[src] / num_neighbors(src) — the PageRank push of pagerank.h:21)
+// (contrib != nullptr: also emit, per edge, node_values[src] / num_neighbors(src) — the PageRank push of pagerank.h:21;
+//  triples != nullptr: emit (src + src_base, dest, value) per edge instead of / besides dests)
 PMA_KERNEL void k_scan_write(View v, const uint32_t *__restrict__ chunkcnt, uint32_t tile_chunks, const uint32_t *__restrict__ tile_excl,
                              unsigned long long *__restrict__ row_offsets, int *__restrict__ dests, uint64_t cap,
-                             const float *__restrict__ node_values, float *__restrict__ contrib) {
+                             const float *__restrict__ node_values, float *__restrict__ contrib, Op *__restrict__ triples, uint32_t src_base) {
   PMA_SHARED uint32_t pre[256];
   PMA_SHARED uint32_t wsum[4];
   const int lane = wv::lane(), w = wv::wave_in_block();
@@ -1421,7 +1441,9 @@ PMA_KERNEL void k_scan_write(View v, const uint32_t *__restrict__ chunkcnt, uint
       const bool live = nn && !sent && (s + 1 < N);
       const uint64_t m = wv::ballot(live);
       const unsigned long long o = base + pre[c0 + q] + dev::lanemask_lt_count(m, lane);
-      if (live && o < cap) {
+      if (live && o < cap && triples != nullptr)  // (pppcsr_repartition: the edge as an add of the global stream)
+        triples[o] = Op{e[q].src + src_base, e[q].dest, e[q].value};
+      if (live && o < cap && dests != nullptr) {
         dests[o] = (int)e[q].dest;
         if (contrib != nullptr) {
           if (e[q].dest >= v.g.n) dests[o] = (int)v.g.n;  // (the reference would write out of bounds; keeps the sort keys short)
@@ -2804,10 +2826,18 @@ PMA_KERNEL void o_compact(OptArgs a) {
 constexpr uint32_t kBucketRows = 8;                          // rows of 256 updates per tile
 constexpr uint32_t kBucketTile = 256 * kBucketRows;
 constexpr uint32_t kMaxParts = 64;
-PMA_DEV uint32_t owner_of_src(uint32_t src, uint32_t part_size, uint32_t nparts) {
-  if (part_size == 0) return nparts - 1u;
-  const uint32_t o = src / part_size;
-  return o < nparts ? o : nparts - 1u;
+struct PartTable {  // first global vertex of every partition (PPPCSR::distribution, PPPCSR.h:57), passed by value
+  uint32_t start[kMaxParts];
+};
+// PPPCSR::get_partiton (PPPCSR.cpp:58-66): the last partition whose first vertex is <= src (starts are non-decreasing,
+// start[0] = 0; equal starts — empty partitions — resolve to the last of them, as the reference's linear walk does)
+PMA_DEV uint32_t owner_of_src(uint32_t src, const uint32_t *pstart /* LDS */, uint32_t nparts) {
+  uint32_t lo = 0, hi = nparts;
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (pstart[mid] <= src) lo = mid; else hi = mid;
+  }
+  return lo;
 }
 // counts[w][p] for the 4 waves of one row; returns this lane's rank among same-owner lanes of its wave
 PMA_DEV uint32_t bucket_rank_in_wave(uint32_t owner, bool valid, uint32_t *wave_counts /* [kMaxParts] of this wave */) {
@@ -2824,17 +2854,19 @@ PMA_DEV uint32_t bucket_rank_in_wave(uint32_t owner, bool valid, uint32_t *wave_
   }
   return myrank;
 }
-PMA_KERNEL void k_bucket_hist(const Op *ops, uint64_t n, uint32_t part_size, uint32_t nparts, uint32_t *hist /* [ntiles][nparts] */) {
+PMA_KERNEL void k_bucket_hist(const Op *ops, uint64_t n, PartTable tab, uint32_t nparts, uint32_t *hist /* [ntiles][nparts] */) {
   PMA_SHARED uint32_t cnt[kBucketRows][4][kMaxParts];
+  PMA_SHARED uint32_t pstart[kMaxParts];
   const uint32_t tid = wv::thread_idx();
   const int w = wv::wave_in_block();
   const uint64_t tile = wv::block_idx();
   for (uint32_t i = tid; i < kBucketRows * 4 * kMaxParts; i += 256) (&cnt[0][0][0])[i] = 0;
+  if (tid < kMaxParts) pstart[tid] = tab.start[tid];
   wv::block_sync();
   for (uint32_t r = 0; r < kBucketRows; r++) {
     const uint64_t i = tile * kBucketTile + (uint64_t)r * 256 + tid;
     const bool valid = i < n;
-    const uint32_t owner = valid ? owner_of_src(ops[i].src, part_size, nparts) : 0u;
+    const uint32_t owner = valid ? owner_of_src(ops[i].src, pstart, nparts) : 0u;
     (void)bucket_rank_in_wave(owner, valid, cnt[r][w]);
   }
   wv::block_sync();
@@ -2866,12 +2898,14 @@ PMA_KERNEL void k_bucket_scan(uint32_t *hist, uint64_t ntiles, uint32_t nparts, 
     for (uint64_t t = 0; t < ntiles; t++) hist[t * nparts + tid] += (uint32_t)base;
   }
 }
-PMA_KERNEL void k_bucket_scatter(const Op *ops, uint64_t n, uint32_t part_size, uint32_t nparts, const uint32_t *off, Op *out) {
+PMA_KERNEL void k_bucket_scatter(const Op *ops, uint64_t n, PartTable tab, uint32_t nparts, const uint32_t *off, Op *out) {
   PMA_SHARED uint32_t cnt[kBucketRows][4][kMaxParts];
+  PMA_SHARED uint32_t pstart[kMaxParts];
   const uint32_t tid = wv::thread_idx();
   const int w = wv::wave_in_block();
   const uint64_t tile = wv::block_idx();
   for (uint32_t i = tid; i < kBucketRows * 4 * kMaxParts; i += 256) (&cnt[0][0][0])[i] = 0;
+  if (tid < kMaxParts) pstart[tid] = tab.start[tid];
   wv::block_sync();
   Op mine[kBucketRows];
   uint32_t owner[kBucketRows], rank[kBucketRows];
@@ -2879,7 +2913,7 @@ PMA_KERNEL void k_bucket_scatter(const Op *ops, uint64_t n, uint32_t part_size, 
     const uint64_t i = tile * kBucketTile + (uint64_t)r * 256 + tid;
     const bool valid = i < n;
     mine[r] = valid ? ops[i] : Op{0u, 0u, 0u};
-    owner[r] = valid ? owner_of_src(mine[r].src, part_size, nparts) : 0u;
+    owner[r] = valid ? owner_of_src(mine[r].src, pstart, nparts) : 0u;
     rank[r] = bucket_rank_in_wave(owner[r], valid, cnt[r][w]);
   }
   wv::block_sync();
@@ -2899,54 +2933,10 @@ PMA_KERNEL void k_bucket_scatter(const Op *ops, uint64_t n, uint32_t part_size, 
     if (i < n) {
       const uint32_t p = owner[r];
       Op o = mine[r];
-      o.src = o.src - p * part_size;  // partition-local source, global destination (PPPCSR.cpp:46-52)
+      o.src = o.src - pstart[p];  // partition-local source, global destination (PPPCSR.cpp:46-52)
       out[(uint64_t)off[tile * nparts + p] + cnt[r][w][p] + rank[r]] = o;
     }
   }
-}
-
-// ---- native exchange (pppcsr_exchange_apply): fixed-capacity chunks, one per peer ------------------------------------
-// chunk layout (rows of 12 B): [hrows header rows holding the ppr bucket sizes | the peer's ppr buckets back to back | padding]
-// k_xchg_pack: bucketed ops (grouped by partition) -> send chunks; counts[P] on the device, nothing read back by the host
-PMA_KERNEL void k_xchg_pack(const Op *bucketed, const unsigned long long *counts, uint64_t n, uint32_t nparts, uint32_t ppr, uint64_t rows,
-                            uint32_t hrows, Op *send) {
-  PMA_SHARED unsigned long long off[kMaxParts + 1];
-  if (wv::thread_idx() == 0) {
-    unsigned long long run = 0;
-    for (uint32_t p = 0; p < nparts; p++) {
-      off[p] = run;
-      run += counts[p];
-    }
-    off[nparts] = run;
-  }
-  wv::block_sync();
-  const uint64_t stride = (uint64_t)wv::grid_dim() * wv::block_dim();
-  const uint64_t gid = (uint64_t)wv::block_idx() * wv::block_dim() + wv::thread_idx();
-  const uint32_t world = nparts / ppr;
-  for (uint64_t i = gid; i < (uint64_t)world * hrows * 3ull; i += stride) {  // headers
-    const uint32_t peer = (uint32_t)(i / (hrows * 3ull)), w = (uint32_t)(i % (hrows * 3ull));
-    uint32_t *hdr = reinterpret_cast<uint32_t *>(send + (uint64_t)peer * rows);
-    hdr[w] = (w < ppr) ? (uint32_t)counts[peer * ppr + w] : 0u;
-  }
-  for (uint64_t i = gid; i < n; i += stride) {
-    uint32_t p = 0;  // partition of bucketed row i (nparts <= 64: a short scan of the prefix)
-    while (p + 1 < nparts && off[p + 1] <= i) p++;
-    const uint32_t peer = p / ppr;
-    send[(uint64_t)peer * rows + hrows + (i - off[peer * ppr])] = bucketed[i];
-  }
-}
-// k_xchg_unpack: received chunks -> one contiguous stream per local partition, source ranks in order (= global stream order).
-// starts[q * world + r] = first output row of (partition q, source r) inside out_q; the host computed them from the headers.
-PMA_KERNEL void k_xchg_unpack(const Op *recv, uint64_t rows, uint32_t hrows, uint32_t world, uint32_t ppr, const unsigned long long *seg_src,
-                              const unsigned long long *seg_dst, const unsigned long long *seg_len, Op *out) {
-  // one (partition, source) segment per blockIdx.y-less flat index: grid-stride over segments, threads over rows
-  const uint32_t nseg = world * ppr;
-  for (uint32_t sgi = wv::block_idx(); sgi < nseg; sgi += wv::grid_dim()) {
-    const unsigned long long len = seg_len[sgi], so = seg_src[sgi], dofs = seg_dst[sgi];
-    for (unsigned long long i = wv::thread_idx(); i < len; i += wv::block_dim()) out[dofs + i] = recv[so + i];
-  }
-  (void)rows;
-  (void)hrows;
 }
 
 }  // namespace ppcsr

@@ -151,3 +151,45 @@ def slide_off_end_stream():
     import numpy as np
     src = np.array(SLIDE_OFF_END_SRC, np.uint32)
     return np.stack([src, np.arange(len(src), dtype=np.uint32), np.ones(len(src), np.uint32)], 1)
+
+
+def live_triples(items, base=0):
+    """every edge of a raw edges[] export as (src + base, dest, value), array order (sentinels and empty slots dropped; the
+    last slot included — see Engine::export_triples_device)"""
+    it = np.asarray(items, np.uint32).reshape(-1, 3)
+    live = (it[:, 2] != 0) & (it[:, 1] != 0xFFFFFFFF) & (it[:, 2] != 0xFFFFFFFF)
+    out = it[live].copy()
+    out[:, 0] += np.uint32(base)
+    return out
+
+
+def oracle_repartition(parts, old_starts, new_starts, total_n, make):
+    """the rule of pppcsr_repartition (include/ppcsr.h) restated over per-partition oracles: partitions whose vertex range
+    changes are recreated empty (make(size)) and receive, in ascending (src, dest) order, the edges of all changed
+    partitions that now fall into their range, then every vertex's num_neighbors as it was; the others are left as they
+    are.  Returns the new list of partitions."""
+    P = len(parts)
+    end = lambda st, k: int(st[k + 1]) if k + 1 < P else int(total_n)
+    changed = [int(old_starts[k]) != int(new_starts[k]) or end(old_starts, k) != end(new_starts, k) for k in range(P)]
+    moved = [live_triples(parts[k].state()[0], int(old_starts[k])) for k in range(P) if changed[k]]
+    moved = np.concatenate(moved) if moved else np.zeros((0, 3), np.uint32)
+    nn = {}  # num_neighbors travels with the vertex (a counter of calls, not the degree)
+    for k in range(P):
+        if changed[k]:
+            for v, c in enumerate(parts[k].state()[1][:, 2]):
+                nn[int(old_starts[k]) + v] = int(c)
+    out = []
+    for k in range(P):
+        if not changed[k]:
+            out.append(parts[k])
+            continue
+        lo, hi = int(new_starts[k]), end(new_starts, k)
+        o = make(hi - lo)
+        sub = moved[(moved[:, 0] >= lo) & (moved[:, 0] < hi)].copy()
+        sub[:, 0] -= np.uint32(lo)
+        if len(sub):
+            o.apply(sub)  # (src, dest, op = value): an add of that value
+        for v in range(lo, hi):
+            o.set_num_neighbors(v - lo, nn[v])
+        out.append(o)
+    return out

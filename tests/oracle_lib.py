@@ -49,6 +49,7 @@ def _load_oracle():
     L.po_get_stats.argtypes = [c_vp, c_vp]
     L.po_reset_stats.argtypes = [c_vp]
     L.po_debug_redistribute.argtypes = [c_vp, c_u64, c_u64]
+    L.po_set_num_neighbors.argtypes = [c_vp, c_u32, c_u32]
     L.po_redistribute_positions.argtypes = [c_u64, c_u64, c_u64, c_vp]
     L.pop_create.restype = c_vp
     L.pop_create.argtypes = [c_u32, c_u32, c_int, c_int, c_int]
@@ -150,6 +151,7 @@ class Oracle(_State):
         return dict(zip(STAT_FIELDS, list(buf)))
     def reset_stats(self): self.L.po_reset_stats(self.h)
     def debug_redistribute(self, index, length): self.L.po_debug_redistribute(self.h, index, length)
+    def set_num_neighbors(self, v, nn): self.L.po_set_num_neighbors(self.h, int(v), int(nn))
 
 
 class OraclePPPCSR:

@@ -117,3 +117,123 @@ def test_exchange_parts_world2(n_global, n_parts):
                 exp = glob[owner == part].copy()
                 exp[:, 0] -= np.uint32(pp.partition_start(part))
                 np.testing.assert_array_equal(got[r][k][ql], exp, err_msg=f"step {k} partition {part}")
+
+
+# ---- the engine library's own exchange (pppcsr_xchg_pack / _layout / _apply) past one rank: two CPU-emulator processes, gloo as
+# ---- the carrier.  Everything but the ncclSend/ncclRecv calls of pppcsr_exchange_apply is the code the GPU build runs.
+def _sim_tune(pp, ks):
+    for k in ks:
+        e = pp.partition(k)
+        for key, v in dict(mode=1, opt_horizon=64, epoch_ops=1024, region_slots=64, small_batch=0, big_grid=2, big_min=512,
+                           big_window=131072, max_horizon=32, min_horizon=4, init_horizon=8, rounds_per_sync=2).items():
+            e.set_option(key, v)
+
+
+def _gloo_exchange(pp, world, rank, ppr, blk, set_nn=False):
+    """one batch through pack -> (gloo) -> layout -> apply.  blk: this rank's block, a (n,3) uint32 array or a (address, n) pair"""
+    import ctypes
+    addr, n = (blk.ctypes.data, len(blk)) if isinstance(blk, np.ndarray) else blk
+    counts, d_send = pp.xchg_pack(addr, n)
+    send = np.ctypeslib.as_array((ctypes.c_uint32 * (3 * max(n, 1))).from_address(d_send)).reshape(-1, 3)[:n] if n else np.zeros((0, 3), np.uint32)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    # carrier step 1: the counts (every rank learns what every source holds for its partitions)
+    allc = [torch.zeros(world * ppr, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allc, torch.from_numpy(counts.astype(np.int64)))
+    recv_counts = np.concatenate([allc[r].numpy()[rank * ppr:(rank + 1) * ppr] for r in range(world)]).astype(np.uint64)
+    dst = pp.xchg_layout(recv_counts)
+    # carrier step 2: the rows, one message per peer, scattered to the addresses the layout asked for
+    reqs, inbox = [], {}
+    for r in range(world):
+        if r == rank:
+            continue
+        out = torch.from_numpy(send[off[r * ppr]:off[(r + 1) * ppr]].copy().view(np.int32).reshape(-1))
+        inbox[r] = torch.zeros(int(recv_counts[r * ppr:(r + 1) * ppr].sum()) * 3, dtype=torch.int32)
+        if out.numel():
+            reqs.append(dist.isend(out, r))
+        if inbox[r].numel():
+            reqs.append(dist.irecv(inbox[r], r))
+    for q in reqs:
+        q.wait()
+    for r in range(world):
+        rows = send[off[r * ppr]:off[(r + 1) * ppr]] if r == rank else inbox[r].numpy().view(np.uint32).reshape(-1, 3)
+        rows = np.ascontiguousarray(rows)
+        o = 0
+        for q in range(ppr):
+            c = int(recv_counts[r * ppr + q])
+            if c:
+                ctypes.memmove(dst[r * ppr + q], rows[o:o + c].ctypes.data, c * 12)
+            o += c
+    pp.xchg_set_num_neighbors() if set_nn else pp.xchg_apply()
+
+
+def _worker_native(rank, world, port, n_global, n_parts, blocks, new_starts, after, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import load_pkg
+    from test_sim_engine import SIM_SO
+    pkg = load_pkg()
+    lib = pkg.load_library(SIM_SO)
+    ppr = n_parts // world
+    mine = range(rank * ppr, (rank + 1) * ppr)
+    pp = pkg.PPPCSR(n_global, numDomain=world, partitionsPerDomain=ppr, lib=lib, local=(rank * ppr, ppr, 0))
+    _sim_tune(pp, mine)
+    pp.xchg_create(world, rank)
+    for blk in blocks[rank]:
+        _gloo_exchange(pp, world, rank, ppr, blk)
+    snap = [(pp.partition(k).state(), pp.partition(k).geometry()) for k in mine]
+    # repartition across the ranks: the edges on the move are one more block of the global stream
+    moved, nn_recs = pp.repartition_export(new_starts)
+    _sim_tune(pp, mine)
+    _gloo_exchange(pp, world, rank, ppr, moved)
+    _gloo_exchange(pp, world, rank, ppr, nn_recs, set_nn=True)
+    mid = [(pp.partition(k).state(), pp.partition(k).geometry()) for k in mine]
+    _gloo_exchange(pp, world, rank, ppr, after[rank])
+    end = [(pp.partition(k).state(), pp.partition(k).geometry()) for k in mine]
+    q.put((rank, [[digest(*s, g) for s, g in x] for x in (snap, mid, end)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_global,n_parts", [(600, 4), (403, 2)])
+def test_native_exchange_and_repartition_world2_hostsim(n_global, n_parts):
+    from oracle_lib import Oracle, OraclePPPCSR
+    from helpers import oracle_repartition
+    from test_sim_engine import build_sim
+    build_sim()
+    streams = load_streams()
+    world, ppr = 2, n_parts // 2
+    sizes = [[1500, 1], [0, 1200]]  # ragged and empty blocks
+    blocks = [[streams.random_stream(n_global, sizes[k][r], seed=70 + 5 * k + r, p_delete=0.25) for k in range(2)] for r in range(world)]
+    after = [streams.random_stream(n_global, 700, seed=170 + r, p_delete=0.4) for r in range(world)]
+    pp = OraclePPPCSR(n_global, True, world, ppr)
+    old = np.array([pp.partition_start(k) for k in range(n_parts)], np.uint64)
+    # vertex ranges move across the rank boundary (partition ppr - 1 / ppr) as well as inside a rank
+    new = old.copy()
+    new[ppr] = old[ppr] - min(37, int(old[ppr] - old[ppr - 1]))
+    if ppr > 1:
+        new[1] = old[1] + 11
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_native, args=(r, world, port, n_global, n_parts, blocks, new, after, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in range(2):
+        pp.apply(np.concatenate([blocks[r][k] for r in range(world)]))
+    parts = [pp.partition(k) for k in range(n_parts)]
+    dg = lambda ps: [digest(*p.state(), p.geometry()) for p in ps]
+    assert [d for r in range(world) for d in got[r][0]] == dg(parts), "after the exchanged batches"
+    parts = oracle_repartition(parts, old, new, n_global, lambda m: Oracle(m))
+    assert [d for r in range(world) for d in got[r][1]] == dg(parts), "after the repartition"
+    glob = np.concatenate(after)
+    own = np.searchsorted(new, glob[:, 0], side="right") - 1
+    for k in range(n_parts):
+        sub = glob[own == k].copy()
+        sub[:, 0] -= np.uint32(new[k])
+        parts[k].apply(sub)
+    assert [d for r in range(world) for d in got[r][2]] == dg(parts), "updates after the repartition"

@@ -570,19 +570,19 @@ def test_bucket_ops_device_matches_host_routing(pkg, streams):
 
 def test_native_rccl_exchange_single_rank(pkg, streams):
     """pppcsr_exchange_apply with a one-rank RCCL communicator (all a one-GPU box can run: RCCL refuses two ranks on one
-    device): device bucketing -> chunk packing -> grouped ncclSend / ncclRecv to self -> unpack -> concurrent per-partition
-    apply, against the oracle's PPPCSR partition by partition.  The multi-rank routing rule itself is covered by the
-    gloo tests (same chunk layout, torch carrier)."""
+    device): device bucketing -> counts to self -> rows to self (grouped ncclSend / ncclRecv, landing where the partition
+    streams want them) -> concurrent per-partition apply, against the oracle's PPPCSR partition by partition.  Past one rank
+    the same pack / layout / apply code runs in tests/test_exchange_gloo.py (two emulator processes, gloo as the carrier)."""
     import torch
     n, P = 50000, 8
     o = OraclePPPCSR(n, True, 1, P)
     pp = pkg.PPPCSR(n, numDomain=1, partitionsPerDomain=P, local=(0, P, 0))
     pp.comm_create(pkg.PPPCSR.comm_unique_id(), 1, 0, 0)
-    for k in range(3):
-        ops = streams.random_stream(n, [200000, 1, 70000][k], seed=60 + k, p_delete=0.25)
-        t = torch.from_numpy(ops.view(np.int32)).cuda()
+    for k in range(4):
+        ops = streams.random_stream(n, [200000, 1, 0, 70000][k], seed=60 + k, p_delete=0.25)
+        t = torch.from_numpy(ops.view(np.int32).copy()).cuda()
         torch.cuda.synchronize()
-        pp.exchange_apply(t.data_ptr(), len(ops), 200000)
+        pp.exchange_apply(t.data_ptr() if len(ops) else 0, len(ops))
         o.apply(ops)
     for k in range(P):
         a, b = pp.partition(k), o.partition(k)
@@ -590,6 +590,101 @@ def test_native_rccl_exchange_single_rank(pkg, streams):
         ei, en = a.state()
         oi, on = b.state()
         assert np.array_equal(ei, oi) and np.array_equal(en, on), f"partition {k}"
+    pp.close()
+    # a handle that does not hold exactly the communicator's range is refused (here: 4 of 8 partitions, one rank)
+    half = pkg.PPPCSR(n, numDomain=2, partitionsPerDomain=4, local=(0, 4, 0))
+    half.comm_create(pkg.PPPCSR.comm_unique_id(), 1, 0, 0)
+    t = torch.zeros((4, 3), dtype=torch.int32).cuda()
+    with pytest.raises(pkg.PpcsrError):
+        half.exchange_apply(t.data_ptr(), 4)
+    half.close()
+
+
+def test_xchg_steps_single_rank(pkg, streams):
+    """pack -> layout -> apply with the rows moved by the caller (device-to-device copies through torch): the carrier-free form
+    of the exchange, on the GPU build"""
+    import torch
+    n, P = 30000, 4
+    o = OraclePPPCSR(n, True, 1, P)
+    pp = pkg.PPPCSR(n, numDomain=1, partitionsPerDomain=P)
+    pp.xchg_create(1, 0)
+    for k in range(2):
+        ops = streams.random_stream(n, 120000, seed=80 + k, p_delete=0.3)
+        t = torch.from_numpy(ops.view(np.int32).copy()).cuda()
+        torch.cuda.synchronize()
+        cnt, d_send = pp.xchg_pack(t.data_ptr(), len(ops))
+        ref, ref_cnt = pkg.bucket_ops(n, P, ops)
+        np.testing.assert_array_equal(cnt, ref_cnt)
+        dst = pp.xchg_layout(cnt)
+        off = 0
+        for q in range(P):
+            c = int(cnt[q])
+            rows = torch.from_numpy(ref[off:off + c].view(np.int32).copy()).cuda()  # what the bucketed block holds for q
+            torch.cuda.synchronize()
+            pkg.load_library().ppcsr_device_count()
+            _d2d(dst[q], rows.data_ptr(), c * 12)
+            off += c
+        pp.xchg_apply()
+        o.apply(ops)
+    for k in range(P):
+        a, b = pp.partition(k), o.partition(k)
+        assert digest(*a.state(), a.geometry()) == digest(*b.state(), b.geometry()), f"partition {k}"
+    pp.close()
+
+
+def _d2d(dst, src, nbytes):
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert nbytes == 0 or hip.hipMemcpy(dst, src, nbytes, 3) == 0  # hipMemcpyDeviceToDevice
+    assert hip.hipDeviceSynchronize() == 0
+
+
+@pytest.mark.parametrize("P", [4, 8])
+def test_repartition(pkg, streams, P):
+    """pppcsr_repartition: edge set, num_neighbors and PMA invariants survive; partitions whose range stays keep
+    their array bit for bit; partitions that change equal the oracle rebuilt by the same rule (tests/helpers.py
+    oracle_repartition); updates applied afterwards stay bit-exact.  Skewed graph (RMAT labels), balanced starts."""
+    from helpers import check_pma_invariants, oracle_repartition
+    n = 1 << 14
+    s_, d_ = streams.rmat_edges(14, 150000, seed=7)
+    core = streams.adds(s_, d_)
+    pp = pkg.PPPCSR(n, numDomain=1, partitionsPerDomain=P)
+    o = OraclePPPCSR(n, True, 1, P)
+    pp.apply(core)
+    o.apply(core)
+    parts = [o.partition(k) for k in range(P)]
+    old = np.array([pp.partition_start(k) for k in range(P)], np.uint64)
+    before = [int(parts[k].state()[1][:, 2].astype(np.int64).sum()) for k in range(P)]
+    adj_before = {v: pp.get_neighbourhood(v).copy() for v in range(0, n, 97)}
+    st = pp.balanced_starts()
+    assert st[0] == 0 and np.all(np.diff(st.astype(np.int64)) >= 0)
+    for new in (st, old):  # to the balanced layout and back to the uniform one
+        parts = oracle_repartition(parts, old, new, n, lambda m: Oracle(m))
+        pp.repartition(new)
+        assert pp.get_n() == n
+        for k in range(P):
+            a, b = pp.partition(k), parts[k]
+            assert a.get_n() == b.get_n()
+            ai, an = a.state()
+            assert digest(ai, an, a.geometry()) == digest(*b.state(), b.geometry()), f"partition {k} after {new}"
+            assert a.check_invariants() == 0
+            check_pma_invariants(ai, an)
+        for v, adj in adj_before.items():
+            np.testing.assert_array_equal(pp.get_neighbourhood(v), adj)
+        upd = streams.mixed_existing_stream(core[:50000], streams.random_stream(n, 30000, seed=int(new[1]) % 1000), seed=11)
+        pp.apply(upd)
+        own = np.searchsorted(new, upd[:, 0], side="right") - 1
+        for k in range(P):
+            sub = upd[own == k].copy()
+            sub[:, 0] -= np.uint32(new[k])
+            parts[k].apply(sub)
+            a = pp.partition(k)
+            assert digest(*a.state(), a.geometry()) == digest(*parts[k].state(), parts[k].geometry()), f"updates after {new}: {k}"
+        adj_before = {v: pp.get_neighbourhood(v).copy() for v in range(0, n, 97)}
+        old = new
+    after = [int(parts[k].state()[1][:, 2].astype(np.int64).sum()) for k in range(P)]
+    assert max(before) > 2 * min(before)  # (the raw RMAT labels were skewed to begin with)
     pp.close()
 
 

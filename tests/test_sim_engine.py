@@ -476,3 +476,73 @@ def test_sim_bucket_kernels(streams):
         assert rc == 0
         np.testing.assert_array_equal(counts, ref_counts)
         np.testing.assert_array_equal(out, ref)
+
+
+def test_sim_xchg_steps_and_repartition(streams):
+    """one rank of the exchange (pack -> layout -> apply, the rows copied by hand) and pppcsr_repartition under the emulator:
+    unequal starts go through the boundary table of the bucketing kernels; the oracle mirror of the repartition rule is
+    tests/helpers.py oracle_repartition"""
+    import ctypes
+    from helpers import oracle_repartition
+    from oracle_lib import OraclePPPCSR
+    build_sim()
+    pkg = load_pkg()
+    lib = pkg.load_library(SIM_SO)
+    n, P = 300, 4
+    pp = pkg.PPPCSR(n, numDomain=1, partitionsPerDomain=P, lib=lib)
+
+    def tune():
+        for k in range(P):
+            e = pp.partition(k)
+            for key, v in dict(mode=1, opt_horizon=64, epoch_ops=1024, region_slots=64, small_batch=0, big_grid=2, big_min=512,
+                               big_window=131072, max_horizon=32, min_horizon=4, init_horizon=8, rounds_per_sync=2).items():
+                e.set_option(key, v)
+
+    def same(parts, label):
+        for k in range(P):
+            a, b = pp.partition(k), parts[k]
+            assert a.get_n() == b.get_n(), label
+            assert digest(*a.state(), a.geometry()) == digest(*b.state(), b.geometry()), f"{label}: partition {k}"
+
+    tune()
+    ops = streams.random_stream(n, 1200, seed=5, p_delete=0.2)
+    pp.xchg_create(1, 0)
+    cnt, d_send = pp.xchg_pack(ops.ctypes.data, len(ops))
+    assert int(cnt.sum()) == len(ops)
+    with pytest.raises(pkg.PpcsrError):  # a rank knows what it sends to itself
+        pp.xchg_layout(cnt[::-1].copy() + np.uint64(1))
+    dst = pp.xchg_layout(cnt)
+    off = 0
+    for q in range(P):
+        ctypes.memmove(dst[q], d_send + off * 12, int(cnt[q]) * 12)
+        off += int(cnt[q])
+    pp.xchg_apply()
+    with pytest.raises(pkg.PpcsrError):  # nothing packed
+        pp.xchg_apply()
+    o = OraclePPPCSR(n, True, 1, P)
+    o.apply(ops)
+    parts = [o.partition(k) for k in range(P)]
+    same(parts, "exchange")
+    old = np.array([pp.partition_start(k) for k in range(P)], np.uint64)
+    st = pp.balanced_starts()
+    assert st[0] == 0 and np.all(np.diff(st.astype(np.int64)) >= 0) and st[-1] <= n
+    with pytest.raises(pkg.PpcsrError):
+        pp.repartition(np.array([0, 150, 100, 200], np.uint64))
+    for new in (np.array([0, 50, 50, 299], np.uint64), st):
+        parts = oracle_repartition(parts, old, new, n, lambda m: Oracle(m))
+        (d_moved, n_moved), (d_nn, n_nn) = pp.repartition_export(new)  # (pppcsr_repartition = these three steps; the recreated
+        tune()                                                           #  engines get the emulator-sized options before they run)
+        pp.apply_device(d_moved, n_moved)
+        pp.set_num_neighbors_device(d_nn, n_nn)
+        assert [pp.partition_start(k) for k in range(P)] == [int(x) for x in new]
+        same(parts, f"repartition {new}")
+        ops2 = streams.random_stream(n, 500, seed=6 + int(new[1]), p_delete=0.3)
+        pp.apply(ops2)
+        own = np.searchsorted(new, ops2[:, 0], side="right") - 1
+        assert [pp.get_partiton(int(v)) for v in ops2[:50, 0]] == [int(x) for x in own[:50]]
+        for k in range(P):
+            sub = ops2[own == k].copy()
+            sub[:, 0] -= np.uint32(new[k])
+            parts[k].apply(sub)
+        same(parts, f"updates after {new}")
+        old = new
