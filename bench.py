@@ -278,13 +278,16 @@ def main():
             es = [pp.partition(rank * ppr + q) for q in range(ppr)]
             if N > 1 and carrier["use_native"]:
                 pp.comm_create(new_uid(), N, rank, dev_id)
+        apply_options(es)
+        return pp, es
+
+    def apply_options(es):
         for e in es:
             if args.mode >= 0:
                 e.set_option("mode", args.mode)
             for kv in args.opt:
                 k, v = kv.split("=")
                 e.set_option(k, int(v))
-        return pp, es
 
     def sum_stats(es):
         tot = {}
@@ -310,8 +313,9 @@ def main():
             return
         torch_exchange_apply(pp, ops_dev, n_global)
 
-    def run_workload(wl_, label, steps, warmup, want_profile):
-        """core load (untimed), snapshot, warm-up, timed steps [, profiled replay]; returns a result dict"""
+    def run_workload(wl_, label, steps, warmup, want_profile, after_core=None):
+        """core load (untimed), snapshot, warm-up, timed steps [, profiled replay]; returns a result dict.
+        after_core(pp, es) -> es: hook between the core load and the snapshot (the repartitioning leg)"""
         t0 = time.time()
         core_blk = wl_.core(rank * my_core, my_core)
         nb = max(1, min(args.distinct_batches, warmup + steps))
@@ -328,6 +332,8 @@ def main():
         st = sum_stats(es)
         log(rank, f"{label}: core loaded in {time.time() - t0:.1f}s: N={st['N']} logN={st['logN']} rounds={st['rounds']} "
                   f"exclusive={st['exclusive_ops']} doubles={st['double_calls']} rollbacks={st['rollbacks']}")
+        if after_core is not None:
+            es = after_core(pp, es)
         for e in es:
             e.snapshot()
         upd_dev = [to_dev(u) for u in upd]
@@ -526,6 +532,32 @@ def main():
                           f"one batch of {len(seq_upd)} updates in stream order on one host thread ({tc:.2f}s) — the sequential order is "
                           "the parity semantics"),
                "cores_visible": cores}
+        if cfg in (4, 5) or args.zipf:
+            # configs #4 / #5: the reference's own pools (-pppcsrnuma -partitions_per_domain=8, thread sweep) on the GPU box's host
+            # cores.  One run loads the 100 M-edge core for 12 s and needs 1.6 GB of text files, so the sweep is a protocol of
+            # its own (tools/cpu_baseline_protocol.py ... 4|5, same generator and seeds as this workload) whose committed
+            # record is attached here; the live sample above stays the bounded one.
+            ppath = os.path.join(ROOT, "profiles", f"r03_cpu_baseline_config{5 if (cfg == 5 or args.zipf) else 4}.json")
+            if os.path.exists(ppath):
+                try:
+                    pj = json.load(open(ppath))
+                    best = pj.get("best")
+                    cpu["reference_pools"] = {"file": os.path.relpath(ppath, ROOT), "workload": pj.get("workload"), "best": best,
+                                              "cores_available": pj.get("cores_available_to_this_process"), "cpu_model": pj.get("cpu_model"),
+                                              "runs": {k: {"threads": v["threads"], "updates_per_s_mean": v["updates_per_s_mean"],
+                                                           "updates_per_s_std": v["updates_per_s_std"], "repetitions": v["repetitions"]}
+                                                       for k, v in pj.get("runs", {}).items()}}
+                    if best:
+                        cpu["one_thread_sequential"] = cpu["value"]
+                        cpu["value"] = pj["runs"][best]["updates_per_s_mean"]
+                        cpu["cores"] = pj["runs"][best]["threads"]
+                        cpu["kind"] = "reference"
+                        cpu["sample"] = (f"reference CLI -pppcsrnuma -partitions_per_domain=8 -threads={cpu['cores']} on this workload's text files "
+                                         f"(core = phase 1, untimed; first update batch = phase 2), mean of {pj['runs'][best]['repetitions']} runs, "
+                                         f"recorded by tools/cpu_baseline_protocol.py in {os.path.relpath(ppath, ROOT)}; live in this run: "
+                                         + cpu["sample"])
+                except Exception as e:
+                    cpu["reference_pools_error"] = str(e)
         ref_cli = os.path.join(ROOT, "oracle", "_ref", "ref_cli")
         if os.path.exists(ref_cli) and not args.no_ref_cli and cfg == 2:
             # the north_star's comparison: the reference's -pppcsrnuma path on the same box's host cores.  Text edge lists in
@@ -630,10 +662,12 @@ def main():
         res["pp"].close()
     res = None
 
-    def side_leg(key, wl_, steps, warmup, check):
+    def side_leg(key, wl_, steps, warmup, check, after_core=None, more=None):
         try:
-            r = run_workload(wl_, key, steps, warmup, False)
+            r = run_workload(wl_, key, steps, warmup, False, after_core=after_core)
             out = {"workload": wl_.name(P, N), "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": steps, "engine": r["engine"]}
+            if more:
+                out.update(more)
             if check and not args.no_check:
                 ok, against, osecs, nops = parity_check(wl_, r)
                 out["parity_checked"] = ok
@@ -653,6 +687,27 @@ def main():
         # the same graph with raw labels (the faithful input: partition 0 holds 44 % of the edges), and config #5's stream
         if permute:
             side_leg("raw_labels", Workload(streams, 4, n_global, scale, core_edges, batch, False), max(1, min(args.steps, 2)), 1, False)
+            if N == 1:
+                # the same raw-label graph after pppcsr_repartition to balanced vertex ranges (no reference
+                # behaviour to compare with — the repartitioning tests hold the rule): what balancing buys on the skewed input
+                info = {}
+
+                def rebalance_parts(pp_, es_):
+                    before = [int(e.stats()["N"]) for e in es_]
+                    st_new = pp_.balanced_starts()
+                    t_r = time.perf_counter()
+                    pp_.repartition(st_new)
+                    t_r = time.perf_counter() - t_r
+                    es2 = [pp_.partition(q) for q in range(P)]
+                    apply_options(es2)
+                    info.update({"starts": [int(x) for x in st_new], "repartition_s": t_r, "N_slots_before": before,
+                                 "N_slots_after": [int(e.stats()["N"]) for e in es2],
+                                 "note": "raw labels, vertex ranges moved to equal (num_neighbors + 1) weight by pppcsr_repartition after the core "
+                                         "load; compare with raw_labels (uniform ranges)"})
+                    return es2
+
+                side_leg("raw_labels_repartitioned", Workload(streams, 4, n_global, scale, core_edges, batch, False), max(1, min(args.steps, 2)), 1,
+                         False, after_core=rebalance_parts, more=info)
         side_leg("config5_zipf", Workload(streams, 5, n_global, scale, core_edges, batch, permute), 1, 1, True)
     if not args.no_secondary and cfg == 2 and N == 1 and not args.zipf:
         # config #3 and the config #5 stream shape on this one-GPU graph

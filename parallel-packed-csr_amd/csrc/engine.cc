@@ -145,6 +145,9 @@ struct Engine::Impl {
   uint32_t rb_tile = 0;          // leaves per rebalance tile (power of two <= 256); 0 = pick per window
   uint32_t rb_min_tiles = 4096;  // auto tile: shrink the tile until the window has at least this many
   uint32_t rb_prefetch = 1;  // 1: four chunks in flight per wave, 0: one
+  uint32_t rb_run = 0;       // destination tiles per workgroup of k_rb_gather (0: so that about rb_run_wgs workgroups are launched)
+  uint32_t rb_run_wgs = 2048;
+  uint32_t rb_gather = 0;    // 1: destination-centric final pass (k_rb_gather: LDS image of the tile, 16-byte stores; measured slower: DESIGN.md section 9), 0: k_rb_scatter
   uint64_t rb_inplace_min = 1ull << 19;  // partial windows of at least this many slots are rebalanced in place (0 = never)
   uint32_t rb_inplace_cpw = 0;   // 64-slot chunks per wave of an in-place tile (8 or 16; 0 = by window size)
   uint32_t *d_ip = nullptr;      // in-place rebalance: header (sticky error, ticket counters), tile order, the tiles' flags
@@ -586,6 +589,18 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "rb_inplace_min") {
     p.rb_inplace_min = value < 0 ? 0ull : (uint64_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "rb_run") {
+    p.rb_run = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 4096));
+    return PPCSR_OK;
+  }
+  if (k == "rb_run_wgs") {
+    p.rb_run_wgs = (uint32_t)std::max<int64_t>(64, value);
+    return PPCSR_OK;
+  }
+  if (k == "rb_gather") {
+    p.rb_gather = value ? 1u : 0u;
     return PPCSR_OK;
   }
   if (k == "rb_prefetch") {
@@ -1414,13 +1429,26 @@ int Engine::rebalance_fused(const View &nv, const Edge *src_items, uint64_t src_
   if (rc == PPCSR_OK) rc = ensure_tiles(ntiles);
   if (rc != PPCSR_OK) return rc;
   // (inplace: a window of the live array, src_cnt = its slice of the live leaf counts -> the matching slice of the dirty tags)
+  const int dsh = nv.g.sh;
+  const bool gather = p.rb_gather && dsh >= 2 && dsh <= 10 && (tb_index & ((1ull << dsh) - 1)) == 0 && (tb_len & ((1ull << dsh) - 1)) == 0;
   GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, src_cnt, nleaves, tile, p.d_tiles, inplace ? p.d_rank : (uint32_t *)nullptr,
-             inplace ? (uint32_t *)nullptr : dst_cnt, inplace ? (uint64_t)0 : dst_nleaves,
+             inplace ? (uint32_t *)nullptr : dst_cnt, (inplace || gather) ? (uint64_t)0 : dst_nleaves,
              inplace ? p.v.ldirty + (src_cnt - p.v.leafcnt) : (uint32_t *)nullptr, p.serial);
   GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, tb_index, tb_len, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
-  GPU_LAUNCH(p.stream, k_rb_scatter, ntiles, 256, nv, src_items, src_lo, src_len, src_sh,
-             inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, tile, p.rb_prefetch ? 4u : 1u, (const uint32_t *)p.d_tiles,
-             (const ChainTable *)p.d_table, dst, dst_bias, dst_cnt, nv.g.sh, (uint64_t)0);
+  const uint64_t ntd = (tb_len + kGtSlots - 1) / kGtSlots;
+  const uint32_t run = p.rb_run ? p.rb_run : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ntd / p.rb_run_wgs, 64));  // destination tiles per workgroup
+  if (gather && tb_index != 0)  // every destination leaf count is stored by the one workgroup that owns the leaf
+    GPU_LAUNCH(p.stream, k_rb_gather, (ntd + run - 1) / run, 256, nv, src_items, src_lo, src_len, src_sh,
+               inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, tile, ntiles, (const uint32_t *)p.d_tiles,
+               (const ChainTable *)p.d_table, dst, dst_bias, dst_cnt, dsh, (uint64_t)0, run);
+  else if (gather)  // (a window from slot 0 crosses a binade per doubling: the long position table)
+    GPU_LAUNCH(p.stream, k_rb_gather_from0, (ntd + run - 1) / run, 256, nv, src_items, src_lo, src_len, src_sh,
+               inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, tile, ntiles, (const uint32_t *)p.d_tiles,
+               (const ChainTable *)p.d_table, dst, dst_bias, dst_cnt, dsh, (uint64_t)0, run);
+  else
+    GPU_LAUNCH(p.stream, k_rb_scatter, ntiles, 256, nv, src_items, src_lo, src_len, src_sh,
+               inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, tile, p.rb_prefetch ? 4u : 1u, (const uint32_t *)p.d_tiles,
+               (const ChainTable *)p.d_table, dst, dst_bias, dst_cnt, nv.g.sh, (uint64_t)0);
   return PPCSR_OK;
 }
 

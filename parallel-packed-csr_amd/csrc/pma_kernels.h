@@ -1035,6 +1035,291 @@ PMA_KERNEL void k_rb_scatter(View v, const Edge *__restrict__ src, uint64_t src_
   }
 }
 
+// ---- destination-centric rebalance pass (round 3) ---------------------------------------------------------------------
+// k_rb_scatter walks SOURCE tiles and stores every element (and the nulls behind it) where it goes: one 12-byte store per
+// lane at scattered addresses, several store instructions per chunk.  k_rb_gather turns the pass round: a workgroup owns
+// kGtSlots DESTINATION slots, finds the ranks that land there (the position table is monotone: ranks [k_lo, k_hi)), streams
+// the source chunks that hold those ranks (a contiguous stretch of the source), places the elements in an LDS image of
+// its destination tile that starts out as all nulls, and writes the image with full 16-byte stores — every destination
+// byte leaves the CU exactly once, coalesced.  Destination leaf counts come out of the image (LDS atomics), so nobody
+// zeroes or atomically adds to the global leaf counts.  Same position table, same results.
+PMA_DEV uint64_t gt_pos_or_end(const ChainTable *stb, uint64_t k, uint64_t j, uint64_t wend) {
+  int hint = -1;
+  return k < j ? chain_pos(stb, k, &hint) : wend;
+}
+// first rank k in [0, j] whose position is >= T (j: none).  Whole wave; every lane returns the answer.
+PMA_DEV uint64_t gt_first_rank_at(const ChainTable *stb, uint64_t T, uint64_t j, uint64_t wend, int lane) {
+  if (T <= stb->index) return 0;
+  if (T >= wend) return j;
+  // positions are about index + k * len / j: start one wave-width window around the estimate, slide until it brackets T
+  uint64_t k0 = (uint64_t)((double)(T - stb->index) * ((double)j / (double)stb->len));  // (an estimate: fp64 is plenty)
+  if (k0 > j) k0 = j;
+  k0 = k0 > 31 ? k0 - 31 : 0;
+  for (;;) {
+    if (k0 + 63 > j) k0 = j > 63 ? j - 63 : 0;
+    const uint64_t k = k0 + (uint64_t)lane;  // <= j
+    const bool ge = gt_pos_or_end(stb, k <= j ? k : j, j, wend) >= T;
+    const uint64_t m = wv::ballot(ge);
+    if (m == 0) {  // all below T: the answer lies above this window (k0 + 63 < j here, or the window's last lane is j itself)
+      k0 += 64;
+      continue;
+    }
+    const int f = wv::ctz64(m);
+    if (f == 0 && k0 > 0) {  // the window's first rank is already at or past T: look further down
+      k0 = k0 > 63 ? k0 - 63 : 0;
+      continue;
+    }
+    return k0 + (uint64_t)f;
+  }
+}
+// source tile that holds rank k: the last t with tile_excl[t] <= k (tile_excl[0] = 0).  Whole wave.  One 64-wide probe
+// around the spot a uniform spread suggests, then 64-ary narrowing of whatever range is left.
+PMA_DEV uint64_t gt_find_tile(const uint32_t *__restrict__ tile_excl, uint64_t ntiles, uint64_t k, uint64_t j, int lane) {
+  uint64_t lo = 0, hi = ntiles;  // the answer is in [lo, hi); tile_excl[lo] <= k
+  {
+    uint64_t g = (uint64_t)((double)k * ((double)ntiles / (double)(j ? j : 1)));
+    if (g > ntiles) g = ntiles;
+    g = g > 31 ? g - 31 : 0;
+    if (g + 64 > ntiles) g = ntiles > 64 ? ntiles - 64 : 0;
+    const uint64_t t = g + (uint64_t)lane;
+    const uint64_t m = wv::ballot(t < ntiles && (uint64_t)tile_excl[t] <= k);
+    if (m == 0) {
+      hi = g;  // (g > 0 here: tile_excl[0] = 0 <= k)
+    } else {
+      const int f = 63 - __builtin_clzll(m);
+      lo = g + (uint64_t)f;
+      if (f < 63 || lo + 1 >= ntiles) return lo;  // the next tile was probed and lies above k, or there is none
+    }
+  }
+  while (hi - lo > 1) {
+    const uint64_t span = (hi - lo + 63) / 64;
+    const uint64_t t = lo + (uint64_t)lane * span;
+    const uint64_t m = wv::ballot(t < hi && (uint64_t)tile_excl[t] <= k);  // (lane 0 is always set)
+    const int f = 63 - __builtin_clzll(m);
+    lo += (uint64_t)f * span;
+    if (lo + span < hi) hi = lo + span;
+  }
+  return lo;
+}
+template <int SEGS>
+struct ChainTableLds {  // ChainTable with a shorter segment list (same layout in front): what a workgroup keeps in LDS
+  uint64_t index, len, j;
+  int nseg;
+  int overflow;
+  ChainSeg seg[SEGS];
+};
+// A workgroup owns a RUN of consecutive destination tiles.  The ranks that land in consecutive tiles are consecutive, so
+// after one search for the start of the run the source is simply streamed: batches of 4 x kGtBatch chunks (the next batch
+// is requested before the current one is placed), live counts through LDS give every element its rank, elements below
+// the current tile's last rank go into the image; when the batch runs past it the image is written out, cleared, and the
+// same batch continues into the next tile.  The start-up searches are paid once per run, not once per tile.
+constexpr int kGtBatch = 4;  // chunks per wave and batch
+// (blockDim.x is a load from the dispatch packet wherever it is used, and the wait behind that load drains every store and
+//  prefetch in flight: the workgroup size is a constant here)
+constexpr uint32_t kGtThreads = 256;
+template <uint32_t SLOTS, int SEGS>
+PMA_DEV void rb_gather_body(const View &v, const Edge *__restrict__ src, uint64_t src_lo, uint64_t src_len, int src_sh,
+                            const uint32_t *__restrict__ cnt, uint32_t tile_leaves, uint64_t ntiles_src,
+                            const uint32_t *__restrict__ tile_excl, const ChainTable *tb, Edge *__restrict__ dst, uint64_t dst_bias,
+                            uint32_t *dst_leafcnt, int dst_sh, uint64_t dst_leaf_bias, uint32_t run_tiles) {
+  PMA_SHARED ChainTableLds<SEGS> stb_s;
+  PMA_SHARED uint32_t img[SLOTS * 3];
+  PMA_SHARED uint32_t lcnt[SLOTS / 4];
+  PMA_SHARED uint32_t pre[256 + 1];
+  PMA_SHARED uint32_t wsum[4];
+  PMA_SHARED uint32_t bc[2][4 * kGtBatch];  // live elements per chunk of the batch (double buffered: one sync per batch)
+  PMA_SHARED unsigned long long bnd[2];     // first chunk of the stream, rank in front of it
+  const ChainTable *stb = reinterpret_cast<const ChainTable *>(&stb_s);
+  const uint32_t tid = wv::thread_idx();
+  const int lane = wv::lane(), w = wv::wave_in_block();
+  {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
+    uint32_t *sp = reinterpret_cast<uint32_t *>(&stb_s);
+    const uint32_t words = (uint32_t)((sizeof(ChainTable) - sizeof(ChainSeg) * (size_t)(kMaxSeg - tb->nseg)) / 4);
+    for (uint32_t i = tid; i < words; i += kGtThreads) sp[i] = g[i];  // (the host picked SEGS for this window)
+  }
+  for (uint32_t i = tid; i < SLOTS * 3; i += kGtThreads) img[i] = (i % 3u == 0u) ? kMax : 0u;  // null_edge()
+  for (uint32_t i = tid; i < SLOTS / 4; i += kGtThreads) lcnt[i] = 0u;
+  wv::block_sync();
+  const uint64_t j = stb->j, wend = stb->index + stb->len;
+  const uint64_t ntiles_dst = (stb->len + SLOTS - 1) / SLOTS;
+  uint64_t t = (uint64_t)wv::block_idx() * run_tiles;
+  const uint64_t t_end = (t + run_tiles < ntiles_dst) ? t + run_tiles : ntiles_dst;
+  const int lsh = 6 - src_sh;  // log2(leaves per 64-slot chunk)
+  const uint64_t nleaves = src_len >> src_sh;
+  const uint64_t nchunks = (src_len + 63) >> 6;
+  uint64_t T0 = stb->index + t * SLOTS;
+  uint64_t T1 = (T0 + SLOTS < wend) ? T0 + SLOTS : wend;
+  uint64_t k_lo = gt_first_rank_at(stb, T0, j, wend, lane);  // (every wave computes it: no hand-over, no barrier)
+  uint64_t k_hi = gt_first_rank_at(stb, T1, j, wend, lane);
+  // where the stream starts: the source chunk that holds rank k_lo, and the rank of that chunk's first live element
+  {
+    const uint64_t ts = (k_lo < j && ntiles_src > 1) ? gt_find_tile(tile_excl, ntiles_src, k_lo, j, lane) : 0;
+    const uint64_t base = (k_lo < j && ntiles_src > 0) ? (uint64_t)tile_excl[ts] : 0ull;
+    const uint64_t l = ts * (uint64_t)tile_leaves + tid;
+    const uint32_t x = (k_lo < j && tid < tile_leaves && l < nleaves) ? cnt[l] : 0u;
+    uint32_t incl = x;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = wv::shfl(incl, lane - o < 0 ? 0 : lane - o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[w] = incl;
+    if (tid == 0) {
+      bnd[0] = nchunks;  // (no element at or after k_lo: nothing to stream)
+      bnd[1] = j;
+    }
+    wv::block_sync();
+    uint32_t woff = 0;
+    for (int q = 0; q < w; q++) woff += wsum[q];
+    const uint32_t ex = woff + incl - x;
+    pre[tid] = ex;
+    wv::block_sync();
+    if (x != 0 && base + ex <= k_lo && k_lo < base + ex + x) {  // the leaf that holds rank k_lo: exactly one thread
+      const uint32_t lf0 = (tid >> lsh) << lsh;                  // first leaf of its chunk
+      bnd[0] = (ts * (uint64_t)tile_leaves + lf0) >> lsh;
+      bnd[1] = base + pre[lf0];
+    }
+    wv::block_sync();
+  }
+  uint64_t cc = bnd[0];  // next chunk to request
+  uint64_t rb = bnd[1];  // rank of the first live element of chunk cc
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  int hint = -1, hint3 = -1;
+  // Loads are issued unconditionally (the address is clamped, the value is masked when it is used): a load under a branch
+  // makes the compiler wait for it on the spot, which serialises the batch and defeats the prefetch.
+  Edge e[kGtBatch], en[kGtBatch];
+  bool okn[kGtBatch];
+#pragma unroll
+  for (int q = 0; q < kGtBatch; q++) {
+    const uint64_t off = ((cc + (uint64_t)(w * kGtBatch + q)) << 6) + (uint64_t)lane;
+    okn[q] = off < src_len;
+    en[q] = src[src_lo + (okn[q] ? off : 0)];
+  }
+  uint32_t par = 0;
+  for (;;) {
+#pragma unroll
+    for (int q = 0; q < kGtBatch; q++) {
+      e[q] = en[q];
+      if (!okn[q]) e[q] = null_edge();
+    }
+#pragma unroll
+    for (int q = 0; q < kGtBatch; q++) {  // the next batch is on its way while this one is placed
+      const uint64_t off = ((cc + (uint64_t)(4 * kGtBatch + w * kGtBatch + q)) << 6) + (uint64_t)lane;
+      okn[q] = off < src_len;
+      en[q] = src[src_lo + (okn[q] ? off : 0)];
+    }
+    uint64_t m[kGtBatch];
+#pragma unroll
+    for (int q = 0; q < kGtBatch; q++) {
+      m[q] = wv::ballot(e[q].value != 0);
+      if (lane == 0) bc[par][w * kGtBatch + q] = (uint32_t)wv::popc64(m[q]);
+    }
+    wv::block_sync();
+    uint32_t before = 0, btotal = 0;  // live elements of the batch in front of this wave's chunks / in all of it
+#pragma unroll
+    for (int q = 0; q < 4 * kGtBatch; q++) {
+      const uint32_t c = bc[par][q];
+      if (q < w * kGtBatch) before += c;
+      btotal += c;
+    }
+    par ^= 1u;
+    uint64_t kq[kGtBatch];
+    uint64_t pq[kGtBatch];
+    {
+      uint64_t r0 = rb + before;
+#pragma unroll
+      for (int q = 0; q < kGtBatch; q++) {
+        const uint32_t cn = (uint32_t)wv::popc64(m[q]);
+        const uint32_t i = (uint32_t)wv::popc64(m[q] & lt_mask);
+        const bool nn = e[q].value != 0;
+        kq[q] = r0 + i;
+        pq[q] = 0;
+        if (cn) {
+          uint64_t A, D;
+          int shift;
+          if (chain_linear_run(stb, r0, (r0 + cn <= j - 1) ? cn : cn - 1, &hint3, &A, &D, &shift)) pq[q] = (A + (uint64_t)i * D) >> shift;
+          else if (nn) pq[q] = chain_pos(stb, kq[q], &hint);
+        }
+        r0 += cn;
+      }
+    }
+    const uint64_t bend = rb + btotal;  // rank behind the batch
+    for (;;) {                          // the tiles this batch reaches
+#pragma unroll
+      for (int q = 0; q < kGtBatch; q++) {
+        if (e[q].value != 0 && kq[q] >= k_lo && kq[q] < k_hi) {
+          const uint32_t o = (uint32_t)(pq[q] - T0);
+          img[o * 3u] = e[q].src;
+          img[o * 3u + 1u] = e[q].dest;
+          img[o * 3u + 2u] = e[q].value;
+          dev::fix_sentinel(v, e[q], (uint32_t)pq[q]);
+        }
+        // destination leaf counts: the lanes that land in one leaf are neighbours, so the first of each group adds the
+        // group's size (same-address LDS atomics are served one lane at a time: one add per element cost 100 us here)
+        {
+          const bool mine = e[q].value != 0 && kq[q] >= k_lo && kq[q] < k_hi;
+          const uint64_t mm = wv::ballot(mine);
+          if (mm != 0) {
+            const uint32_t lf = mine ? (uint32_t)((pq[q] - T0) >> dst_sh) : 0xFFFFFFFFu;
+            const uint64_t below = mm & lt_mask;
+            const int prevlane = below ? 63 - __builtin_clzll(below) : lane;
+            const uint32_t prevlf = wv::shfl(lf, prevlane);
+            const bool head = mine && (below == 0 || prevlf != lf);
+            const uint64_t hm = wv::ballot(head);
+            if (head) {
+              const uint64_t later = hm & ~lt_mask & ~(1ull << lane);
+              const uint64_t upto = later ? ((1ull << wv::ctz64(later)) - 1ull) : ~0ull;
+              wv::atomic_add_u32(&lcnt[lf], (uint32_t)wv::popc64(mm & upto & ~lt_mask));
+            }
+          }
+        }
+      }
+      if (!(bend >= k_hi || bend >= j || cc >= nchunks)) break;  // the tile may get more from the next batch
+      // the tile is complete: out it goes (16-byte stores when it starts on a 16-byte boundary), then a fresh image
+      wv::block_sync();
+      const uint32_t nsl = (uint32_t)(T1 - T0);
+      uint32_t *out = reinterpret_cast<uint32_t *>(dst + (T0 - dst_bias));
+      if ((reinterpret_cast<uintptr_t>(out) & 15u) == 0 && (nsl & 3u) == 0) {
+        uint4 *o4 = reinterpret_cast<uint4 *>(out);
+        const uint4 *i4 = reinterpret_cast<const uint4 *>(img);
+        for (uint32_t i = tid; i < nsl * 3u / 4u; i += kGtThreads) o4[i] = i4[i];
+      } else {
+        for (uint32_t i = tid; i < nsl * 3u; i += kGtThreads) out[i] = img[i];
+      }
+      const uint32_t nlf = nsl >> dst_sh;
+      for (uint32_t i = tid; i < nlf; i += kGtThreads) dst_leafcnt[(T0 >> dst_sh) - dst_leaf_bias + i] = lcnt[i];
+      if (++t >= t_end) return;
+      wv::block_sync();
+      for (uint32_t i = tid; i < SLOTS * 3; i += kGtThreads) img[i] = (i % 3u == 0u) ? kMax : 0u;
+      for (uint32_t i = tid; i < SLOTS / 4; i += kGtThreads) lcnt[i] = 0u;
+      wv::block_sync();
+      T0 = T1;
+      T1 = (T0 + SLOTS < wend) ? T0 + SLOTS : wend;
+      k_lo = k_hi;
+      k_hi = gt_first_rank_at(stb, T1, j, wend, lane);
+    }
+    rb = bend;
+    cc += 4 * kGtBatch;
+  }
+}
+constexpr uint32_t kGtSlots = 1024;
+constexpr int kGtSegsSmall = 4, kGtSegsBig = kMaxSeg;
+// (windows that do not start at slot 0 lie in one binade: one or two segments; windows from slot 0 cross one per binade)
+PMA_KERNEL void k_rb_gather(View v, const Edge *__restrict__ src, uint64_t src_lo, uint64_t src_len, int src_sh,
+                            const uint32_t *__restrict__ cnt, uint32_t tile_leaves, uint64_t ntiles_src,
+                            const uint32_t *__restrict__ tile_excl, const ChainTable *tb, Edge *__restrict__ dst, uint64_t dst_bias,
+                            uint32_t *dst_leafcnt, int dst_sh, uint64_t dst_leaf_bias, uint32_t run_tiles) {
+  rb_gather_body<kGtSlots, kGtSegsSmall>(v, src, src_lo, src_len, src_sh, cnt, tile_leaves, ntiles_src, tile_excl, tb, dst, dst_bias, dst_leafcnt, dst_sh,
+                                         dst_leaf_bias, run_tiles);
+}
+PMA_KERNEL void k_rb_gather_from0(View v, const Edge *__restrict__ src, uint64_t src_lo, uint64_t src_len, int src_sh,
+                                  const uint32_t *__restrict__ cnt, uint32_t tile_leaves, uint64_t ntiles_src,
+                                  const uint32_t *__restrict__ tile_excl, const ChainTable *tb, Edge *__restrict__ dst, uint64_t dst_bias,
+                                  uint32_t *dst_leafcnt, int dst_sh, uint64_t dst_leaf_bias, uint32_t run_tiles) {
+  rb_gather_body<kGtSlots, kGtSegsBig>(v, src, src_lo, src_len, src_sh, cnt, tile_leaves, ntiles_src, tile_excl, tb, dst, dst_bias, dst_leafcnt, dst_sh,
+                                       dst_leaf_bias, run_tiles);
+}
+
 constexpr uint32_t kIpSpinLimit = 1u << 22;
 template <int CPW>  // chunks (64 slots) per wave: the tile is 4 * CPW * 64 slots
 PMA_DEV void rb_inplace_body(const View &v, uint64_t wstart, uint64_t wlen, int sh, const uint32_t *__restrict__ cnt,
@@ -1071,9 +1356,10 @@ PMA_DEV void rb_inplace_body(const View &v, uint64_t wstart, uint64_t wlen, int 
   Edge e[CPW];  // requested first: everything below overlaps with these loads
 #pragma unroll
   for (int q = 0; q < CPW; q++) {
+    // (the window is a whole number of tiles — the engine checks — so the load needs no guard; a load under a branch makes the
+    //  compiler wait for it on the spot, which turned these CPW requests into CPW / 2 round trips)
     const uint64_t off = tile_slot0 + (uint64_t)(w * CPW + q) * 64u + (uint64_t)lane;
-    e[q] = null_edge();
-    if (off < wlen) e[q] = v.items[wstart + off];
+    e[q] = v.items[wstart + off];
   }
   {
     const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);

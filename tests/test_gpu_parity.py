@@ -772,3 +772,37 @@ def test_large_graph_properties(pkg, streams):
     # (6) the bulk scan agrees with the array
     rows, dests = eng.scan_all()
     assert rows[-1] == len(e) - (1 if (live[-1] and not sent[-1]) else 0)
+
+
+def test_rebalance_gather_variant(pkg, streams):
+    """option rb_gather=1 (destination-centric final pass of the big rebalances, an opt-in variant) leaves exactly the array the
+    default pass leaves: resizes of a growing and shrinking stream against the oracle, and whole / partial windows of a
+    loaded graph against the default pass"""
+    n = 3000
+    a = streams.random_stream(n, 400000, seed=77)
+    d = a.copy()
+    d[:, 2] = 0
+    ops = np.concatenate([a, d[::-1]])
+    e, o = pkg.PCSR(n), Oracle(n)
+    e.set_option("rb_gather", 1)
+    for lo in range(0, len(ops), 100000):
+        e.apply(ops[lo:lo + 100000])
+        o.apply(ops[lo:lo + 100000])
+        _same(e, o, f"after {lo + 100000}")
+    assert e.stats()["double_calls"] >= 3
+    e.close()
+    s_, d_ = streams.rmat_edges(16, 600000, seed=5)
+    g = pkg.PCSR(1 << 16)
+    g.apply(streams.adds(s_, d_))
+    N = g.geometry()[0]
+    states = []
+    for variant in (0, 1, 1):
+        g.set_option("rb_gather", variant)
+        g.set_option("rb_run", 0 if len(states) < 2 else 5)
+        g.set_option("rb_inplace_min", 0)  # partial windows through the scratch stretch: the pass under test
+        for w in (N, N // 2, N // 8):
+            g.bench_rebalance(w, 1)
+        states.append(digest(*g.state(), g.geometry()))
+        assert g.check_invariants() == 0
+    assert len(set(states)) == 1
+    g.close()

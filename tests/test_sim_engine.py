@@ -546,3 +546,22 @@ def test_sim_xchg_steps_and_repartition(streams):
             parts[k].apply(sub)
         same(parts, f"updates after {new}")
         old = new
+
+
+@pytest.mark.parametrize("run", [1, 3])
+def test_sim_rebalance_gather_variant(sim, streams, run):
+    """k_rb_gather (option rb_gather=1: destination tiles staged in LDS, runs of `rb_run` tiles per workgroup) on a stream that
+    doubles and halves the array several times: same states as the oracle, like the default source-centric pass"""
+    n = 300
+    e, o = sim(n, big_window=4096), Oracle(n)
+    e.set_option("rb_gather", 1)
+    e.set_option("rb_run", run)
+    a = streams.random_stream(n, 9000, seed=2 + run)
+    d = a.copy()
+    d[:, 2] = 0
+    ops = np.concatenate([a, d[::-1]])
+    for lo in range(0, len(ops), 3000):
+        e.apply(ops[lo:lo + 3000])
+        o.apply(ops[lo:lo + 3000])
+        _same(e, o, f"after {lo + 3000}")
+    assert e.stats()["double_calls"] >= 3
