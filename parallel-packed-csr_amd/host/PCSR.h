@@ -94,12 +94,22 @@ class PCSR {
   }
   void add_edge(uint32_t src, uint32_t dest, uint32_t value) {  // PCSR.cpp:706 (value 0 / src >= n: silently ignored)
     if (value == 0) return;
-    std::lock_guard<std::mutex> g(pending_mu_);
-    pending_.push_back(ppcsr_op{src, dest, value});
+    enqueue(ppcsr_op{src, dest, value});
   }
   void remove_edge(uint32_t src, uint32_t dest) {  // PCSR.cpp:709
-    std::lock_guard<std::mutex> g(pending_mu_);
-    pending_.push_back(ppcsr_op{src, dest, 0u});
+    enqueue(ppcsr_op{src, dest, 0u});
+  }
+  // Updates wait in host memory (12 B each) until a reader or flush() applies them.  A writer-only client would let that
+  // grow with the stream, so past a high-water mark (default 64 Mi updates = 768 MiB; PPCSR_PENDING_MAX overrides) the
+  // submitting thread applies what is there.  The reference's benchmark batches (<= 10 M updates) never reach it, so no
+  // engine call lands inside a pool's timed submit window.
+  static std::size_t pending_high_water() {
+    static const std::size_t v = [] {
+      const char *e = std::getenv("PPCSR_PENDING_MAX");
+      const unsigned long long x = e ? std::strtoull(e, nullptr, 10) : 0ull;
+      return x ? (std::size_t)x : ((std::size_t)64 << 20);
+    }();
+    return v;
   }
   void read_neighbourhood(int src) {  // PCSR.cpp:892
     std::lock_guard<std::mutex> g(engine_mu_);
@@ -180,6 +190,15 @@ class PCSR {
 
  private:
   // engine_mu_ is held
+  void enqueue(const ppcsr_op &op) {
+    std::size_t held;
+    {
+      std::lock_guard<std::mutex> g(pending_mu_);
+      pending_.push_back(op);
+      held = pending_.size();
+    }
+    if (held >= pending_high_water()) flush();
+  }
   void flush_locked() {
     std::vector<ppcsr_op> batch;
     {

@@ -61,12 +61,10 @@ class PPPCSR {
   }
   void add_edge(uint32_t src, uint32_t dest, uint32_t value) {  // PPPCSR.cpp:46-48
     if (value == 0) return;
-    std::lock_guard<std::mutex> g(pending_mu_);
-    pending_.push_back(ppcsr_op{src, dest, value});
+    enqueue(ppcsr_op{src, dest, value});
   }
   void remove_edge(uint32_t src, uint32_t dest) {  // PPPCSR.cpp:50-52
-    std::lock_guard<std::mutex> g(pending_mu_);
-    pending_.push_back(ppcsr_op{src, dest, 0u});
+    enqueue(ppcsr_op{src, dest, 0u});
   }
   void read_neighbourhood(int src) {
     std::lock_guard<std::mutex> g(engine_mu_);
@@ -112,6 +110,15 @@ class PPPCSR {
   pppcsr_t handle() { return h_; }
 
  private:
+  void enqueue(const ppcsr_op &op) {  // (bounded like PCSR::enqueue: past the high-water mark the submitter applies the backlog)
+    std::size_t held;
+    {
+      std::lock_guard<std::mutex> g(pending_mu_);
+      pending_.push_back(op);
+      held = pending_.size();
+    }
+    if (held >= PCSR::pending_high_water()) flush();
+  }
   void flush_locked() {  // engine_mu_ is held
     std::vector<ppcsr_op> batch;
     {
@@ -121,7 +128,10 @@ class PPPCSR {
     }
     const bool timing = std::getenv("PPCSR_CLI_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    check(pppcsr_apply_batch(h_, batch.data(), batch.size()));
+    for (auto &p : partitions) p->edges.global_lock->applying.store(1, std::memory_order_release);  // (FastLock::lockable() of the views)
+    const int rc = pppcsr_apply_batch(h_, batch.data(), batch.size());
+    for (auto &p : partitions) p->edges.global_lock->applying.store(0, std::memory_order_release);
+    check(rc);
     const auto t1 = std::chrono::steady_clock::now();
     for (auto &p : partitions) p->sync_geometry();
     if (timing)

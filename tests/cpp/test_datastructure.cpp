@@ -128,8 +128,24 @@ static void run(bool lock_search) {
   }
 }
 
+// the host mirror keeps submitted updates in memory until a reader or flush() applies them; past the high-water mark
+// (PPCSR_PENDING_MAX, here 1000) the submitter applies the backlog itself, so a writer-only client stays bounded
+static void high_water() {
+  PCSR pcsr(100, 100, true, 0);
+  for (uint32_t i = 0; i < 5000; ++i) {
+    pcsr.add_edge(i % 100, (i * 7) % 100, 1 + i);
+    EXPECT_TRUE(pcsr.pending() < 1000u);
+  }
+  PPPCSR pp(100, 100, true, 1, 4, false);
+  for (uint32_t i = 0; i < 5000; ++i) pp.add_edge(i % 100, (i * 7) % 100, 1 + i);
+  for (uint32_t i = 0; i < 5000; i += 37) EXPECT_TRUE(pp.edge_exists(i % 100, (i * 7) % 100) == pcsr.edge_exists(i % 100, (i * 7) % 100));
+  EXPECT_TRUE(pp.get_neighbourhood(3) == pcsr.get_neighbourhood(3));
+}
+
 int main() {
   PCSR::quiet() = true;
+  setenv("PPCSR_PENDING_MAX", "1000", 1);  // (read once, at the first submit)
+  high_water();
   run(false);
   run(true);
   std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED\n", failures);

@@ -42,9 +42,12 @@ if cfg == 2:
 else:
     wl = bench.Workload(st, cfg, 10_000_000, 24, 100_000_000, 10_000_000, labels == "permuted")
 t_gen = time.time()
+print("generating the core ...", flush=True)  # (a silent stretch of minutes looks like a hang to the GPU box's watchdog)
 core = wl.core(0, wl.core_edges)
+print(f"core generated ({time.time() - t_gen:.0f}s); generating the updates ...", flush=True)
 upd = wl.updates(0, 0, wl.batch, core_for_mixed=core)
 n_upd = len(upd)
+print(f"updates generated ({time.time() - t_gen:.0f}s); writing the text files ...", flush=True)
 cf, uf = "/tmp/ppcsr_proto_core.txt", "/tmp/ppcsr_proto_upd.txt"
 pd.DataFrame(core[:, :2]).to_csv(cf, sep=" ", header=False, index=False)
 pd.DataFrame(upd[:, :2]).to_csv(uf, sep=" ", header=False, index=False)
@@ -73,6 +76,8 @@ for mode, flags in (("pppcsrnuma", ["-pppcsrnuma", "-partitions_per_domain=8"]),
             if len(el) >= 2 and el[1] > 0:
                 vals.append(n_upd / (el[1] * 1e-3))
                 loads.append(el[0])
+            print(f"  {mode} threads={t} run {len(vals)}: phase 1 {el[0] if el else '?'} ms, phase 2 {el[1] if len(el) > 1 else '?'} ms "
+                  f"({time.time() - t00:.0f}s)", flush=True)
         if vals:
             res["runs"][f"{mode}_t{t}"] = {"mode": mode, "threads": t, "repetitions": len(vals), "updates_per_s_mean": float(np.mean(vals)),
                                           "updates_per_s_std": float(np.std(vals, ddof=1)) if len(vals) > 1 else 0.0,
