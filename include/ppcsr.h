@@ -116,18 +116,22 @@ int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out);
  *   scheduler  "mode" (0 strict prefix rounds, 1 speculative rounds + validated rollback; default 1), "opt_horizon" (round
  *              width cap; default 3 x "resident_waves" = 3 x CUs x 24), "start_horizon", "adaptive", "epoch_ops", "epoch_short", "epoch_grow_after",
  *              "region_slots" / "region_wide" / "region_calm", "soft_barrier", "defer_barrier", "small_batch" (batches up to this size take the strict
- *              rounds), "max_horizon" / "min_horizon" / "init_horizon" (strict rounds), "rounds_per_sync"
+ *              rounds), "max_horizon" / "min_horizon" / "init_horizon" (strict rounds), "rounds_per_sync";
+ *              opt-in experiments (bit-exact, measured slower or neutral: DESIGN.md section 3): "chain" (0 off, 2 in-round chains
+ *              per region), "chain_steps", "chain_grid", "zone_factor" (0 off: soft barriers made spatial)
  *   windows    "big_min" / "big_window" (slots: above big_min a workgroup of the round rebalances the window, above
  *              big_window the update is exclusive), "big_grid", "excl_in_wave"
  *   rebalance  "scatter_variant" (0 LDS-staged, 1 register runs, 2 runs + in-tile leaf scan), "scatter_blocks",
- *              "rb_tile", "rb_min_tiles", "rb_prefetch", "rb_inplace_min" (partial windows of at least this many slots are
+ *              "rb_tile", "rb_min_tiles", "rb_prefetch", "rb_gather" / "rb_run" / "rb_run_wgs" (opt-in destination-centric final
+ *              pass: DESIGN.md section 9), "rb_inplace_min" (partial windows of at least this many slots are
  *              rebalanced in place; 0 = always through the scratch array), "rb_inplace_cpw", "rb_inplace_lists"
  *   search     "search_narrow" (0: literal binary walk only)
  *   measuring  "profile" (1: HIP events around every round kernel, reported through ppcsr_stats), "diag" (1: why updates
- *              did not commit, per epoch, on stderr), "marker" (marker kernels for profile cuts), "test_block_rebalance" */
+ *              did not commit, per epoch, on stderr; 2: also a per-update dependency trace, PPCSR_DIAG_DUMP = file), "marker" (marker kernels for profile cuts), "test_block_rebalance" */
 int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value);
 /* device-side copy of the whole state and return to it (used by the benchmark to replay a batch on the same
- * core graph, and by the engine itself as the rollback point of speculative rounds); no reference equivalent */
+ * core graph, and by the engine itself as the rollback point of speculative rounds); no reference equivalent.
+ * After the first copy both directions are incremental: only leaves / node records written since (dirty tags) move */
 int ppcsr_snapshot(ppcsr_t h);
 int ppcsr_restore(ppcsr_t h);
 /* debugging / measurement helpers */
