@@ -582,9 +582,9 @@ PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint
     const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
     uint32_t *sp = reinterpret_cast<uint32_t *>(&stb);
     const uint32_t words = (uint32_t)((sizeof(ChainTable) - sizeof(ChainSeg) * (size_t)(kMaxSeg - tb->nseg)) / 4);
-    for (uint32_t i = wv::thread_idx(); i < words; i += wv::block_dim()) sp[i] = g[i];
+    for (uint32_t i = wv::thread_idx(); i < words; i += kIpOrderThreads) sp[i] = g[i];
   }
-  for (uint32_t i = wv::thread_idx(); i <= ntiles; i += wv::block_dim()) hist[i] = 0u;
+  for (uint32_t i = wv::thread_idx(); i <= ntiles; i += kIpOrderThreads) hist[i] = 0u;
   if (wv::thread_idx() < 8u) ctl[kIpTicketStride * (1u + wv::thread_idx())] = 0u;  // the ticket counters
   wv::block_sync();
   const int lane = wv::lane(), w = wv::wave_in_block();
@@ -636,7 +636,7 @@ PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint
       }
     }
     key[r] = d_r > d_l ? d_r : d_l;
-    wv::atomic_add_u32(&hist[key[r]], 1u);
+    wv::atomic_add_u32(&hist[key[r]], 1u);  // (the keys of a wave's tiles are mostly distinct: electing leaders per key value was measured slower)
   }
   wv::block_sync();
   {  // exclusive scan of hist[0 .. ntiles]
@@ -1365,7 +1365,7 @@ PMA_DEV void rb_inplace_body(const View &v, uint64_t wstart, uint64_t wlen, int 
     const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
     uint32_t *sp = reinterpret_cast<uint32_t *>(&stb);
     const uint32_t words = (uint32_t)((sizeof(ChainTable) - sizeof(ChainSeg) * (size_t)(kMaxSeg - tb->nseg)) / 4);
-    for (uint32_t i = wv::thread_idx(); i < words; i += wv::block_dim()) sp[i] = g[i];
+    for (uint32_t i = wv::thread_idx(); i < words; i += 256u /* the launch's workgroup size: blockDim.x would be a load + a wait for everything in flight */) sp[i] = g[i];
   }
   const uint32_t tile_leaves = kTileSlots >> sh;
   const uint64_t nleaves = wlen >> sh;
@@ -1391,7 +1391,7 @@ PMA_DEV void rb_inplace_body(const View &v, uint64_t wstart, uint64_t wlen, int 
   wv::block_sync();
   if (wv::thread_idx() == 0) wv::flag_publish(&flags[tile], epoch);
   if (j == 0) {  // empty window: nothing is read by anybody, every tile clears its own slots
-    for (uint32_t t = wv::thread_idx(); t < kTileSlots; t += wv::block_dim())
+    for (uint32_t t = wv::thread_idx(); t < kTileSlots; t += 256u /* the launch's workgroup size: blockDim.x would be a load + a wait for everything in flight */)
       if (tile_slot0 + t < wlen) v.items[wstart + tile_slot0 + t] = null_edge();
     return;
   }

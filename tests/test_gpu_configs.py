@@ -136,3 +136,28 @@ def test_config4_one_partition_full_size(pkg, streams, graph4, labels, part):
         _branch(eng, o, zupd, f"config #5 partition {part} (permuted): its share of the 10 M Zipf(1.2) updates")
     o.close()
     eng.close()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), both ranks on the one GPU of
+    this box with gloo as the process-group backend (RCCL refuses two ranks on one device): the N > 1 code path of the
+    benchmark — per-rank blocks, owner exchange, per-partition apply, cross-rank parity of every resident partition — on a
+    small config #4 graph.  The exchange carrier of the real multi-GPU run (native RCCL) is covered by
+    test_native_rccl_exchange_single_rank and tests/test_exchange_gloo.py."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "4",
+           "--vertices", "200000", "--scale", "18", "--core-edges", "2000000", "--batch", "200000", "--steps", "1", "--warmup", "1",
+           "--no-secondary", "--no-cpu-baseline", "--no-profile"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["parity_checked"] is True and out["value"] > 0
+    assert "8 partition(s), 4 per GPU x 2 GPU(s)" in out["config"]["parallelism"]

@@ -33,6 +33,19 @@ st = load_streams()
 cfg = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 modes = sys.argv[5].split(",") if len(sys.argv) > 5 else ["pppcsrnuma", "ppcsr"]
 labels = sys.argv[6] if len(sys.argv) > 6 else ("raw" if cfg == 2 else "permuted")  # bench.py's defaults
+size_cap = int(sys.argv[7]) if len(sys.argv) > 7 else 0  # only the first `size_cap` updates of the batch (-size=): a bounded sample
+run_timeout = int(sys.argv[8]) if len(sys.argv) > 8 else 900
+import threading  # noqa: E402
+
+
+def _heartbeat():  # (the GPU box's watchdog kills a command that prints nothing for 7 minutes; one reference run can take longer)
+    t0 = time.time()
+    while True:
+        time.sleep(60)
+        print(f"  ... running ({time.time() - t0:.0f}s)", flush=True)
+
+
+threading.Thread(target=_heartbeat, daemon=True).start()
 import importlib.util  # noqa: E402
 spec = importlib.util.spec_from_file_location("ppcsr_bench", os.path.join(ROOT, "bench.py"))
 bench = importlib.util.module_from_spec(spec)
@@ -46,7 +59,7 @@ print("generating the core ...", flush=True)  # (a silent stretch of minutes loo
 core = wl.core(0, wl.core_edges)
 print(f"core generated ({time.time() - t_gen:.0f}s); generating the updates ...", flush=True)
 upd = wl.updates(0, 0, wl.batch, core_for_mixed=core)
-n_upd = len(upd)
+n_upd = min(len(upd), size_cap) if size_cap else len(upd)
 print(f"updates generated ({time.time() - t_gen:.0f}s); writing the text files ...", flush=True)
 cf, uf = "/tmp/ppcsr_proto_core.txt", "/tmp/ppcsr_proto_upd.txt"
 pd.DataFrame(core[:, :2]).to_csv(cf, sep=" ", header=False, index=False)
@@ -61,7 +74,7 @@ except Exception:
 numa = len([x for x in os.listdir("/sys/devices/system/node") if x.startswith("node")]) if os.path.isdir("/sys/devices/system/node") else None
 res = {"workload": f"{wl.name(8 if cfg != 2 else 1, 1)}: core = phase 1 (untimed), the first update batch = phase 2 (timed)", "config": cfg, "labels": labels,
        "binary": "oracle/_ref/ref_cli (unmodified reference)",
-       "cores_available_to_this_process": cores, "cpus_online": os.cpu_count(), "cpu_model": cpu_model, "numa_nodes": numa, "repetitions": reps, "runs": {}}
+       "cores_available_to_this_process": cores, "cpus_online": os.cpu_count(), "cpu_model": cpu_model, "numa_nodes": numa, "repetitions": reps, "updates_timed": n_upd, "runs": {}}
 t00 = time.time()
 for mode, flags in (("pppcsrnuma", ["-pppcsrnuma", "-partitions_per_domain=8"]), ("ppcsr", ["-ppcsr"])):
     if mode not in modes:
@@ -70,9 +83,16 @@ for mode, flags in (("pppcsrnuma", ["-pppcsrnuma", "-partitions_per_domain=8"]),
         vals, loads = [], []
         r_n = reps if t > 1 else min(reps, 3)  # (a one-thread run takes ~20 s)
         for _ in range(r_n):
-            r = subprocess.run([cli, f"-threads={t}", f"-size={n_upd}", "-insert"] + flags + [f"-core_graph={cf}", f"-update_file={uf}"],
-                               capture_output=True, text=True, timeout=900)
-            el = [int(l.split(":")[1]) for l in r.stdout.splitlines() if l.startswith("Elapsed wall clock time")]
+            try:
+                r = subprocess.run([cli, f"-threads={t}", f"-size={n_upd}", "-insert"] + flags + [f"-core_graph={cf}", f"-update_file={uf}"],
+                                   capture_output=True, text=True, timeout=run_timeout)
+                el = [int(l.split(":")[1]) for l in r.stdout.splitlines() if l.startswith("Elapsed wall clock time")]
+            except subprocess.TimeoutExpired:
+                res["runs"][f"{mode}_t{t}"] = {"mode": mode, "threads": t, "timed_out_after_s": run_timeout, "updates": n_upd,
+                                              "note": "the reference did not finish load + update phase within the limit"}
+                print(f"  {mode} threads={t}: no result within {run_timeout}s", flush=True)
+                json.dump(res, open(out, "w"), indent=1)
+                break
             if len(el) >= 2 and el[1] > 0:
                 vals.append(n_upd / (el[1] * 1e-3))
                 loads.append(el[0])
@@ -84,7 +104,8 @@ for mode, flags in (("pppcsrnuma", ["-pppcsrnuma", "-partitions_per_domain=8"]),
                                           "phase2_ms": [round(n_upd * 1e3 / v) for v in vals], "phase1_ms_mean": float(np.mean(loads))}
             print(f"{mode} threads={t}: {np.mean(vals) / 1e6:.2f} +- {(np.std(vals, ddof=1) if len(vals) > 1 else 0) / 1e6:.2f} M updates/s ({len(vals)} runs, {time.time() - t00:.0f}s)", flush=True)
         json.dump(res, open(out, "w"), indent=1)
-best = max(res["runs"], key=lambda k: res["runs"][k]["updates_per_s_mean"]) if res["runs"] else None
+done = {k: v for k, v in res["runs"].items() if "updates_per_s_mean" in v}
+best = max(done, key=lambda k: done[k]["updates_per_s_mean"]) if done else None
 res["best"] = best
 json.dump(res, open(out, "w"), indent=1)
 os.remove(cf)
