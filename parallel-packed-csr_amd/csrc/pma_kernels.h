@@ -2332,6 +2332,8 @@ PMA_KERNEL void o_check(OptArgs a) {
   const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
   const uint32_t hor = c->hor[par];
   const unsigned long long gbar = c->gbar[par], sbar = c->sbar[par];
+  const uint32_t nzones = c->nzones[par];  // (requested with the other control words: asked for where it is used, it is one more
+                                           //  dependent round trip on every wave's path — 2 us per launch)
   const uint32_t idx = a.opidx[wid];
   const Plan *pl = &a.plans[wid];
   const PlanHead h = load_plan_head(pl, lane);
@@ -2369,7 +2371,7 @@ PMA_KERNEL void o_check(OptArgs a) {
   const bool strong = kind_strong(kind);
   {  // zones of earlier soft-barrier updates: anything of ours inside one -> deferred (and treated like any other deferred
      // update below: it keeps later updates out of its own regions)
-    uint32_t nz = c->nzones[par];
+    uint32_t nz = nzones;
     if (nz > kMaxZones) nz = kMaxZones;
     for (uint32_t z = 0; z < nz; z++) {
       if (!key_earlier(c->zone_key[par][z], tag, idx)) continue;
@@ -2522,6 +2524,9 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
   const uint32_t idx = a.opidx[wid];
   const Plan *pl = &a.plans[wid];
   const PlanHead h = load_plan_head(pl, lane);
+  // the update itself: requested as soon as its index is known (unconditionally — slot 0 for waves beyond the horizon), so
+  // that it travels while the region checks below wait for their own loads instead of after them
+  const Op op = a.ops[(wid < hor) ? idx : 0u];
   if (f_done || f_viol || f_excl || f_err) return;
   if (wid >= hor) return;
   if (!(st & OS_PASS)) return;
@@ -2590,7 +2595,6 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
     }
     return;
   }
-  const Op op = a.ops[idx];
   // a window too large for one wave goes to a workgroup of o_big: take a queue slot BEFORE touching the state (a full queue
   // leaves the update pending for the next round)
   dev::BigJob *job = nullptr;
