@@ -215,28 +215,35 @@ int pppcsr_xchg_pack(pppcsr_xchg_t x, const ppcsr_op *d_ops, uint64_t n, uint64_
 int pppcsr_xchg_layout(pppcsr_xchg_t x, const uint64_t *recv_counts, ppcsr_op **d_dst);
 int pppcsr_xchg_apply(pppcsr_xchg_t x);
 int pppcsr_xchg_set_num_neighbors(pppcsr_xchg_t x); /* the routed records are (vertex, num_neighbors, *): see pppcsr_repartition_export */
+int pppcsr_xchg_bulk_build(pppcsr_xchg_t x);        /* the routed records are the adds EMPTY partitions are bulk-built from: idem */
 int pppcsr_comm_unique_id(void *id_out_128_bytes);
 int pppcsr_comm_create(const void *id_128_bytes, int n_ranks, int rank, int device, pppcsr_comm_t *out);
 int pppcsr_comm_destroy(pppcsr_comm_t c);
 int pppcsr_exchange_apply(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_ops, uint64_t n);
 int pppcsr_exchange_set_num_neighbors(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_recs, uint64_t n);
+int pppcsr_exchange_bulk_build(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_adds, uint64_t n);
 
 /* ---- repartitioning.  The reference only sketches it (PCSR.h:91-112 is commented out), so there
  * is no reference behaviour to match; the rule here is deterministic and the tests rebuild it with the oracle:
  * new_starts[P] = first global vertex of every partition (new_starts[0] = 0, non-decreasing).  A partition whose vertex
  * range is unchanged keeps its array as it is.  A partition whose range changes is recreated empty at its new size, and
  * the edges of all such partitions are returned as adds of the global stream — (global src, dest, value), ascending
- * (src, dest) — in device memory owned by the handle (valid until the next call): route them like any batch
- * (pppcsr_apply_batch_device in one process, pppcsr_exchange_apply across ranks; every rank calls with the same
- * new_starts).  num_neighbors is a counter of calls, not the degree (duplicate adds and deletes of missing edges move
- * it, PCSR.cpp:1380/1409), so it travels beside the edges: d_nn holds one record (global vertex, num_neighbors, 1) per
- * vertex of the changed partitions, to be routed the same way AFTER the adds (pppcsr_set_num_neighbors_device /
- * pppcsr_exchange_set_num_neighbors / pppcsr_xchg_set_num_neighbors).  pppcsr_repartition does all of it when every
- * partition is resident in this process.
+ * (src, dest) — in device memory owned by the handle (valid until the next call).  They are routed like any batch (owner
+ * bucketing by the new starts; the exchange across ranks, every rank calling with the same new_starts) into the BULK BUILD
+ * of the recreated partitions (ppcsr_bulk_build's rules: a valid packed-memory array with these edges, not the layout
+ * one-by-one inserts would leave — there is no reference layout here, and a source-sorted stream through the exact path
+ * is the hot-vertex worst case): pppcsr_bulk_build_device in one process, pppcsr_exchange_bulk_build across ranks,
+ * pppcsr_xchg_bulk_build with a carrier of your own.  num_neighbors is a counter of calls, not the degree (duplicate adds
+ * and deletes of missing edges move it, PCSR.cpp:1380/1409), so it travels beside the edges: d_nn holds one record
+ * (global vertex, num_neighbors, 1) per vertex of the changed partitions, routed the same way AFTER the build
+ * (pppcsr_set_num_neighbors_device / pppcsr_exchange_set_num_neighbors / pppcsr_xchg_set_num_neighbors).
+ * pppcsr_repartition does all of it when every partition is resident in this process.  Updates applied afterwards go
+ * through the ordinary (sequentially exact) path.
  * pppcsr_balanced_starts proposes starts of about equal weight, weight(v) = num_neighbors(v) + 1. */
 int pppcsr_repartition_export(pppcsr_t h, const uint64_t *new_starts, const ppcsr_op **d_ops, uint64_t *n, const ppcsr_op **d_nn,
                               uint64_t *n_nn);
 int pppcsr_set_num_neighbors_device(pppcsr_t h, const ppcsr_op *d_recs, uint64_t n);
+int pppcsr_bulk_build_device(pppcsr_t h, const ppcsr_op *d_adds, uint64_t n); /* global src; every receiving partition must be empty */
 int pppcsr_repartition(pppcsr_t h, const uint64_t *new_starts);
 int pppcsr_balanced_starts(pppcsr_t h, uint64_t *starts_out);
 

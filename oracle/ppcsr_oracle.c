@@ -537,6 +537,20 @@ uint64_t po_get_neighbourhood(const po_pcsr *p, int src, int *out, uint64_t cap)
 }
 /* test hook: run the reference's redistribute() on an arbitrary aligned window */
 void po_debug_redistribute(po_pcsr *p, uint64_t index, uint64_t len) { po_redistribute(p, (int64_t)index, (int64_t)len); }
+/* test hook (no reference equivalent): an oracle that starts from a given raw state — edges[N] and nodes[n] as exported —
+ * so that updates applied after a non-parity step (bulk build, repartitioning) can still be checked one by one */
+po_pcsr *po_import_state(uint64_t N, const uint32_t *items3, uint32_t n, const uint32_t *nodes3, int lock_search) {
+  po_pcsr *p = (po_pcsr *)calloc(1, sizeof(po_pcsr));
+  p->lock_search = lock_search;
+  po_resize_geometry(p, N);
+  p->items = (po_edge *)malloc(p->N * sizeof(po_edge));
+  memcpy(p->items, items3, p->N * sizeof(po_edge));
+  p->n = n;
+  p->ncap = n ? n : 1;
+  p->nodes = (po_node *)calloc(p->ncap, sizeof(po_node));
+  if (n) memcpy(p->nodes, nodes3, (size_t)n * sizeof(po_node));
+  return p;
+}
 /* test hook for the repartitioning tests (no reference equivalent): overwrite a vertex's call counter */
 void po_set_num_neighbors(po_pcsr *p, uint32_t v, uint32_t nn) { if (v < p->n) p->nodes[v].num_neighbors = nn; }
 void po_get_stats(const po_pcsr *p, po_stats *out) { *out = p->st; }

@@ -54,6 +54,7 @@ void po_export(const po_pcsr *p, uint32_t *items3, uint32_t *nodes3);
 uint64_t po_get_neighbourhood(const po_pcsr *p, int src, int *out, uint64_t cap);
 void po_debug_redistribute(po_pcsr *p, uint64_t index, uint64_t len);
 void po_set_num_neighbors(po_pcsr *p, uint32_t v, uint32_t nn);
+po_pcsr *po_import_state(uint64_t N, const uint32_t *items3, uint32_t n, const uint32_t *nodes3, int lock_search);
 void po_get_stats(const po_pcsr *p, po_stats *out);
 void po_reset_stats(po_pcsr *p);
 /* exact redistribute target positions (PCSR.cpp:237-247) for a window; out[k] = slot of element k */

@@ -49,7 +49,8 @@ EXPORTED = [
     "pppcsr_comm_unique_id", "pppcsr_comm_create", "pppcsr_comm_destroy", "pppcsr_exchange_apply",
     "pppcsr_xchg_create", "pppcsr_xchg_destroy", "pppcsr_xchg_pack", "pppcsr_xchg_layout", "pppcsr_xchg_apply",
     "pppcsr_repartition_export", "pppcsr_repartition", "pppcsr_balanced_starts", "pppcsr_set_num_neighbors_device",
-    "pppcsr_xchg_set_num_neighbors", "pppcsr_exchange_set_num_neighbors",
+    "pppcsr_xchg_set_num_neighbors", "pppcsr_exchange_set_num_neighbors", "pppcsr_bulk_build_device", "pppcsr_xchg_bulk_build",
+    "pppcsr_exchange_bulk_build",
 ]
 
 _LIBS = {}
@@ -147,6 +148,9 @@ def load_library(path=None):
     L.pppcsr_repartition_export.argtypes = [c_vp, c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_u64), ctypes.POINTER(c_vp), ctypes.POINTER(c_u64)]
     L.pppcsr_set_num_neighbors_device.argtypes = [c_vp, c_vp, c_u64]
     L.pppcsr_xchg_set_num_neighbors.argtypes = [c_vp]
+    L.pppcsr_xchg_bulk_build.argtypes = [c_vp]
+    L.pppcsr_bulk_build_device.argtypes = [c_vp, c_vp, c_u64]
+    L.pppcsr_exchange_bulk_build.argtypes = [c_vp, c_vp, c_vp, c_u64]
     L.pppcsr_exchange_set_num_neighbors.argtypes = [c_vp, c_vp, c_vp, c_u64]
     L.pppcsr_repartition.argtypes = [c_vp, c_vp]
     L.pppcsr_balanced_starts.argtypes = [c_vp, c_vp]
@@ -441,6 +445,15 @@ class PPPCSR:
     def xchg_set_num_neighbors(self):
         self._chk(self.L.pppcsr_xchg_set_num_neighbors(self.xchg))
 
+    def xchg_bulk_build(self):
+        self._chk(self.L.pppcsr_xchg_bulk_build(self.xchg))
+
+    def bulk_build_device(self, dev_ptr, n):
+        self._chk(self.L.pppcsr_bulk_build_device(self.h, dev_ptr, n))
+
+    def exchange_bulk_build(self, dev_ptr, n):
+        self._chk(self.L.pppcsr_exchange_bulk_build(self.h, self.comm, dev_ptr, n))
+
     def exchange_set_num_neighbors(self, dev_ptr, n):
         self._chk(self.L.pppcsr_exchange_set_num_neighbors(self.h, self.comm, dev_ptr, n))
 
@@ -455,7 +468,8 @@ class PPPCSR:
 
     def repartition_export(self, new_starts):
         """-> ((device address, n) of the edges on the move as adds of the global stream, (device address, n) of the
-        num_neighbors records); route the first like any batch, then the second through the set_num_neighbors calls"""
+        num_neighbors records); route the first into the bulk build of the recreated partitions (bulk_build_device /
+        exchange_bulk_build / xchg_bulk_build), then the second through the set_num_neighbors calls"""
         st = np.ascontiguousarray(new_starts, np.uint64)
         assert st.size == self.num_partitions()
         d, n, dn, nn = c_vp(), c_u64(), c_vp(), c_u64()

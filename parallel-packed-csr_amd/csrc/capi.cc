@@ -376,7 +376,8 @@ int pppcsr_bucket_ops_device(uint32_t init_n, uint64_t n_parts, const ppcsr_op *
 // reference runs every domain's workers concurrently (thread_pool_pppcsr.cpp:121-156) — so the latency-bound round
 // kernels of different partitions overlap on the GPU(s).  Each partition still applies its own subsequence in stream order.
 // ops[i] / counts[i] belong to partition first + i; `device_resident` selects the entry point.
-enum { PARTS_HOST = 0, PARTS_DEVICE = 1, PARTS_SET_NN = 2 };  // what the routed records are: updates (host / HBM) or num_neighbors records
+// what the routed records are: updates (host / HBM), num_neighbors records, or the adds an EMPTY partition is bulk-built from
+enum { PARTS_HOST = 0, PARTS_DEVICE = 1, PARTS_SET_NN = 2, PARTS_BULK = 3 };
 static int apply_parts(pppcsr_t h, uint64_t first, uint64_t np, const ppcsr_op *const *ops, const uint64_t *counts, int kind) {
   for (uint64_t i = 0; i < np; i++)
     if (counts[i] && (first + i >= h->parts.size() || !h->parts[first + i])) return bad("partition not resident in this process");
@@ -384,6 +385,8 @@ static int apply_parts(pppcsr_t h, uint64_t first, uint64_t np, const ppcsr_op *
     if (!counts[i]) return 0;
     if (kind == PARTS_SET_NN)
       return ret(h->parts[first + i]->e, h->parts[first + i]->e->set_num_neighbors_device(reinterpret_cast<const ppcsr::Op *>(ops[i]), counts[i]));
+    if (kind == PARTS_BULK)
+      return ret(h->parts[first + i]->e, h->parts[first + i]->e->bulk_build_device(reinterpret_cast<const ppcsr::Op *>(ops[i]), counts[i], nullptr));
     return kind == PARTS_DEVICE ? ppcsr_apply_batch_device(h->parts[first + i], ops[i], counts[i])
                                 : ppcsr_apply_batch(h->parts[first + i], ops[i], counts[i]);
   };
@@ -487,6 +490,7 @@ static int route_device(pppcsr_t h, const ppcsr_op *d_ops, uint64_t n, int kind)
 }
 int pppcsr_apply_batch_device(pppcsr_t h, const ppcsr_op *d_ops, uint64_t n) { return route_device(h, d_ops, n, PARTS_DEVICE); }
 int pppcsr_set_num_neighbors_device(pppcsr_t h, const ppcsr_op *d_recs, uint64_t n) { return route_device(h, d_recs, n, PARTS_SET_NN); }
+int pppcsr_bulk_build_device(pppcsr_t h, const ppcsr_op *d_adds, uint64_t n) { return route_device(h, d_adds, n, PARTS_BULK); }
 
 // ---- owner exchange in three steps: pack -> transport -> apply (thread_pool_pppcsr.cpp:96-118 replaced across processes) ----
 // The staging object below knows nothing about the carrier: pppcsr_exchange_apply moves the bytes with RCCL, the tests move
@@ -627,6 +631,7 @@ static int xchg_finish(pppcsr_xchg_t x, int kind) {
 }
 int pppcsr_xchg_apply(pppcsr_xchg_t x) { return xchg_finish(x, PARTS_DEVICE); }
 int pppcsr_xchg_set_num_neighbors(pppcsr_xchg_t x) { return xchg_finish(x, PARTS_SET_NN); }
+int pppcsr_xchg_bulk_build(pppcsr_xchg_t x) { return xchg_finish(x, PARTS_BULK); }
 }  // extern "C"
 
 // ---- the RCCL carrier: grouped ncclSend / ncclRecv on a HIP stream, no torch in the data path ----
@@ -735,6 +740,7 @@ int pppcsr_exchange_apply(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_ops, ui
 int pppcsr_exchange_set_num_neighbors(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_recs, uint64_t n) {
   return exchange_run(h, c, d_recs, n, PARTS_SET_NN);
 }
+int pppcsr_exchange_bulk_build(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_adds, uint64_t n) { return exchange_run(h, c, d_adds, n, PARTS_BULK); }
 }  // extern "C"
 #else
 extern "C" {
@@ -743,6 +749,7 @@ int pppcsr_comm_create(const void *, int, int, int, pppcsr_comm_t *) { return ba
 int pppcsr_comm_destroy(pppcsr_comm_t) { return 0; }
 int pppcsr_exchange_apply(pppcsr_t, pppcsr_comm_t, const ppcsr_op *, uint64_t) { return bad("no RCCL in the CPU emulator build"); }
 int pppcsr_exchange_set_num_neighbors(pppcsr_t, pppcsr_comm_t, const ppcsr_op *, uint64_t) { return bad("no RCCL in the CPU emulator build"); }
+int pppcsr_exchange_bulk_build(pppcsr_t, pppcsr_comm_t, const ppcsr_op *, uint64_t) { return bad("no RCCL in the CPU emulator build"); }
 }  // extern "C"
 #endif
 
@@ -750,9 +757,11 @@ extern "C" {
 // ---- repartitioning (the reference only sketches it: PCSR.h:91-112 was never implemented) ----
 // The vertex ranges move; the edges of every partition whose range changes leave it as adds of the global stream
 // (src global, array order = ascending (src, dest)), the partition is recreated empty at its new size, and the caller
-// routes the adds with the ordinary machinery — pppcsr_apply_batch_device in one process, pppcsr_exchange_apply across
-// ranks (ranks hold ascending ranges, so per-partition order stays ascending).  Partitions whose range stays keep their
-// array untouched.  Scheduler options set on a recreated partition's engine return to their defaults.
+// routes the adds with the ordinary machinery (owner bucketing by the new starts, the exchange across ranks) into the BULK
+// BUILD of the recreated partitions (pppcsr_bulk_build_device / pppcsr_exchange_bulk_build / pppcsr_xchg_bulk_build): a
+// source-sorted stream of a whole partition through the exact one-by-one path is the hot-vertex worst case (minutes for
+// 10^8 edges), and there is no reference layout to reproduce anyway.  Partitions whose range stays keep their array
+// untouched.  Scheduler options set on a recreated partition's engine return to their defaults.
 int pppcsr_repartition_export(pppcsr_t h, const uint64_t *new_starts, const ppcsr_op **d_ops, uint64_t *n_out, const ppcsr_op **d_nn,
                               uint64_t *n_nn) {
   PP_CHECK();
@@ -831,7 +840,7 @@ int pppcsr_repartition(pppcsr_t h, const uint64_t *new_starts) {
   uint64_t n = 0, nn = 0;
   int rc = pppcsr_repartition_export(h, new_starts, &d, &n, &dn, &nn);
   if (rc != 0) return rc;
-  rc = pppcsr_apply_batch_device(h, d, n);
+  rc = pppcsr_bulk_build_device(h, d, n);
   if (rc != 0) return rc;
   return pppcsr_set_num_neighbors_device(h, dn, nn);
 }

@@ -1809,7 +1809,9 @@ static int sort_edges_stable(gpu::stream_t st, unsigned long long *kin, unsigned
 #endif
 }
 
-int Engine::bulk_build(const Op *host_ops, uint64_t m, double *device_ms) {
+int Engine::bulk_build(const Op *host_ops, uint64_t m, double *device_ms) { return bulk_build_from(host_ops, false, m, device_ms); }
+int Engine::bulk_build_device(const Op *d_adds, uint64_t m, double *device_ms) { return bulk_build_from(d_adds, true, m, device_ms); }
+int Engine::bulk_build_from(const Op *in_ops, bool on_device, uint64_t m, double *device_ms) {
   Impl &p = *p_;
   GCHK(gpu::set_device(device_));
   const uint32_t nn = n();
@@ -1828,17 +1830,18 @@ int Engine::bulk_build(const Op *host_ops, uint64_t m, double *device_ms) {
   DevGuard tmpg;
   tmpg.add(&d_ops); tmpg.add(&d_k0); tmpg.add(&d_k1); tmpg.add(&d_v0); tmpg.add(&d_v1); tmpg.add(&d_flags);
   const uint64_t mm = std::max<uint64_t>(m, 1);
-  GCHK(gpu::dmalloc((void **)&d_ops, mm * sizeof(Op)));
+  if (!on_device) GCHK(gpu::dmalloc((void **)&d_ops, mm * sizeof(Op)));
   GCHK(gpu::dmalloc((void **)&d_k0, mm * sizeof(unsigned long long)));
   GCHK(gpu::dmalloc((void **)&d_k1, mm * sizeof(unsigned long long)));
   GCHK(gpu::dmalloc((void **)&d_v0, mm * sizeof(uint32_t)));
   GCHK(gpu::dmalloc((void **)&d_v1, mm * sizeof(uint32_t)));
   GCHK(gpu::dmalloc((void **)&d_flags, mm * sizeof(uint32_t)));
-  if (m) GCHK(gpu::h2d(d_ops, host_ops, m * sizeof(Op), p.stream));
+  if (m && !on_device) GCHK(gpu::h2d(d_ops, in_ops, m * sizeof(Op), p.stream));
+  const Op *src_ops = on_device ? in_ops : (const Op *)d_ops;
   p.timer.start(p.stream);
   uint64_t E = 0;
   if (m) {
-    GPU_LAUNCH(p.stream, k_bb_keys, grid_for(m, 256), 256, (const Op *)d_ops, m, nn, d_k0, d_v0);
+    GPU_LAUNCH(p.stream, k_bb_keys, grid_for(m, 256), 256, src_ops, m, nn, d_k0, d_v0);
     unsigned bits = 1;  // the source half of the key never exceeds n (entries to ignore carry src = n)
     while (bits < 32 && ((uint64_t)nn >> bits) != 0) bits++;
     int rc = sort_edges_stable(p.stream, d_k0, d_k1, d_v0, d_v1, m, 32u + bits);

@@ -53,6 +53,7 @@ class Engine {
   int scan_all_device(double *ms, uint64_t *total);  // device-only timing of the bulk scan (bench)
   // graph-algorithm consumers over the gapped array (reference: src/utility/bfs.h, src/utility/pagerank.h)
   int bulk_build(const Op *host_ops, uint64_t m, double *device_ms);  // non-parity fast path
+  int bulk_build_device(const Op *d_adds, uint64_t m, double *device_ms);  // the same, adds already in HBM (pppcsr_repartition)
   int bfs(uint32_t start, uint32_t *levels, double *device_ms);
   int pagerank(const float *node_values, float *out, double *device_ms);
   int export_state(Edge *items, Node *nodes);
@@ -91,6 +92,7 @@ class Engine {
   int run_speculative(const Op *d_ops, uint64_t n);
   int rebalance_fused(const View &nv, const Edge *src_items, uint64_t src_lo, uint64_t src_len, int src_sh, uint32_t *src_cnt,
                       bool inplace, uint64_t tb_index, uint64_t tb_len, Edge *dst, uint64_t dst_bias, uint32_t *dst_cnt, uint64_t dst_nleaves);
+  int bulk_build_from(const Op *in_ops, bool on_device, uint64_t m, double *device_ms);
   int scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap, const float *d_values = nullptr, float *d_contrib = nullptr,
                   Op *d_triples = nullptr, uint32_t src_base = 0);
 

@@ -163,33 +163,35 @@ def live_triples(items, base=0):
     return out
 
 
-def oracle_repartition(parts, old_starts, new_starts, total_n, make):
-    """the rule of pppcsr_repartition (include/ppcsr.h) restated over per-partition oracles: partitions whose vertex range
-    changes are recreated empty (make(size)) and receive, in ascending (src, dest) order, the edges of all changed
-    partitions that now fall into their range, then every vertex's num_neighbors as it was; the others are left as they
-    are.  Returns the new list of partitions."""
-    P = len(parts)
+def check_repartitioned(new_states, old_states, old_starts, new_starts, total_n, build_bulk):
+    """the rule of pppcsr_repartition (include/ppcsr.h) checked on raw states: new_states[k] / old_states[k] = (items, nodes) of
+    partition k after / before.  A partition whose vertex range did not change is untouched bit for bit.  A changed one
+    equals what the SAME bulk path builds from the edges that fall into its new range — build_bulk(size, adds) -> (items,
+    nodes) of a fresh engine of `size` vertices bulk-built from `adds` (partition-local src, ascending (src, dest)) — except
+    for num_neighbors, which every vertex carries over unchanged (it is a counter of calls, not the degree)."""
+    P = len(old_states)
     end = lambda st, k: int(st[k + 1]) if k + 1 < P else int(total_n)
     changed = [int(old_starts[k]) != int(new_starts[k]) or end(old_starts, k) != end(new_starts, k) for k in range(P)]
-    moved = [live_triples(parts[k].state()[0], int(old_starts[k])) for k in range(P) if changed[k]]
+    moved = [live_triples(old_states[k][0], int(old_starts[k])) for k in range(P) if changed[k]]
     moved = np.concatenate(moved) if moved else np.zeros((0, 3), np.uint32)
-    nn = {}  # num_neighbors travels with the vertex (a counter of calls, not the degree)
+    nn_old = np.concatenate([np.asarray(old_states[k][1], np.uint32).reshape(-1, 3)[:, 2] for k in range(P)])  # by global vertex
     for k in range(P):
-        if changed[k]:
-            for v, c in enumerate(parts[k].state()[1][:, 2]):
-                nn[int(old_starts[k]) + v] = int(c)
-    out = []
-    for k in range(P):
-        if not changed[k]:
-            out.append(parts[k])
-            continue
+        it, nd = new_states[k]
+        nd = np.asarray(nd, np.uint32).reshape(-1, 3)
         lo, hi = int(new_starts[k]), end(new_starts, k)
-        o = make(hi - lo)
+        assert len(nd) == hi - lo, f"partition {k}: {len(nd)} vertices, range [{lo}, {hi})"
+        if not changed[k]:
+            assert np.array_equal(it, old_states[k][0]) and np.array_equal(nd, np.asarray(old_states[k][1], np.uint32).reshape(-1, 3)), f"partition {k} was to stay untouched"
+            continue
         sub = moved[(moved[:, 0] >= lo) & (moved[:, 0] < hi)].copy()
         sub[:, 0] -= np.uint32(lo)
+        if hi > lo:
+            eit, end_ = build_bulk(hi - lo, sub)
+            end_ = np.asarray(end_, np.uint32).reshape(-1, 3)
+            assert np.array_equal(it, eit), f"partition {k}: edges[] differ from the bulk build of its new range"
+            assert np.array_equal(nd[:, :2], end_[:, :2]), f"partition {k}: vertex ranges differ from the bulk build"
+        np.testing.assert_array_equal(nd[:, 2], nn_old[lo:hi], err_msg=f"partition {k}: num_neighbors not carried over")
+        if hi > lo:
+            check_pma_invariants(np.asarray(it, np.uint32).reshape(-1, 3), nd)
         if len(sub):
-            o.apply(sub)  # (src, dest, op = value): an add of that value
-        for v in range(lo, hi):
-            o.set_num_neighbors(v - lo, nn[v])
-        out.append(o)
-    return out
+            np.testing.assert_array_equal(live_triples(it, lo), sub + np.array([lo, 0, 0], np.uint32))

@@ -50,6 +50,8 @@ def _load_oracle():
     L.po_reset_stats.argtypes = [c_vp]
     L.po_debug_redistribute.argtypes = [c_vp, c_u64, c_u64]
     L.po_set_num_neighbors.argtypes = [c_vp, c_u32, c_u32]
+    L.po_import_state.restype = c_vp
+    L.po_import_state.argtypes = [c_u64, c_vp, c_u32, c_vp, c_int]
     L.po_redistribute_positions.argtypes = [c_u64, c_u64, c_u64, c_vp]
     L.pop_create.restype = c_vp
     L.pop_create.argtypes = [c_u32, c_u32, c_int, c_int, c_int]
@@ -112,6 +114,17 @@ class Oracle(_State):
         self.L = oracle_lib()
         self.own = handle is None
         self.h = handle if handle is not None else self.L.po_create(init_n, init_n if src_n is None else src_n, int(lock_search))
+
+    @classmethod
+    def from_state(cls, items, nodes, lock_search=True):
+        """an oracle that starts from a raw exported state (edges[N], nodes[n]): what follows a non-parity step"""
+        items = np.ascontiguousarray(items, np.uint32)
+        nodes = np.ascontiguousarray(nodes, np.uint32)
+        L = oracle_lib()
+        h = L.po_import_state(len(items), items.ctypes.data, len(nodes), nodes.ctypes.data if len(nodes) else None, int(lock_search))
+        o = cls(0, handle=h)
+        o.own = True
+        return o
 
     def close(self):
         if self.own and self.h:

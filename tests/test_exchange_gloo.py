@@ -129,7 +129,7 @@ def _sim_tune(pp, ks):
             e.set_option(key, v)
 
 
-def _gloo_exchange(pp, world, rank, ppr, blk, set_nn=False):
+def _gloo_exchange(pp, world, rank, ppr, blk, finish="apply"):
     """one batch through pack -> (gloo) -> layout -> apply.  blk: this rank's block, a (n,3) uint32 array or a (address, n) pair"""
     import ctypes
     addr, n = (blk.ctypes.data, len(blk)) if isinstance(blk, np.ndarray) else blk
@@ -163,7 +163,7 @@ def _gloo_exchange(pp, world, rank, ppr, blk, set_nn=False):
             if c:
                 ctypes.memmove(dst[r * ppr + q], rows[o:o + c].ctypes.data, c * 12)
             o += c
-    pp.xchg_set_num_neighbors() if set_nn else pp.xchg_apply()
+    {"apply": pp.xchg_apply, "set_nn": pp.xchg_set_num_neighbors, "bulk": pp.xchg_bulk_build}[finish]()
 
 
 def _worker_native(rank, world, port, n_global, n_parts, blocks, new_starts, after, q):
@@ -181,16 +181,17 @@ def _worker_native(rank, world, port, n_global, n_parts, blocks, new_starts, aft
     pp.xchg_create(world, rank)
     for blk in blocks[rank]:
         _gloo_exchange(pp, world, rank, ppr, blk)
-    snap = [(pp.partition(k).state(), pp.partition(k).geometry()) for k in mine]
-    # repartition across the ranks: the edges on the move are one more block of the global stream
+    snap = [pp.partition(k).state() for k in mine]
+    # repartition across the ranks: the edges on the move and the counters beside them are two more blocks of the exchange
     moved, nn_recs = pp.repartition_export(new_starts)
     _sim_tune(pp, mine)
-    _gloo_exchange(pp, world, rank, ppr, moved)
-    _gloo_exchange(pp, world, rank, ppr, nn_recs, set_nn=True)
-    mid = [(pp.partition(k).state(), pp.partition(k).geometry()) for k in mine]
+    _gloo_exchange(pp, world, rank, ppr, moved, finish="bulk")
+    _gloo_exchange(pp, world, rank, ppr, nn_recs, finish="set_nn")
+    _sim_tune(pp, mine)
+    mid = [pp.partition(k).state() for k in mine]
     _gloo_exchange(pp, world, rank, ppr, after[rank])
-    end = [(pp.partition(k).state(), pp.partition(k).geometry()) for k in mine]
-    q.put((rank, [[digest(*s, g) for s, g in x] for x in (snap, mid, end)]))
+    end = [pp.partition(k).state() for k in mine]
+    q.put((rank, [snap, mid, end]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -198,7 +199,7 @@ def _worker_native(rank, world, port, n_global, n_parts, blocks, new_starts, aft
 @pytest.mark.parametrize("n_global,n_parts", [(600, 4), (403, 2)])
 def test_native_exchange_and_repartition_world2_hostsim(n_global, n_parts):
     from oracle_lib import Oracle, OraclePPPCSR
-    from helpers import oracle_repartition
+    from helpers import check_repartitioned
     from test_sim_engine import build_sim
     build_sim()
     streams = load_streams()
@@ -226,14 +227,32 @@ def test_native_exchange_and_repartition_world2_hostsim(n_global, n_parts):
     for k in range(2):
         pp.apply(np.concatenate([blocks[r][k] for r in range(world)]))
     parts = [pp.partition(k) for k in range(n_parts)]
-    dg = lambda ps: [digest(*p.state(), p.geometry()) for p in ps]
-    assert [d for r in range(world) for d in got[r][0]] == dg(parts), "after the exchanged batches"
-    parts = oracle_repartition(parts, old, new, n_global, lambda m: Oracle(m))
-    assert [d for r in range(world) for d in got[r][1]] == dg(parts), "after the repartition"
+    flat = lambda stage: [st for r in range(world) for st in got[r][stage]]
+    for k, (items, nodes) in enumerate(flat(0)):
+        oi, on = parts[k].state()
+        assert np.array_equal(items, oi) and np.array_equal(nodes, on), f"partition {k} after the exchanged batches"
+    # the repartition rule, checked on the raw states (the bulk path itself run on a fresh emulator engine)
+    from helpers import load_pkg
+    from test_sim_engine import SIM_SO
+    pkg = load_pkg()
+    lib = pkg.load_library(SIM_SO)
+
+    def build_bulk(size, adds):
+        e = pkg.PCSR(size, lib=lib)
+        e.bulk_build(adds)
+        out = e.state()
+        e.close()
+        return out
+
+    check_repartitioned(flat(1), flat(0), old, new, n_global, build_bulk)
+    # updates after the rebuild are exact again: oracles started from the rebuilt states
+    parts = [Oracle.from_state(*st) for st in flat(1)]
     glob = np.concatenate(after)
     own = np.searchsorted(new, glob[:, 0], side="right") - 1
     for k in range(n_parts):
         sub = glob[own == k].copy()
         sub[:, 0] -= np.uint32(new[k])
         parts[k].apply(sub)
-    assert [d for r in range(world) for d in got[r][2]] == dg(parts), "updates after the repartition"
+        oi, on = parts[k].state()
+        items, nodes = flat(2)[k]
+        assert np.array_equal(items, oi) and np.array_equal(nodes, on), f"partition {k}: updates after the repartition"

@@ -642,36 +642,44 @@ def _d2d(dst, src, nbytes):
 
 @pytest.mark.parametrize("P", [4, 8])
 def test_repartition(pkg, streams, P):
-    """pppcsr_repartition: edge set, num_neighbors and PMA invariants survive; partitions whose range stays keep
-    their array bit for bit; partitions that change equal the oracle rebuilt by the same rule (tests/helpers.py
-    oracle_repartition); updates applied afterwards stay bit-exact.  Skewed graph (RMAT labels), balanced starts."""
-    from helpers import check_pma_invariants, oracle_repartition
+    """pppcsr_repartition: partitions whose range stays are untouched bit for bit; partitions that change equal
+    what the same bulk path builds from the edges of their new range, with every vertex's num_neighbors carried over
+    (tests/helpers.py check_repartitioned: edge set, vertex ranges, PMA invariants); neighbourhoods survive; updates applied
+    afterwards are bit-exact against oracles started from the rebuilt states.  Skewed graph (RMAT labels) to balanced starts
+    and back; duplicates and deletes of missing edges in the load make num_neighbors differ from the degree."""
+    from helpers import check_repartitioned
     n = 1 << 14
     s_, d_ = streams.rmat_edges(14, 150000, seed=7)
-    core = streams.adds(s_, d_)
+    core = np.concatenate([streams.adds(s_, d_), streams.random_stream(n, 5000, seed=8, p_delete=1.0)])  # (RMAT repeats edges; + misses)
     pp = pkg.PPPCSR(n, numDomain=1, partitionsPerDomain=P)
-    o = OraclePPPCSR(n, True, 1, P)
     pp.apply(core)
-    o.apply(core)
-    parts = [o.partition(k) for k in range(P)]
     old = np.array([pp.partition_start(k) for k in range(P)], np.uint64)
-    before = [int(parts[k].state()[1][:, 2].astype(np.int64).sum()) for k in range(P)]
+    st0 = [pp.partition(k).state() for k in range(P)]
+    deg = np.concatenate([np.diff(np.append(np.nonzero(it[:, 1] == 0xFFFFFFFF)[0], len(it))) for it, _ in st0])
+    assert (np.concatenate([nd[:, 2] for _, nd in st0]).astype(np.int64) != (deg - 1)).any()  # counters are not degrees here
+    sizes_before = [int((it[:, 2] != 0).sum()) for it, _ in st0]
     adj_before = {v: pp.get_neighbourhood(v).copy() for v in range(0, n, 97)}
     st = pp.balanced_starts()
     assert st[0] == 0 and np.all(np.diff(st.astype(np.int64)) >= 0)
+
+    def build_bulk(size, adds):
+        e = pkg.PCSR(size)
+        e.bulk_build(adds)
+        out = e.state()
+        e.close()
+        return out
+
     for new in (st, old):  # to the balanced layout and back to the uniform one
-        parts = oracle_repartition(parts, old, new, n, lambda m: Oracle(m))
+        before = [pp.partition(k).state() for k in range(P)]
         pp.repartition(new)
-        assert pp.get_n() == n
+        assert pp.get_n() == n and [pp.partition_start(k) for k in range(P)] == [int(x) for x in new]
+        after = [pp.partition(k).state() for k in range(P)]
+        check_repartitioned(after, before, old, new, n, build_bulk)
         for k in range(P):
-            a, b = pp.partition(k), parts[k]
-            assert a.get_n() == b.get_n()
-            ai, an = a.state()
-            assert digest(ai, an, a.geometry()) == digest(*b.state(), b.geometry()), f"partition {k} after {new}"
-            assert a.check_invariants() == 0
-            check_pma_invariants(ai, an)
+            assert pp.partition(k).check_invariants() == 0
         for v, adj in adj_before.items():
             np.testing.assert_array_equal(pp.get_neighbourhood(v), adj)
+        parts = [Oracle.from_state(*after[k]) for k in range(P)]
         upd = streams.mixed_existing_stream(core[:50000], streams.random_stream(n, 30000, seed=int(new[1]) % 1000), seed=11)
         pp.apply(upd)
         own = np.searchsorted(new, upd[:, 0], side="right") - 1
@@ -683,8 +691,7 @@ def test_repartition(pkg, streams, P):
             assert digest(*a.state(), a.geometry()) == digest(*parts[k].state(), parts[k].geometry()), f"updates after {new}: {k}"
         adj_before = {v: pp.get_neighbourhood(v).copy() for v in range(0, n, 97)}
         old = new
-    after = [int(parts[k].state()[1][:, 2].astype(np.int64).sum()) for k in range(P)]
-    assert max(before) > 2 * min(before)  # (the raw RMAT labels were skewed to begin with)
+    assert max(sizes_before) > 2 * min(sizes_before)  # (the raw RMAT labels were skewed to begin with)
     pp.close()
 
 

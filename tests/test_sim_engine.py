@@ -480,10 +480,10 @@ def test_sim_bucket_kernels(streams):
 
 def test_sim_xchg_steps_and_repartition(streams):
     """one rank of the exchange (pack -> layout -> apply, the rows copied by hand) and pppcsr_repartition under the emulator:
-    unequal starts go through the boundary table of the bucketing kernels; the oracle mirror of the repartition rule is
-    tests/helpers.py oracle_repartition"""
+    unequal starts go through the boundary table of the bucketing kernels; the repartition rule is checked by
+    tests/helpers.py check_repartitioned, updates afterwards against oracles started from the rebuilt state"""
     import ctypes
-    from helpers import oracle_repartition
+    from helpers import check_repartitioned
     from oracle_lib import OraclePPPCSR
     build_sim()
     pkg = load_pkg()
@@ -528,14 +528,26 @@ def test_sim_xchg_steps_and_repartition(streams):
     assert st[0] == 0 and np.all(np.diff(st.astype(np.int64)) >= 0) and st[-1] <= n
     with pytest.raises(pkg.PpcsrError):
         pp.repartition(np.array([0, 150, 100, 200], np.uint64))
+
+    def build_bulk(size, adds):  # the same bulk path on a fresh engine
+        e = pkg.PCSR(size, lib=lib)
+        e.bulk_build(adds)
+        out = e.state()
+        e.close()
+        return out
+
     for new in (np.array([0, 50, 50, 299], np.uint64), st):
-        parts = oracle_repartition(parts, old, new, n, lambda m: Oracle(m))
+        before = [pp.partition(k).state() for k in range(P)]
         (d_moved, n_moved), (d_nn, n_nn) = pp.repartition_export(new)  # (pppcsr_repartition = these three steps; the recreated
         tune()                                                           #  engines get the emulator-sized options before they run)
-        pp.apply_device(d_moved, n_moved)
+        pp.bulk_build_device(d_moved, n_moved)
         pp.set_num_neighbors_device(d_nn, n_nn)
+        tune()
         assert [pp.partition_start(k) for k in range(P)] == [int(x) for x in new]
-        same(parts, f"repartition {new}")
+        after = [pp.partition(k).state() for k in range(P)]
+        check_repartitioned(after, before, old, new, n, build_bulk)
+        # updates after the (non-parity) rebuild are exact again: oracles started from the engine's state
+        parts = [Oracle.from_state(*after[k]) for k in range(P)]
         ops2 = streams.random_stream(n, 500, seed=6 + int(new[1]), p_delete=0.3)
         pp.apply(ops2)
         own = np.searchsorted(new, ops2[:, 0], side="right") - 1
