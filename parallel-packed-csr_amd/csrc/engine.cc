@@ -1032,6 +1032,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       a.defer_barrier = p.defer_barrier;
       a.zone_factor = p.zone_factor;
       const bool use_chain = p.chain == 2 || (p.chain == 1 && p.chain_on);
+      // the round kernels come in two instantiations: without / with the opt-in experiments and the diagnostics compiled in
+      const bool extras = p.chain != 0 || p.diag != 0 || p.zone_factor != 0 || p.chain_fence != 0;
       a.chain = use_chain ? std::max<uint32_t>(1u, p.chain_steps) : 0u;
       a.chain_fence = p.chain_fence;
       a.chshift = std::max(0, 10 - p.v.g.sh);
@@ -1081,12 +1083,12 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       for (uint32_t r = 0; r < rounds; r++) {
         a.round = ++p.round;
         if (p.profile) p.events[5 * r + 0].record(p.stream);
-        GPU_LAUNCH(p.stream, o_plan, blocks, 256, a);
+        if (extras) GPU_LAUNCH(p.stream, o_plan_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_plan, blocks, 256, a);
         if (use_chain) GPU_LAUNCH(p.stream, o_bscan, 1, 1024, a);  // (profile: counted with o_plan)
         if (p.profile) p.events[5 * r + 1].record(p.stream);
-        GPU_LAUNCH(p.stream, o_check, blocks, 256, a);
+        if (extras) GPU_LAUNCH(p.stream, o_check_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_check, blocks, 256, a);
         if (p.profile) p.events[5 * r + 2].record(p.stream);
-        GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
+        if (extras) GPU_LAUNCH(p.stream, o_apply_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
         if (use_chain) GPU_LAUNCH(p.stream, o_chain, p.chain_grid, 64, a);  // one wave per workgroup; (profile: counted with o_apply)
         if (p.profile) p.events[5 * r + 3].record(p.stream);
         GPU_LAUNCH(p.stream, o_compact, 1u + (use_big ? p.big_grid : 0u), 1024, a);  // workgroup 0 compacts, the others rebalance big windows

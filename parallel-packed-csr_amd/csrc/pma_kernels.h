@@ -2202,7 +2202,8 @@ PMA_DEV PlanHead load_plan_head(const Plan *pl, int lane) {
     }                                                                                         \
   } while (0)
 
-PMA_KERNEL void o_plan(OptArgs a) {
+template <bool EXTRAS>
+PMA_DEV void o_plan_t(const OptArgs &a) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
   const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
@@ -2227,7 +2228,7 @@ PMA_KERNEL void o_plan(OptArgs a) {
       pl->mv_lo = 1;
       pl->mv_hi = 0;
       pl->sleaf_b = pl->sleaf_e = 0;
-      if (a.chain) a.bk_pos[wid] = kMax;
+      if ((EXTRAS && a.chain)) a.bk_pos[wid] = kMax;
     }
     return;
   }
@@ -2238,7 +2239,7 @@ PMA_KERNEL void o_plan(OptArgs a) {
   const uint32_t kind = pr.kind;
   if (kind == K_EXCL) {
     if (lane == 0) wv::atomic_min_u64(&c->gbar[par], key);
-    if (lane == 0 && a.chain) a.bk_pos[wid] = kMax;
+    if (lane == 0 && (EXTRAS && a.chain)) a.bk_pos[wid] = kMax;
     return;
   }
   if (kind == K_DUP) {
@@ -2253,10 +2254,10 @@ PMA_KERNEL void o_plan(OptArgs a) {
     // is a candidate for a rollback
     if ((pr.wlen >= a.soft_barrier || (a.defer_barrier && wid < used && pr.wlen >= a.defer_barrier)) && lane == 0) {
       uint32_t zslot = kMaxZones;
-      if (a.zone_factor) zslot = wv::atomic_add_u32(&c->nzones[par], 1u);
+      if ((EXTRAS ? a.zone_factor : 0u)) zslot = wv::atomic_add_u32(&c->nzones[par], 1u);
       if (zslot < kMaxZones) {
         const uint32_t nleaves = (uint32_t)(a.v.g.N >> a.v.g.sh);
-        uint64_t zl = (uint64_t)(pr.wlen >> a.v.g.sh) * a.zone_factor;  // leaves in the block (a power of two when the factor is)
+        uint64_t zl = (uint64_t)(pr.wlen >> a.v.g.sh) * (EXTRAS ? a.zone_factor : 0u);  // leaves in the block (a power of two when the factor is)
         if (zl > nleaves) zl = nleaves;
         uint64_t blo = (uint64_t)(pr.wstart >> a.v.g.sh) / zl * zl, bhi = blo + zl - 1u;
         if (wl < blo) blo = wl;
@@ -2283,7 +2284,7 @@ PMA_KERNEL void o_plan(OptArgs a) {
     if (lane == 0 && (pr.sdep & 1u)) wv::atomic_min_u64(&a.v.vr[op.src], key);
     if (lane == 1 && (pr.sdep & 2u) && op.src + 1u < a.v.g.n) wv::atomic_min_u64(&a.v.vr[op.src + 1u], key);
   }
-  if (a.chain && lane == 0) {  // list the update under the region of its target slot (arrival order: o_chain sorts)
+  if ((EXTRAS && a.chain) && lane == 0) {  // list the update under the region of its target slot (arrival order: o_chain sorts)
     uint32_t region = kMax, pos = kMax;
     if (kind_real(kind)) {
       region = (pr.index >> a.v.g.sh) >> a.chshift;
@@ -2295,6 +2296,8 @@ PMA_KERNEL void o_plan(OptArgs a) {
     a.bk_reg[wid] = region;
   }
 }
+PMA_KERNEL void o_plan(OptArgs a) { o_plan_t<false>(a); }
+PMA_KERNEL void o_plan_x(OptArgs a) { o_plan_t<true>(a); }
 
 // A deferred update tells the regions it touches WITHOUT living there (its window, slide pad, growth block, read ranges or
 // the sentinels it locates its range by reach into them) that somebody earlier is still pending: a chain of that region
@@ -2324,7 +2327,8 @@ PMA_DEV void chain_list_entry(const OptArgs &a, OptCtl *c, uint32_t par, uint32_
   }
 }
 
-PMA_KERNEL void o_check(OptArgs a) {
+template <bool EXTRAS>
+PMA_DEV void o_check_t(const OptArgs &a) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
   const uint32_t wid = wv::block_idx() * (wv::block_dim() >> 6) + (uint32_t)wv::wave_in_block();
@@ -2350,8 +2354,8 @@ PMA_KERNEL void o_check(OptArgs a) {
     // (the barrier is earlier than all of them), so there is nobody to keep out of its regions and nothing to learn from
     // its footprint — which, for a climb towards the root, is every leaf of the array (a 3.5 ms walk by one wave, while
     // the rest of the launch waits).  Its stamps are looked at in the round that does check it.
-    if (a.diag && lane == 0) wv::atomic_add_u64(&c->why[why], 1ull);
-    if (lane == 0 && a.diag && a.dg != nullptr) {
+    if ((EXTRAS && a.diag) && lane == 0) wv::atomic_add_u64(&c->why[why], 1ull);
+    if (lane == 0 && (EXTRAS && a.diag) && a.dg != nullptr) {
       uint32_t *r = a.dg + 4ull * idx;
       r[0] += 1u;
       r[1] = why;
@@ -2359,11 +2363,11 @@ PMA_KERNEL void o_check(OptArgs a) {
       r[3] = h.wlen;
     }
     if (lane == 0) a.status[wid] = 0u;
-    if (a.chain && lane == 0) chain_list_entry(a, c, par, wid, false);
+    if ((EXTRAS && a.chain) && lane == 0) chain_list_entry(a, c, par, wid, false);
     return;
   }
-#define PMA_WHY(code) do { if (a.diag && (code) < why) why = (code); } while (0)
-#define PMA_WHYB(code, bkey) do { if (a.diag && (code) < why) { why = (code); blk = (uint32_t)(bkey); } } while (0)
+#define PMA_WHY(code) do { if ((EXTRAS && a.diag) && (code) < why) why = (code); } while (0)
+#define PMA_WHYB(code, bkey) do { if ((EXTRAS && a.diag) && (code) < why) { why = (code); blk = (uint32_t)(bkey); } } while (0)
   uint32_t blk = kMax;
   bool stamp_bad = false;
   const uint32_t me1 = idx + 1u;  // stamps hold (index + 1) of the latest committed toucher
@@ -2371,7 +2375,7 @@ PMA_KERNEL void o_check(OptArgs a) {
   const bool strong = kind_strong(kind);
   {  // zones of earlier soft-barrier updates: anything of ours inside one -> deferred (and treated like any other deferred
      // update below: it keeps later updates out of its own regions)
-    uint32_t nz = nzones;
+    uint32_t nz = EXTRAS ? nzones : 0u;
     if (nz > kMaxZones) nz = kMaxZones;
     for (uint32_t z = 0; z < nz; z++) {
       if (!key_earlier(c->zone_key[par][z], tag, idx)) continue;
@@ -2465,7 +2469,7 @@ PMA_KERNEL void o_check(OptArgs a) {
   }
   const bool anyfail = wv::ballot(fail) != 0;
   const bool anybad = wv::ballot(stamp_bad) != 0;
-  if (a.diag && anyfail) {
+  if ((EXTRAS && a.diag) && anyfail) {
     uint32_t w = why, wb = blk;
     for (int o = 32; o > 0; o >>= 1) {
       const uint32_t y = wv::shfl(w, lane ^ o), yb = wv::shfl(wb, lane ^ o);
@@ -2504,15 +2508,21 @@ PMA_KERNEL void o_check(OptArgs a) {
     if (lh > bh) bh = lh;
     if (bh >= nleaves) bh = nleaves - 1u;
     for (uint32_t leaf = bl + (uint32_t)lane; leaf <= bh; leaf += 64) wv::atomic_min_u64(&a.pfail[leaf], key);
-    if (a.chain) {  // (what it reserves NOW; its window may still grow — that is what validation is for)
+    if ((EXTRAS && a.chain)) {  // (what it reserves NOW; its window may still grow — that is what validation is for)
       const uint32_t xl = writes ? h.wleaf_lo : (h.index >> a.v.g.sh), xh = writes ? h.wleaf_hi : xl;
       mark_foreign_regions(a, h, pl, key, xl, xh, lane);
     }
   }
   if (lane == 0) a.status[wid] = (anyfail ? 0u : OS_PASS) | (anybad ? OS_STAMP_BAD : 0u);
-  if (a.chain && lane == 0) chain_list_entry(a, c, par, wid, !anyfail);
+  if ((EXTRAS && a.chain) && lane == 0) chain_list_entry(a, c, par, wid, !anyfail);
 }
 
+PMA_KERNEL void o_check(OptArgs a) { o_check_t<false>(a); }
+PMA_KERNEL void o_check_x(OptArgs a) { o_check_t<true>(a); }
+
+// EXTRAS = false: the opt-in experiments (chains, zones) and the diagnostics are compiled out — carried along as run-time
+// branches they cost the calm stream 4 % (config #2: 179 vs 187 M updates/s); the engine launches the *_x kernels when one is on
+template <bool EXTRAS>
 PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
@@ -2555,8 +2565,8 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
     if (lane == 0 && (h.sdep & 1u) && key_earlier(a.pfail[h.sleaf_b], tag, idx)) blocked = true;
     if (lane == 1 && (h.sdep & 2u) && key_earlier(a.pfail[h.sleaf_e], tag, idx)) blocked = true;
     const bool any_r = wv::ballot(blocked_r) != 0, any_p = wv::ballot(blocked) != 0;
-    if (a.diag && (any_r || any_p) && lane == 0) wv::atomic_add_u64(&c->why[any_r ? 8 : 9], 1ull);
-    if (a.diag && a.dg != nullptr && (any_r || any_p)) {
+    if ((EXTRAS && a.diag) && (any_r || any_p) && lane == 0) wv::atomic_add_u64(&c->why[any_r ? 8 : 9], 1ull);
+    if ((EXTRAS && a.diag) && a.dg != nullptr && (any_r || any_p)) {
       for (int o = 32; o > 0; o >>= 1) {
         const uint32_t y = wv::shfl(rblk, lane ^ o);
         rblk = y < rblk ? y : rblk;
@@ -2570,7 +2580,7 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
       }
     }
     if (any_r || any_p) {  // an earlier update of this region was deferred: keep stream order inside it
-      if (a.chain) {  // (still pending: chains of the other regions it touches must not overtake it)
+      if ((EXTRAS && a.chain)) {  // (still pending: chains of the other regions it touches must not overtake it)
         const uint32_t ll = writes ? h.wleaf_lo : (h.index >> a.v.g.sh), lh = writes ? h.wleaf_hi : ll;
         mark_foreign_regions(a, h, pl, key, ll, lh, lane);
       }
@@ -2578,7 +2588,7 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
     }
   }
   if (st & OS_STAMP_BAD) {
-    if (a.diag && lane == 0) wv::atomic_add_u64(&c->why[10], 1ull);
+    if ((EXTRAS && a.diag) && lane == 0) wv::atomic_add_u64(&c->why[10], 1ull);
     if (lane == 0) {
       const uint32_t prev = wv::atomic_min_u32(&c->viol_idx, idx);
       wv::atomic_exch_u32(&c->violation, 1u);
@@ -2625,7 +2635,7 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
       for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_max_u32(&a.vws[u], me1);
     }
   }
-  if (a.chain_fence & 512u) wv::fence_mode(128u);  // (experiment: write-back after every commit of o_apply)
+  if (EXTRAS && (a.chain_fence & 512u)) wv::fence_mode(128u);  // (experiment: write-back after every commit of o_apply)
   if (lane == 0) a.status[wid] = OS_COMMITTED;  // (the epoch's max committed index is reduced in o_compact: a
                                                 // per-update atomicMax on one word would serialise the whole round)
 }
@@ -3064,7 +3074,11 @@ PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p
 // measured again in round 2: 56 / 44 B of scratch per lane and 113-123 M updates/s against 141 at 6 waves per SIMD.)
 PMA_KERNEL void o_apply(OptArgs a) {
   PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
-  o_apply_wave(a, lds[wv::wave_in_block()]);
+  o_apply_wave<false>(a, lds[wv::wave_in_block()]);
+}
+PMA_KERNEL void o_apply_x(OptArgs a) {
+  PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
+  o_apply_wave<true>(a, lds[wv::wave_in_block()]);
 }
 
 // (Folding the compaction into o_apply's last-finishing workgroup was measured and dropped: the device-scope fences the
