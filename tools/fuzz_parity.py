@@ -53,17 +53,36 @@ for c in range(cases):
         opts.update(resident_waves=int(rng.choice([0, 512, 6144])), big_window=int(rng.choice([2048, 8192, 32768])),
                     soft_barrier=int(rng.choice([0, 1024, 1 << 30])), rb_inplace_min=int(rng.choice([0, 2048, 1 << 19])),
                     epoch_short=int(rng.choice([512, 16384])), epoch_grow_after=int(rng.choice([1, 2, 8])))
+    if rng.integers(0, 3) == 0:  # round-3 knobs: in-round chains, zones, destination-centric rebalance pass, diagnostics on
+        opts.update(chain=int(rng.choice([0, 2])), chain_steps=int(rng.choice([2, 16, 64])), zone_factor=int(rng.choice([0, 2, 8])),
+                    rb_gather=int(rng.integers(0, 2)), rb_run=int(rng.choice([0, 1, 5])), diag=int(rng.choice([0, 0, 1])))
     if rng.integers(0, 5) == 0:
         opts["mode"] = 0
     eng, o = pkg.PCSR(n, lock_search=lock), Oracle(n, lock_search=lock)
     for k, v in opts.items():
         eng.set_option(k, v)
     pos = 0
+    snap_at = int(rng.integers(0, m)) if rng.integers(0, 3) == 0 else -1  # incremental snapshot / restore somewhere in the stream
+    snapped = None
     while pos < m:
         step = int(rng.choice([1, 17, 300, 5000, 100_000]))
+        if snapped is None and snap_at >= 0 and pos >= snap_at:
+            eng.snapshot()
+            snapped = pos
         eng.apply(ops[pos:pos + step])
         pos += step
-    o.apply(ops)
+    if snapped is not None:  # back to the snapshot: must equal the oracle at that point; then the rest of the stream again
+        eng.restore()
+        o.apply(ops[:snapped])
+        ei, en = eng.state()
+        oi, on = o.state()
+        if not (eng.geometry() == o.geometry() and np.array_equal(ei, oi) and np.array_equal(en, on)):
+            print(f"case {c}: MISMATCH after restore to {snapped}", flush=True)
+            bad += 1
+        eng.apply(ops[snapped:])
+        o.apply(ops[snapped:])
+    else:
+        o.apply(ops)
     ei, en = eng.state()
     oi, on = o.state()
     ok = eng.geometry() == o.geometry() and np.array_equal(ei, oi) and np.array_equal(en, on)
