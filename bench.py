@@ -210,8 +210,17 @@ def main():
     carrier = {"use_native": False, "note": None}
 
     def new_uid():
-        uid = [pkg.PPPCSR.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)  # (bootstrap only: 128 bytes)
+        # (bootstrap only: 128 bytes.  Rank 0 always takes part in the broadcast, also when it could not make an id —
+        #  the other ranks would wait for it for ever otherwise — and then every rank fails the same way)
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [pkg.PPPCSR.comm_unique_id()]
+            except Exception as ex:  # noqa: BLE001
+                log(0, f"WARNING: no RCCL unique id: {ex}")
+        dist.broadcast_object_list(uid, src=0)
+        if uid[0] is None:
+            raise RuntimeError("rank 0 could not create an RCCL unique id")
         return uid[0]
 
     def torch_exchange_apply(pp_, ops_dev, n_, cap=None):
