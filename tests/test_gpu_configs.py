@@ -161,3 +161,24 @@ def test_bench_two_ranks_on_one_gpu():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["parity_checked"] is True and out["value"] > 0
     assert "8 partition(s), 4 per GPU x 2 GPU(s)" in out["config"]["parallelism"]
+
+
+def test_bench_config4_legs_small():
+    """`bench.py --config 4` with its secondary legs (raw labels, raw labels after pppcsr_repartition to balanced ranges, the
+    config #5 stream) on a small graph: every leg produces a number, the checked ones are bit-exact"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--vertices", "200000", "--scale", "18", "--core-edges", "2000000",
+           "--batch", "200000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-profile"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["parity_checked"] is True
+    for leg in ("raw_labels", "raw_labels_repartitioned", "config5_zipf"):
+        assert leg in out and out[leg]["value"] > 0, (leg, {k: v for k, v in out.items() if k.endswith("_error")})
+    rp = out["raw_labels_repartitioned"]
+    assert rp["starts"][0] == 0 and len(rp["starts"]) == 8 and rp["repartition_s"] > 0
+    assert out["config5_zipf"]["parity_checked"] is True
