@@ -2339,7 +2339,7 @@ int bucket_ops_device(const uint32_t *starts, uint32_t n_parts, const Op *d_ops,
     return e ? failm("hipMemsetAsync", e) : (int)PPCSR_OK;
   }
   GPU_LAUNCH(st, k_bucket_hist, ntiles, 256, d_ops, n, tab, n_parts, d_hist);
-  GPU_LAUNCH(st, k_bucket_scan, 1, 64, d_hist, ntiles, n_parts, d_counts);
+  GPU_LAUNCH(st, k_bucket_scan, 1, kBucketScanThreads, d_hist, ntiles, n_parts, d_counts);
   GPU_LAUNCH(st, k_bucket_scatter, ntiles, 256, d_ops, n, tab, n_parts, (const uint32_t *)d_hist, d_out);
   int e = gpu::last_error();
   return e ? failm("bucket kernels", e) : (int)PPCSR_OK;

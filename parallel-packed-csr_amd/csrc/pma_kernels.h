@@ -3182,24 +3182,42 @@ PMA_KERNEL void k_bucket_hist(const Op *ops, uint64_t n, PartTable tab, uint32_t
   }
 }
 // exclusive offsets, partition-major: off[tile][p] = sum_{p'<p} total[p'] + sum_{tile'<tile} hist[tile'][p]; counts[p] = total[p]
+// ONE workgroup of kBucketScanThreads = 16 groups x 64 partitions: group g owns a contiguous run of tiles, thread (g, p)
+// sums partition p over that run, the 16 x 64 partial sums are scanned in LDS, and the run is walked once more to write
+// the offsets.  (One thread per partition walking all tiles — 4883 of them for a 10 M-update block — took 1.2 ms.)
+constexpr uint32_t kBucketScanThreads = 1024;
 PMA_KERNEL void k_bucket_scan(uint32_t *hist, uint64_t ntiles, uint32_t nparts, unsigned long long *counts) {
+  constexpr uint32_t G = kBucketScanThreads / kMaxParts;
+  PMA_SHARED unsigned long long part[G][kMaxParts];  // sum of partition p over group g's tiles
   PMA_SHARED unsigned long long tot[kMaxParts];
   const uint32_t tid = wv::thread_idx();
-  if (tid < nparts) {  // one thread per partition walks the tiles (ntiles is a few hundred per million updates)
+  const uint32_t g = tid / kMaxParts, p = tid % kMaxParts;
+  const uint64_t per = (ntiles + G - 1) / G;
+  const uint64_t t0 = (uint64_t)g * per, t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
+  unsigned long long mine = 0;
+  if (p < nparts)
+    for (uint64_t t = t0; t < t1; t++) mine += hist[t * nparts + p];
+  part[g][p] = mine;
+  wv::block_sync();
+  if (g == 0 && p < nparts) {
     unsigned long long run = 0;
-    for (uint64_t t = 0; t < ntiles; t++) {
-      const uint32_t c = hist[t * nparts + tid];
-      hist[t * nparts + tid] = (uint32_t)run;
-      run += c;
+    for (uint32_t q = 0; q < G; q++) {
+      const unsigned long long x = part[q][p];
+      part[q][p] = run;  // partition p: what the groups in front of q hold
+      run += x;
     }
-    tot[tid] = run;
-    counts[tid] = run;
+    tot[p] = run;
+    counts[p] = run;
   }
   wv::block_sync();
-  if (tid < nparts) {
-    unsigned long long base = 0;
-    for (uint32_t p = 0; p < tid; p++) base += tot[p];
-    for (uint64_t t = 0; t < ntiles; t++) hist[t * nparts + tid] += (uint32_t)base;
+  if (p < nparts) {
+    unsigned long long run = part[g][p];
+    for (uint32_t q = 0; q < p; q++) run += tot[q];  // + everything of the partitions in front of p
+    for (uint64_t t = t0; t < t1; t++) {
+      const uint32_t c = hist[t * nparts + p];
+      hist[t * nparts + p] = (uint32_t)run;
+      run += c;
+    }
   }
 }
 PMA_KERNEL void k_bucket_scatter(const Op *ops, uint64_t n, PartTable tab, uint32_t nparts, const uint32_t *off, Op *out) {
