@@ -112,6 +112,14 @@ struct Engine::Impl {
   // Zipf stream on the same partition, 50 rollbacks per 1.5 M updates, was indifferent: 208 ms either way)
   uint32_t epoch_short = 16384;  // epoch length after a rollback
   uint32_t epoch_clean = 0, epoch_grow_after = 2;  // clean epochs in a row / how many of them double the length again
+  // Round 3: with incremental snapshots an epoch boundary costs ~30 us, so a stream that rolls back often is better off with
+  // epochs a good deal shorter than the distance between its rollbacks (hot-vertex stream: one rollback per 28 K updates;
+  // 2048-update epochs that double after 4 clean ones: 121 -> 105 ms per 1 M), while a stream that rolls back three times
+  // per million (a config #4 partition) needs the long ones (4096-update epochs: 24 -> 35 ms).  epoch_adapt = 1: the epoch
+  // after a rollback is 1/8 of the running mean distance between rollbacks, within [2048, epoch_short].
+  uint32_t epoch_adapt = 1, grow_eff = 2;
+  uint64_t since_rollback = 0;
+  double rb_dist = -1.0;
   // per-region prefix rule: nothing later may commit in a region where an earlier update was deferred.  4096 slots blocked
   // 43 K of the 69 K non-commits per 1 M updates of config #2 for nothing (179 M/s; 2048: 184, 1024: 187, 512: 188, 256: 189);
   // the hot-vertex stream needs the rule (1024: 142 ms as with 4096, 83 rollbacks instead of 36; 256: 191 ms, 199 rollbacks)
@@ -657,6 +665,10 @@ int Engine::set_option(const char *key, int64_t value) {
     p.epoch_short = (uint32_t)std::max<int64_t>(64, value);
     return PPCSR_OK;
   }
+  if (k == "epoch_adapt") {
+    p.epoch_adapt = value ? 1u : 0u;
+    return PPCSR_OK;
+  }
   if (k == "epoch_grow_after") {
     p.epoch_grow_after = (uint32_t)std::max<int64_t>(1, value);
     return PPCSR_OK;
@@ -1187,7 +1199,18 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         p.stamps_clean = false;
         GCHK(gpu::d2d(p.d_stats, p.d_stats_snap, kStatShards * sizeof(StatShard), p.stream));
         p.st.wasted_rounds += c.rounds;  // (kept apart: `rounds` / `committed` / `planned` describe committed work only)
-        p.cur_epoch = std::min<uint32_t>(p.cur_epoch, std::min<uint32_t>(p.epoch_ops, kEpochShort));
+        uint32_t short_eff = kEpochShort;
+        p.grow_eff = p.epoch_grow_after;
+        if (p.epoch_adapt) {
+          const double D = (double)std::min<uint64_t>(p.since_rollback, 64ull * kEpochShort);
+          p.rb_dist = p.rb_dist < 0 ? 64.0 * kEpochShort : 0.5 * p.rb_dist + 0.5 * D;
+          p.since_rollback = 0;
+          uint32_t q = 2048;
+          while (2ull * q <= (uint64_t)(p.rb_dist / 8.0) && 2ull * q <= kEpochShort) q *= 2;
+          short_eff = std::min<uint32_t>(kEpochShort, q);
+          if (short_eff < kEpochShort) p.grow_eff = std::max<uint32_t>(p.epoch_grow_after, 4u);
+        }
+        p.cur_epoch = std::min<uint32_t>(p.cur_epoch, std::min<uint32_t>(p.epoch_ops, short_eff));
         p.epoch_clean = 0;
         p.region_eff = std::max(p.region_slots, p.region_wide);
         p.region_clean = 0;
@@ -1233,11 +1256,12 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         p.st.rounds += c.rounds;
         p.st.committed += c.committed;
         p.st.planned += c.planned;
+        p.since_rollback += e1 - e0;
         e0 = e1;
         retries = 0;
         epoch_open = false;
         if (p.region_eff != p.region_slots && ++p.region_clean >= p.region_calm) p.region_eff = p.region_slots;
-        if (++p.epoch_clean >= p.epoch_grow_after) {
+        if (++p.epoch_clean >= std::max(p.grow_eff, p.epoch_grow_after)) {
           p.cur_epoch = (uint32_t)std::min<uint64_t>(p.epoch_ops, 2ull * p.cur_epoch);
           p.epoch_clean = 0;
         }
