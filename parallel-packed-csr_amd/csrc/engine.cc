@@ -116,8 +116,8 @@ struct Engine::Impl {
   // epochs a good deal shorter than the distance between its rollbacks (hot-vertex stream: one rollback per 28 K updates;
   // 2048-update epochs that double after 4 clean ones: 121 -> 105 ms per 1 M), while a stream that rolls back three times
   // per million (a config #4 partition) needs the long ones (4096-update epochs: 24 -> 35 ms).  epoch_adapt = 1: the epoch
-  // after a rollback is 1/8 of the running mean distance between rollbacks, within [2048, epoch_short].
-  uint32_t epoch_adapt = 1, grow_eff = 2;
+  // after a rollback is 1/epoch_adapt (default 8) of the running mean distance between rollbacks, within [2048, epoch_short].
+  uint32_t epoch_adapt = 8, grow_eff = 2;  // (epoch_adapt: 0 off, else the divisor)
   uint64_t since_rollback = 0;
   double rb_dist = -1.0;
   // per-region prefix rule: nothing later may commit in a region where an earlier update was deferred.  4096 slots blocked
@@ -666,7 +666,7 @@ int Engine::set_option(const char *key, int64_t value) {
     return PPCSR_OK;
   }
   if (k == "epoch_adapt") {
-    p.epoch_adapt = value ? 1u : 0u;
+    p.epoch_adapt = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 1024));
     return PPCSR_OK;
   }
   if (k == "epoch_grow_after") {
@@ -1206,7 +1206,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
           p.rb_dist = p.rb_dist < 0 ? 64.0 * kEpochShort : 0.5 * p.rb_dist + 0.5 * D;
           p.since_rollback = 0;
           uint32_t q = 2048;
-          while (2ull * q <= (uint64_t)(p.rb_dist / 8.0) && 2ull * q <= kEpochShort) q *= 2;
+          while (2ull * q <= (uint64_t)(p.rb_dist / (double)p.epoch_adapt) && 2ull * q <= kEpochShort) q *= 2;
           short_eff = std::min<uint32_t>(kEpochShort, q);
           if (short_eff < kEpochShort) p.grow_eff = std::max<uint32_t>(p.epoch_grow_after, 4u);
         }
