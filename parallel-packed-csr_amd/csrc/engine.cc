@@ -128,6 +128,15 @@ struct Engine::Impl {
   // a row have ended cleanly (a config #4 partition at critical density: 31.1 ms / 9 rollbacks with 1024 throughout, 26.7 ms
   // / 3 rollbacks with 4096; its calm second half is config-#2-like again)
   uint32_t region_wide = 4096, region_calm = 8, region_eff = 0, region_clean = 0;
+  // Round 3: a stream whose rollbacks are RARE (running mean distance >= region_rare_dist updates: a config #4 partition at
+  // critical density, one per ~150 K updates while its levels sit at their bounds) is better off paying for none at all:
+  // region_rare slots after a rollback, for region_rare_calm (8) x that distance of committed updates (24.9 -> 19.3 ms per batch of
+  // the partition: 193 -> 157 rounds, 0 rollbacks; the wide rule ends about where the array doubles and the stream turns calm).
+  // A stream that rolls back all the time (hot vertices, one per 28 K updates) keeps region_wide / region_calm: with 16 K-slot
+  // regions it loses more commits per round than the rollbacks cost (105 -> 131 ms); a stream that never rolls back never
+  // sees either rule.
+  uint32_t region_rare = 16384, region_rare_calm = 8, region_rare_dist = 65536;
+  uint64_t region_rare_span = 0;  // > 0: the rare rule is on until this many updates have committed since the rollback
   // Round width (upper bound when `adaptive` is on).  One update = one wave; `resident_waves` of them fit the chip at once
   // (o_plan: 78 VGPRs = 6 waves per SIMD, 24 per CU, 6144 on 256 CUs).  A round's kernels are bound by latency, so a round
   // of 2 x resident takes ~1.4x the time of one of 1 x resident; widths in between leave the second pass partly empty
@@ -532,6 +541,19 @@ int Engine::set_option(const char *key, int64_t value) {
   if (k == "region_wide") {
     if (value < 1 || (value & (value - 1))) return fail(PPCSR_EINVAL, "region_wide must be a power of two");
     p.region_wide = (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "region_rare") {  // 0: off
+    if (value < 0 || (value & (value - 1))) return fail(PPCSR_EINVAL, "region_rare must be 0 or a power of two");
+    p.region_rare = (uint32_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "region_rare_calm") {
+    p.region_rare_calm = (uint32_t)std::max<int64_t>(1, value);
+    return PPCSR_OK;
+  }
+  if (k == "region_rare_dist") {
+    p.region_rare_dist = (uint32_t)std::max<int64_t>(1, value);
     return PPCSR_OK;
   }
   if (k == "region_calm") {
@@ -1212,7 +1234,11 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         }
         p.cur_epoch = std::min<uint32_t>(p.cur_epoch, std::min<uint32_t>(p.epoch_ops, short_eff));
         p.epoch_clean = 0;
-        p.region_eff = std::max(p.region_slots, p.region_wide);
+        {
+          const bool rare = p.epoch_adapt && p.region_rare && p.rb_dist >= (double)p.region_rare_dist;
+          p.region_eff = std::max(p.region_slots, rare ? std::max(p.region_wide, p.region_rare) : p.region_wide);
+          p.region_rare_span = rare ? (uint64_t)(p.region_rare_calm * p.rb_dist) : 0;
+        }
         p.region_clean = 0;
         const uint64_t cut = (uint64_t)c.viol_idx + 1;
         if (retries < 3 && c.viol_idx != kMax && cut > e0 && cut < e1) {
@@ -1260,7 +1286,13 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         e0 = e1;
         retries = 0;
         epoch_open = false;
-        if (p.region_eff != p.region_slots && ++p.region_clean >= p.region_calm) p.region_eff = p.region_slots;
+        if (p.region_eff != p.region_slots) {
+          ++p.region_clean;
+          if (p.region_rare_span ? p.since_rollback >= p.region_rare_span : p.region_clean >= p.region_calm) {
+            p.region_eff = p.region_slots;
+            p.region_rare_span = 0;
+          }
+        }
         if (++p.epoch_clean >= std::max(p.grow_eff, p.epoch_grow_after)) {
           p.cur_epoch = (uint32_t)std::min<uint64_t>(p.epoch_ops, 2ull * p.cur_epoch);
           p.epoch_clean = 0;
