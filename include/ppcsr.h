@@ -115,7 +115,7 @@ int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out);
 /* knobs (int64 values; every key engine.cc's set_option accepts):
  *   scheduler  "mode" (0 strict prefix rounds, 1 speculative rounds + validated rollback; default 1), "opt_horizon" (round
  *              width cap; default 3 x "resident_waves" = 3 x CUs x 24), "start_horizon", "adaptive", "epoch_ops", "epoch_short", "epoch_grow_after",
- *              "epoch_adapt", "region_slots" / "region_wide" / "region_calm" / "region_rare" / "region_rare_calm" / "region_rare_dist", "soft_barrier", "defer_barrier", "small_batch" (batches up to this size take the strict
+ *              "epoch_adapt", "region_slots" / "region_wide" / "region_calm" / "region_rare" / "region_rare_calm" / "region_rare_dist" / "region_rare_cpr", "soft_barrier", "defer_barrier", "small_batch" (batches up to this size take the strict
  *              rounds), "max_horizon" / "min_horizon" / "init_horizon" (strict rounds), "rounds_per_sync";
  *              opt-in experiments (bit-exact, measured slower or neutral: DESIGN.md section 3): "chain" (0 off, 2 in-round chains
  *              per region), "chain_steps", "chain_grid", "zone_factor" (0 off: soft barriers made spatial)

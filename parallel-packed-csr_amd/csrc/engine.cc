@@ -137,6 +137,11 @@ struct Engine::Impl {
   // sees either rule.
   uint32_t region_rare = 16384, region_rare_calm = 8, region_rare_dist = 65536;
   uint64_t region_rare_span = 0;  // > 0: the rare rule is on until this many updates have committed since the rollback
+  // ... and only for streams that commit a good share of a chip-full per round (running mean >= region_rare_cpr): wide regions
+  // make rollbacks rarer for ANY stream, so the distance alone would also switch the rule on for the hot-vertex stream once it
+  // has been on for a while (600-750 commits per round there, 6-8 K on the critical-density partition)
+  uint32_t region_rare_cpr = 1536;
+  double cpr_mean = -1.0;
   // Round width (upper bound when `adaptive` is on).  One update = one wave; `resident_waves` of them fit the chip at once
   // (o_plan: 78 VGPRs = 6 waves per SIMD, 24 per CU, 6144 on 256 CUs).  A round's kernels are bound by latency, so a round
   // of 2 x resident takes ~1.4x the time of one of 1 x resident; widths in between leave the second pass partly empty
@@ -550,6 +555,10 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "region_rare_calm") {
     p.region_rare_calm = (uint32_t)std::max<int64_t>(1, value);
+    return PPCSR_OK;
+  }
+  if (k == "region_rare_cpr") {
+    p.region_rare_cpr = (uint32_t)std::max<int64_t>(0, value);
     return PPCSR_OK;
   }
   if (k == "region_rare_dist") {
@@ -1225,7 +1234,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         p.grow_eff = p.epoch_grow_after;
         if (p.epoch_adapt) {
           const double D = (double)std::min<uint64_t>(p.since_rollback, 64ull * kEpochShort);
-          p.rb_dist = p.rb_dist < 0 ? 64.0 * kEpochShort : 0.5 * p.rb_dist + 0.5 * D;
+          // (running mean with a fast attack downwards: a stream that starts to roll back often is recognised at once)
+          p.rb_dist = p.rb_dist < 0 ? 64.0 * kEpochShort : (D < p.rb_dist ? 0.25 * p.rb_dist + 0.75 * D : 0.5 * p.rb_dist + 0.5 * D);
           p.since_rollback = 0;
           uint32_t q = 2048;
           while (2ull * q <= (uint64_t)(p.rb_dist / (double)p.epoch_adapt) && 2ull * q <= kEpochShort) q *= 2;
@@ -1235,7 +1245,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         p.cur_epoch = std::min<uint32_t>(p.cur_epoch, std::min<uint32_t>(p.epoch_ops, short_eff));
         p.epoch_clean = 0;
         {
-          const bool rare = p.epoch_adapt && p.region_rare && p.rb_dist >= (double)p.region_rare_dist;
+          const bool rare = p.epoch_adapt && p.region_rare && p.rb_dist >= (double)p.region_rare_dist && p.cpr_mean >= (double)p.region_rare_cpr;
           p.region_eff = std::max(p.region_slots, rare ? std::max(p.region_wide, p.region_rare) : p.region_wide);
           p.region_rare_span = rare ? (uint64_t)(p.region_rare_calm * p.rb_dist) : 0;
         }
@@ -1283,6 +1293,10 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         p.st.committed += c.committed;
         p.st.planned += c.planned;
         p.since_rollback += e1 - e0;
+        if (c.rounds) {
+          const double cpr = (double)c.committed / (double)c.rounds;
+          p.cpr_mean = p.cpr_mean < 0 ? cpr : 0.75 * p.cpr_mean + 0.25 * cpr;
+        }
         e0 = e1;
         retries = 0;
         epoch_open = false;
