@@ -365,7 +365,7 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
     if (cus > 0) {
       p.resident_waves = (uint32_t)cus * 24u;
       p.start_horizon = p.resident_waves;
-      p.opt_horizon = 4u * p.resident_waves;  // (round 3: 24576-wide rounds on an MI355X; 3 x was the optimum before the round kernels lost their run-time extras: 190 -> 200 M/s on config #2)
+      p.opt_horizon = 3u * p.resident_waves;
     }
   }
   const uint64_t N = initial_N(init_n, src_n);
