@@ -56,6 +56,10 @@ for c in range(cases):
     if rng.integers(0, 3) == 0:  # round-3 knobs: in-round chains, zones, destination-centric rebalance pass, diagnostics on
         opts.update(chain=int(rng.choice([0, 2])), chain_steps=int(rng.choice([2, 16, 64])), zone_factor=int(rng.choice([0, 2, 8])),
                     rb_gather=int(rng.integers(0, 2)), rb_run=int(rng.choice([0, 1, 5])), diag=int(rng.choice([0, 0, 1])))
+    if rng.integers(0, 3) == 0:  # round-3 policies: epoch length / region width that follow the rollback frequency
+        opts.update(epoch_adapt=int(rng.choice([0, 2, 8, 32])), region_rare=int(rng.choice([0, 4096, 16384])),
+                    region_rare_dist=int(rng.choice([1, 4096, 65536])), region_rare_cpr=int(rng.choice([0, 64, 1536])),
+                    region_rare_calm=int(rng.choice([1, 8])))
     if rng.integers(0, 5) == 0:
         opts["mode"] = 0
     eng, o = pkg.PCSR(n, lock_search=lock), Oracle(n, lock_search=lock)
