@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <string>
 #include <thread>
@@ -18,6 +19,7 @@ int capi_set_device(int d);
 int capi_dev_alloc(void **p, size_t bytes);
 int capi_dev_free(void *p);
 int capi_d2h_sync(void *dst, const void *src, size_t bytes);  // on the NULL stream, after whatever it holds
+int capi_h2d_sync(void *dst, const void *src, size_t bytes);
 int capi_dev_memset(void *p, int byte, size_t bytes, void *stream);
 #if !defined(PPCSR_SIM)
 struct ppcsr_xchg;
@@ -189,6 +191,13 @@ struct pppcsr_engine {
   ppcsr_op *d_bucketed = nullptr;
   uint64_t bucketed_cap = 0;
   uint64_t *d_counts = nullptr;
+  // identity of this handle: a communicator's staging (pppcsr_comm::x) is keyed on it, not on the pointer — a destroyed handle's
+  // address can be handed out again by the allocator
+  uint64_t gen = next_generation();
+  static uint64_t next_generation() {
+    static std::atomic<uint64_t> g{0};
+    return ++g;
+  }
 };
 
 // PPPCSR.cpp:20-29: partitionSize = floor(init_n / P) (the std::ceil wraps an integer division); last takes the rest
@@ -498,6 +507,7 @@ int pppcsr_bulk_build_device(pppcsr_t h, const ppcsr_op *d_adds, uint64_t n) { r
 }  // extern "C"
 struct pppcsr_xchg {
   pppcsr_engine *h = nullptr;
+  uint64_t h_gen = 0;                    // pppcsr_engine::gen of h when this staging was made
   int nranks = 1, rank = 0, device = 0;
   uint64_t ppr = 0, first = 0;           // this rank's partitions: [first, first + ppr)
   ppcsr_op *d_send = nullptr;            // the block, stably bucketed by owner partition (= by peer: ranks hold ascending ranges)
@@ -554,6 +564,7 @@ int pppcsr_xchg_create(pppcsr_t h, int n_ranks, int rank, pppcsr_xchg_t *out) {
   }
   std::unique_ptr<pppcsr_xchg> x(new pppcsr_xchg());
   x->h = h;
+  x->h_gen = h->gen;
   x->nranks = n_ranks;
   x->rank = rank;
   x->ppr = ppr;
@@ -639,6 +650,7 @@ int pppcsr_xchg_bulk_build(pppcsr_xchg_t x) { return xchg_finish(x, PARTS_BULK);
 struct pppcsr_comm {
   ppcsr_xchg *t = nullptr;     // communicator + stream (engine.cc)
   pppcsr_xchg *x = nullptr;    // staging for the PPPCSR it was last used with
+  uint64_t *d_flags = nullptr; // [3][64] device words: status out / status in (and counts out / in of a rank without staging)
 };
 extern "C" {
 int pppcsr_comm_unique_id(void *id_out_128_bytes) {
@@ -666,6 +678,7 @@ int pppcsr_comm_create(const void *id_128_bytes, int n_ranks, int rank, int devi
 int pppcsr_comm_destroy(pppcsr_comm_t c) {
   if (!c) return 0;
   xchg_free(c->x);
+  if (c->d_flags) capi_dev_free(c->d_flags);
   capi_xchg_destroy(c->t);
   delete c;
   return 0;
@@ -676,28 +689,44 @@ static int exchange_run(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_ops, uint
   int W = 0, rank = 0, dev = 0;
   void *stream = nullptr;
   if (capi_xchg_ranks(c->t, &W, &rank, &dev, &stream) != 0) return bad("bad communicator");
-  if (!c->x || c->x->h != h) {  // (the layout checks against the communicator's ranks happen here)
+  // Every rank takes part in every collective step of this call whatever happened locally: a rank that returned between two
+  // steps would leave its peers blocked in their grouped ncclSend / ncclRecv for ever.  Local failures are carried along
+  // (`failed`) and travel inside the steps themselves: (1) poisoned counts — all ranks skip the rows; (2) a status word after
+  // the receive buffers have been laid out — again all ranks skip the rows.  Only a failure of the carrier itself returns at
+  // once (nothing collective can follow it).
+  int failed = 0;
+  std::string first_msg;
+  // (the staging is keyed on the handle's generation, not its address: a destroyed PPPCSR's address can come back)
+  if (!c->x || c->x->h != h || c->x->h_gen != h->gen || c->x->nranks != W || c->x->rank != rank) {
     xchg_free(c->x);
     c->x = nullptr;
-    int rc = pppcsr_xchg_create(h, W, rank, &c->x);
-    if (rc != 0) return rc;
+    failed = pppcsr_xchg_create(h, W, rank, &c->x);  // (the layout checks against the communicator's ranks happen here)
+    if (failed != 0) first_msg = g_last_error;
   }
-  pppcsr_xchg *x = c->x;
-  if (x->device != dev) return bad("the communicator's device does not hold this rank's partitions");
-  const uint64_t P = h->parts.size(), ppr = x->ppr, nseg = (uint64_t)W * ppr;
-  // Every rank runs the counts step whatever happened to its own block — the transfers are collective.  A rank whose
-  // bucketing failed poisons its counts (all ones), so that ALL ranks skip the row transfers and report the failure.
-  int failed = xchg_pack_async(x, d_ops, n, stream);
-  const std::string first_msg = failed != 0 ? g_last_error : std::string();
-  if (failed != 0 && capi_dev_memset(x->d_counts, 0xFF, 64 * sizeof(uint64_t), stream) != 0) return bad("pppcsr_exchange_apply: device memset failed");
+  if (failed == 0 && c->x->device != dev) {
+    failed = bad("the communicator's device does not hold this rank's partitions");
+    first_msg = g_last_error;
+  }
+  const uint64_t P = h->parts.size();
+  if (P == 0 || P > 64 || P % (uint64_t)W) return bad("partitions must be a multiple of the ranks (and at most 64)");  // (the same on every rank)
+  const uint64_t ppr = P / (uint64_t)W, nseg = (uint64_t)W * ppr;
+  if (!c->d_flags && (capi_set_device(dev) != 0 || capi_dev_alloc((void **)&c->d_flags, 3 * 64 * sizeof(uint64_t)) != 0))
+    return bad("pppcsr_exchange_apply: out of device memory (status words)");  // (first call only, before anything collective)
+  pppcsr_xchg *x = c->x;  // may be null (failed): the counts then travel from / to the communicator's own words
+  uint64_t *d_counts = x ? x->d_counts : c->d_flags + 64, *d_rcounts = x ? x->d_rcounts : c->d_flags + 128;
+  if (failed == 0) {
+    failed = xchg_pack_async(x, d_ops, n, stream);
+    if (failed != 0) first_msg = g_last_error;
+  }
+  if (failed != 0 && capi_dev_memset(d_counts, 0xFF, 64 * sizeof(uint64_t), stream) != 0) return bad("pppcsr_exchange_apply: device memset failed");
   std::vector<const void *> sp(nseg);
   std::vector<void *> rp(nseg);
   std::vector<uint64_t> sb(nseg), rb(nseg);
   std::vector<int> peer(nseg);
   // (1) the counts: ppr numbers to and from every peer, straight from the bucketing kernels' output
   for (int r = 0; r < W; r++) {
-    sp[r] = x->d_counts + (uint64_t)r * ppr;
-    rp[r] = x->d_rcounts + (uint64_t)r * ppr;
+    sp[r] = d_counts + (uint64_t)r * ppr;
+    rp[r] = d_rcounts + (uint64_t)r * ppr;
     sb[r] = rb[r] = ppr * sizeof(uint64_t);
     peer[r] = r;
   }
@@ -706,20 +735,52 @@ static int exchange_run(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_ops, uint
     g_last_error = capi_xchg_error(c->t);
     return rc;  // the carrier itself is broken: nothing collective can follow
   }
-  std::vector<uint64_t> rcounts(nseg, 0);
-  if (capi_d2h_sync(x->send_counts.data(), x->d_counts, P * sizeof(uint64_t)) != 0 ||
-      capi_d2h_sync(rcounts.data(), x->d_rcounts, nseg * sizeof(uint64_t)) != 0)
-    return bad("pppcsr_exchange_apply: device-to-host copy failed");
-  if (failed != 0) {
-    g_last_error = first_msg;
-    return failed;
+  std::vector<uint64_t> rcounts(nseg, 0), scounts(P, 0);
+  if (capi_d2h_sync(scounts.data(), d_counts, P * sizeof(uint64_t)) != 0 || capi_d2h_sync(rcounts.data(), d_rcounts, nseg * sizeof(uint64_t)) != 0)
+    return bad("pppcsr_exchange_apply: device-to-host copy failed");  // (the runtime itself is broken)
+  bool peer_failed = false;
+  for (uint64_t i = 0; i < nseg; i++) peer_failed |= rcounts[i] == ~0ull;
+  if (failed != 0 || peer_failed) {  // every rank sees a poisoned row of counts (a failed rank poisons all of its own): all leave here
+    if (failed != 0) {
+      g_last_error = first_msg;
+      return failed;
+    }
+    return bad("pppcsr_exchange_apply: a peer rank failed to bucket its block; no rows were exchanged");
   }
-  for (uint64_t i = 0; i < nseg; i++)
-    if (rcounts[i] == ~0ull) return bad("pppcsr_exchange_apply: a peer rank failed to bucket its block; no rows were exchanged");
+  x->send_counts = scounts;
   xchg_set_send_counts(x);
-  rc = pppcsr_xchg_layout(x, rcounts.data(), nullptr);
-  if (rc != 0) return rc;  // (out of device memory for the received streams: fatal for the job, the peers are already sending)
-  // (2) the rows: segment (peer r, partition q) leaves from the bucketed block and lands where the stream of q wants it
+  // (2) lay out the receive buffers, then agree that every rank could: one status word to and from every peer
+  failed = pppcsr_xchg_layout(x, rcounts.data(), nullptr);  // (out of device memory for the received streams)
+  if (failed != 0) first_msg = g_last_error;
+  {
+    const uint64_t word = failed != 0 ? 1ull : 0ull;
+    std::vector<uint64_t> mine((size_t)W, word), theirs((size_t)W, 0);
+    if (capi_h2d_sync(c->d_flags, mine.data(), (size_t)W * sizeof(uint64_t)) != 0) return bad("pppcsr_exchange_apply: host-to-device copy failed");
+    for (int r = 0; r < W; r++) {
+      sp[r] = c->d_flags + r;
+      rp[r] = c->d_flags + 64 + r;
+      sb[r] = rb[r] = sizeof(uint64_t);
+      peer[r] = r;
+    }
+    rc = capi_xchg_sendrecv(c->t, (uint64_t)W, sp.data(), sb.data(), peer.data(), rp.data(), rb.data(), peer.data());
+    if (rc != 0) {
+      g_last_error = capi_xchg_error(c->t);
+      return rc;
+    }
+    if (capi_d2h_sync(theirs.data(), c->d_flags + 64, (size_t)W * sizeof(uint64_t)) != 0) return bad("pppcsr_exchange_apply: device-to-host copy failed");
+    bool any = false;
+    for (int r = 0; r < W; r++) any |= theirs[r] != 0;
+    if (failed != 0) {
+      x->stage = 0;
+      g_last_error = first_msg;
+      return failed;
+    }
+    if (any) {
+      x->stage = 0;
+      return bad("pppcsr_exchange_apply: a peer rank could not lay out its receive buffers; no rows were exchanged");
+    }
+  }
+  // (3) the rows: segment (peer r, partition q) leaves from the bucketed block and lands where the stream of q wants it
   for (int r = 0; r < W; r++)
     for (uint64_t q = 0; q < ppr; q++) {
       const uint64_t i = (uint64_t)r * ppr + q;
@@ -816,14 +877,26 @@ int pppcsr_repartition_export(pppcsr_t h, const uint64_t *new_starts, const ppcs
     if (rc != 0) return rc;
     noff += nk[k];
   }
+  // All or nothing: every replacement engine is created BEFORE any old partition goes.  A failure (out of device memory for
+  // partition k) destroys the replacements made so far and leaves the handle as it was — every partition, its edges and the
+  // layout untouched; only the exported copy in d_moved has been written.
+  std::vector<ppcsr_t> fresh(P, nullptr);
   for (uint64_t k = 0; k < P; k++) {
     if (!changed[k]) continue;
     const uint64_t size = end_of(new_starts, k) - new_starts[k];
-    ppcsr_t fresh = nullptr;
-    int rc = ppcsr_create((uint32_t)size, (uint32_t)size, h->lock_search, h->device[k], &fresh);
-    if (rc != 0) return rc;  // (the old partition is still in place: the graph is intact, the layout unchanged)
+    int rc = ppcsr_create((uint32_t)size, (uint32_t)size, h->lock_search, h->device[k], &fresh[k]);
+    if (rc != 0) {
+      const std::string why = g_last_error;
+      for (uint64_t q = 0; q < k; q++)
+        if (fresh[q]) ppcsr_destroy(fresh[q]);
+      g_last_error = why;
+      return rc;
+    }
+  }
+  for (uint64_t k = 0; k < P; k++) {
+    if (!changed[k]) continue;
     ppcsr_destroy(h->parts[k]);
-    h->parts[k] = fresh;
+    h->parts[k] = fresh[k];
   }
   for (uint64_t k = 0; k < P; k++) h->distribution[k] = new_starts[k];
   *d_ops = h->d_moved;

@@ -995,18 +995,6 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     // rollback point of the epoch: the epoch snapshot catches up with what the previous epoch wrote (dirty tags) — a full
     // copy only the first time and after the array was replaced
     GCHK(snap_commit(p, p.esnap));
-    if (const char *tv = getenv("PPCSR_TRACE_NN")) {  // debug: num_neighbors of one vertex, live and in the epoch snapshot
-      const uint32_t vtx = (uint32_t)atoi(tv);
-
-      Node a_, b_;
-      uint32_t tg = 0;
-      GCHK(gpu::d2h(&a_, p.v.nodes + vtx, sizeof(Node), p.stream));
-      GCHK(gpu::d2h(&b_, p.esnap.v.nodes + vtx, sizeof(Node), p.stream));
-      GCHK(gpu::d2h(&tg, p.v.vdirty + vtx, sizeof(uint32_t), p.stream));
-      GCHK(gpu::sync(p.stream));
-      fprintf(stderr, "[nn] epoch start e0=%llu: live nn %u snap nn %u tag %u synced %u serial %u\n", (unsigned long long)e0, a_.num_neighbors, b_.num_neighbors, tg,
-              p.esnap.synced, p.serial);
-    }
     GCHK(gpu::d2d(p.d_stats_snap, p.d_stats, kStatShards * sizeof(StatShard), p.stream));
     if (!p.stamps_clean) {
       // validation stamps hold 1 + the stream index of the latest committed toucher: what earlier epochs of this batch left
@@ -1219,16 +1207,6 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
           fprintf(stderr, "[ppcsr] rollback: epoch [%llu,%llu) viol_idx=%u excl=%u maxc=%u after %llu rounds; kind=%u leaf=%u stamp=%u what=%u wleaf=[%u,%u] index=%u nr=%u\n",
                   (unsigned long long)e0, (unsigned long long)e1, c.viol_idx, c.excl, c.maxc, c.rounds, c.viol_info[0],
                   c.viol_info[1], c.viol_info[2], c.viol_info[3], c.viol_info[4], c.viol_info[5], c.viol_info[6], c.viol_info[7]);
-        if (const char *tv = getenv("PPCSR_TRACE_NN")) {
-          const uint32_t vtx = (uint32_t)atoi(tv);
-          Node a_;
-          uint32_t tg = 0;
-          GCHK(gpu::d2h(&a_, p.v.nodes + vtx, sizeof(Node), p.stream));
-          GCHK(gpu::d2h(&tg, p.v.vdirty + vtx, sizeof(uint32_t), p.stream));
-          GCHK(gpu::sync(p.stream));
-          GCHK(gpu::sync(p.stream));
-          fprintf(stderr, "[nn] before rollback: live nn %u tag %u synced %u serial %u (viol_idx %u, rounds %llu)\n", a_.num_neighbors, tg, p.esnap.synced, p.serial, c.viol_idx, c.rounds);
-        }
         GCHK(snap_rollback(p, p.esnap, p.snap));
         p.stamps_clean = false;
         GCHK(gpu::d2d(p.d_stats, p.d_stats_snap, kStatShards * sizeof(StatShard), p.stream));
@@ -2537,6 +2515,12 @@ int capi_dev_memset(void *p, int byte, size_t bytes, void *stream) { return gpu:
 int capi_d2h_sync(void *dst, const void *src, size_t bytes) {
   gpu::stream_t st = gpu::stream_from_ptr(nullptr);
   int e = gpu::d2h(dst, src, bytes, st);
+  if (e) return e;
+  return gpu::sync(st);
+}
+int capi_h2d_sync(void *dst, const void *src, size_t bytes) {
+  gpu::stream_t st = gpu::stream_from_ptr(nullptr);
+  int e = gpu::h2d(dst, src, bytes, st);
   if (e) return e;
   return gpu::sync(st);
 }

@@ -207,8 +207,9 @@ class PCSR {
       batch.swap(pending_);
     }
     edges.global_lock->applying.store(1, std::memory_order_release);
-    check(ppcsr_apply_batch(h_, batch.data(), batch.size()));
-    edges.global_lock->applying.store(0, std::memory_order_release);
+    const int rc = ppcsr_apply_batch(h_, batch.data(), batch.size());
+    edges.global_lock->applying.store(0, std::memory_order_release);  // (before check(): it may not return)
+    check(rc);
     refresh_geometry(false);
   }
   uint64_t get_n_locked() {
