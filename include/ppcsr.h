@@ -62,8 +62,6 @@ typedef struct {
   uint64_t narrow_lost;   /* how often that add_node path was taken */
   uint64_t narrow;        /* 1: regular structure (parallel rounds); 0: add_node after a doubling has left overlapping vertex ranges
                              (PCSR.cpp:533-540, 681-703): updates run one per round until a re-check finds the ranges sane again */
-  uint64_t chained;       /* updates committed by the in-round chains (a region's waiting updates executed one after the other
-                             by one wave inside a round instead of one per round) */
 } ppcsr_stats_t;
 
 /* PCSR::PCSR(init_n, src_n, lock_search, domain)  — PCSR.cpp:775-838; `device` replaces the NUMA domain */
@@ -116,14 +114,11 @@ int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out);
  *   scheduler  "mode" (0 strict prefix rounds, 1 speculative rounds + validated rollback; default 1), "opt_horizon" (round
  *              width cap; default 3 x "resident_waves" = 3 x CUs x 24), "start_horizon", "adaptive", "epoch_ops", "epoch_short", "epoch_grow_after",
  *              "epoch_adapt", "region_slots" / "region_wide" / "region_calm" / "region_rare" / "region_rare_calm" / "region_rare_dist" / "region_rare_cpr", "soft_barrier", "defer_barrier", "small_batch" (batches up to this size take the strict
- *              rounds), "max_horizon" / "min_horizon" / "init_horizon" (strict rounds), "rounds_per_sync";
- *              opt-in experiments (bit-exact, measured slower or neutral: DESIGN.md section 3): "chain" (0 off, 2 in-round chains
- *              per region), "chain_steps", "chain_grid", "zone_factor" (0 off: soft barriers made spatial)
+ *              rounds), "max_horizon" / "min_horizon" / "init_horizon" (strict rounds), "rounds_per_sync"
  *   windows    "big_min" / "big_window" (slots: above big_min a workgroup of the round rebalances the window, above
  *              big_window the update is exclusive), "big_grid", "excl_in_wave"
  *   rebalance  "scatter_variant" (0 LDS-staged, 1 register runs, 2 runs + in-tile leaf scan), "scatter_blocks",
- *              "rb_tile", "rb_min_tiles", "rb_prefetch", "rb_gather" / "rb_run" / "rb_run_wgs" (opt-in destination-centric final
- *              pass: DESIGN.md section 9), "rb_inplace_min" (partial windows of at least this many slots are
+ *              "rb_tile", "rb_min_tiles", "rb_prefetch", "rb_inplace_min" (partial windows of at least this many slots are
  *              rebalanced in place; 0 = always through the scratch array), "rb_inplace_cpw", "rb_inplace_lists"
  *   search     "search_narrow" (0: literal binary walk only)
  *   measuring  "profile" (1: HIP events around every round kernel, reported through ppcsr_stats), "diag" (1: why updates

@@ -30,7 +30,7 @@ class Stats(ctypes.Structure):
                 ("not_found", c_u64), ("duplicates", c_u64), ("noops", c_u64), ("slide_slots", c_u64),
                 ("ops_applied", c_u64), ("last_batch_ms", c_dbl), ("last_batch_h2d_ms", c_dbl),
                 ("prof_plan_ms", c_dbl), ("prof_check_ms", c_dbl), ("prof_apply_ms", c_dbl), ("prof_compact_ms", c_dbl), ("prof_launches", c_u64),
-                ("wasted_rounds", c_u64), ("narrow_lost", c_u64), ("narrow", c_u64), ("chained", c_u64)]
+                ("wasted_rounds", c_u64), ("narrow_lost", c_u64), ("narrow", c_u64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

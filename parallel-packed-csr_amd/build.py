@@ -12,10 +12,7 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                # the rebalance position chain must round like the reference's x86-64 build: no FMA contraction
                "-ffp-contract=off",
                # (compact_block leaves its unrolled loops early on a wave-uniform bound: "loop not unrolled" is intended)
-               "-Wno-pass-failed",
-               # o_chain with its two halves inlined (see chain_plan / chain_apply in pma_kernels.h: as called functions they
-               # need a stack in scratch memory, which makes every launch of the kernel several times slower)
-               "-DPPCSR_CHAIN_INLINE"]
+               "-Wno-pass-failed"]
 
 
 def hipcc():

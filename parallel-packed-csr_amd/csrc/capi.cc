@@ -162,7 +162,6 @@ int ppcsr_stats(ppcsr_t h, ppcsr_stats_t *out) {
   out->wasted_rounds = s.wasted_rounds;
   out->narrow = s.narrow;
   out->narrow_lost = s.narrow_lost;
-  out->chained = s.chained;
   return 0;
 }
 int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value) { H_CHECK(); return ret(h->e, h->e->set_option(key, value)); }

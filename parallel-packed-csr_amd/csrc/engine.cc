@@ -167,9 +167,6 @@ struct Engine::Impl {
   uint32_t rb_tile = 0;          // leaves per rebalance tile (power of two <= 256); 0 = pick per window
   uint32_t rb_min_tiles = 4096;  // auto tile: shrink the tile until the window has at least this many
   uint32_t rb_prefetch = 1;  // 1: four chunks in flight per wave, 0: one
-  uint32_t rb_run = 0;       // destination tiles per workgroup of k_rb_gather (0: so that about rb_run_wgs workgroups are launched)
-  uint32_t rb_run_wgs = 2048;
-  uint32_t rb_gather = 0;    // 1: destination-centric final pass (k_rb_gather: LDS image of the tile, 16-byte stores; measured slower: DESIGN.md section 9), 0: k_rb_scatter
   uint64_t rb_inplace_min = 1ull << 19;  // partial windows of at least this many slots are rebalanced in place (0 = never)
   uint32_t rb_inplace_cpw = 0;   // 64-slot chunks per wave of an in-place tile (8 or 16; 0 = by window size)
   uint32_t *d_ip = nullptr;      // in-place rebalance: header (sticky error, ticket counters), tile order, the tiles' flags
@@ -188,16 +185,7 @@ struct Engine::Impl {
   // inserts; at / 2: 276 rounds and the same 2-3 rollbacks; without any: 234 rounds, but slower ones
   uint32_t soft_barrier = 0;
   uint32_t defer_barrier = 0;  // slots; a deferred update with a window at least this big lets nothing later overtake it (0: off)
-  // a soft barrier holds back later updates only inside the aligned block of zone_factor x its planned window (0: everywhere)
-  uint32_t zone_factor = 0;
   uint32_t diag = 0;     // count, per epoch, why planned updates did not commit (printed to stderr at the end of the epoch)
-  // in-round chains (o_chain): 0 never, 1 when the rounds commit little of what they plan (conflict chains), 2 always
-  uint32_t chain = 0, chain_steps = 32, chain_fence = 0, chain_grid = 2048;
-  bool chain_on = false;  // the regime the last round chunk was in (kept across epochs and batches)
-  unsigned long long *d_bk_cnt = nullptr, *d_xmin = nullptr;
-  uint32_t *d_bk_base = nullptr, *d_bk_list = nullptr, *d_bk_pos = nullptr, *d_bk_reg = nullptr, *d_owners = nullptr, *d_bk_flag = nullptr;
-  uint64_t bk_cap = 0;
-  uint64_t xmin_cap = 0;
   uint32_t *d_dg = nullptr;  // diag >= 2: per-update trace of the batch (OptArgs::dg)
   uint64_t dg_cap = 0;
   std::vector<gpu::Event> events;  // init failed half-way: destructor frees only what exists
@@ -220,14 +208,6 @@ static int ensure_plans(Engine::Impl &p) {
   return 0;
 }
 
-// the chain lists are tagged with the round too
-static int reset_chain_tags(Engine::Impl &p) {
-  int e;
-  if (p.d_bk_cnt && (e = gpu::dset(p.d_bk_cnt, 0, (uint64_t)kChainBuckets * sizeof(unsigned long long), p.stream))) return e;
-  if (p.d_bk_flag && (e = gpu::dset(p.d_bk_flag, 0, (uint64_t)kChainBuckets * sizeof(uint32_t), p.stream))) return e;
-  if (p.d_xmin && (e = gpu::dset(p.d_xmin, 0xFF, p.xmin_cap * sizeof(unsigned long long), p.stream))) return e;
-  return 0;
-}
 // every round-tagged reservation array restarts together with the round counter (stale keys must never meet a reused tag)
 static int reset_tags(Engine::Impl &p) {
   const uint64_t leaves = p.v.g.N >> p.v.g.sh;
@@ -239,7 +219,6 @@ static int reset_tags(Engine::Impl &p) {
   if (p.d_pfail && (e = gpu::dset(p.d_pfail, 0xFF, (leaves + 1) * sizeof(unsigned long long), p.stream))) return e;
   if (p.v.vw && (e = gpu::dset(p.v.vw, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
   if (p.v.vr && (e = gpu::dset(p.v.vr, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
-  if ((e = reset_chain_tags(p))) return e;
   p.round = 0;
   return 0;
 }
@@ -264,11 +243,8 @@ static int alloc_aux(Engine::Impl &p, View &v) {
   if ((e = gpu::dset(p.d_rstamp, 0, leaves * sizeof(uint32_t), p.stream))) return e;
   if ((e = gpu::dmalloc((void **)&v.ldirty, leaves * sizeof(uint32_t)))) return e;
   if ((e = gpu::dset(v.ldirty, 0, leaves * sizeof(uint32_t), p.stream))) return e;
-  if ((e = gpu::dmalloc((void **)&p.d_xmin, (leaves + 2) * sizeof(unsigned long long)))) return e;  // (per region; regions >= 1 leaf)
-  p.xmin_cap = leaves + 2;
   p.leaves_cap = leaves;
   p.round = 0;
-  if ((e = reset_chain_tags(p))) return e;
   if (v.vw && (e = gpu::dset(v.vw, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
   if (v.vr && (e = gpu::dset(v.vr, 0xFF, (p.n_cap + 1) * sizeof(unsigned long long), p.stream))) return e;
   return 0;
@@ -300,9 +276,6 @@ static int alloc_vertex_aux(Engine::Impl &p, View &v) {
 static void free_aux(Engine::Impl &p, View &v) {
   if (v.ldirty) GPU_DFREE(v.ldirty);
   v.ldirty = nullptr;
-  if (p.d_xmin) GPU_DFREE(p.d_xmin);
-  p.d_xmin = nullptr;
-  p.xmin_cap = 0;
   GPU_DFREE(v.wres);
   GPU_DFREE(v.rres);
   GPU_DFREE(v.dres);
@@ -486,13 +459,6 @@ Engine::~Engine() {
   if (p.d_jobs) GPU_DFREE(p.d_jobs);
   if (p.d_xplan) GPU_DFREE(p.d_xplan);
   if (p.d_bigscratch) GPU_DFREE(p.d_bigscratch);
-  if (p.d_bk_cnt) GPU_DFREE(p.d_bk_cnt);
-  if (p.d_bk_base) GPU_DFREE(p.d_bk_base);
-  if (p.d_bk_list) GPU_DFREE(p.d_bk_list);
-  if (p.d_bk_pos) GPU_DFREE(p.d_bk_pos);
-  if (p.d_bk_reg) GPU_DFREE(p.d_bk_reg);
-  if (p.d_owners) GPU_DFREE(p.d_owners);
-  if (p.d_bk_flag) GPU_DFREE(p.d_bk_flag);
   if (p.d_dg) GPU_DFREE(p.d_dg);
   for (Impl::Snap *sp : {&p.snap, &p.esnap}) {
     if (sp->v.items) GPU_DFREE(sp->v.items);
@@ -630,18 +596,6 @@ int Engine::set_option(const char *key, int64_t value) {
     p.rb_inplace_min = value < 0 ? 0ull : (uint64_t)value;
     return PPCSR_OK;
   }
-  if (k == "rb_run") {
-    p.rb_run = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 4096));
-    return PPCSR_OK;
-  }
-  if (k == "rb_run_wgs") {
-    p.rb_run_wgs = (uint32_t)std::max<int64_t>(64, value);
-    return PPCSR_OK;
-  }
-  if (k == "rb_gather") {
-    p.rb_gather = value ? 1u : 0u;
-    return PPCSR_OK;
-  }
   if (k == "rb_prefetch") {
     p.rb_prefetch = value ? 1u : 0u;
     return PPCSR_OK;
@@ -706,28 +660,6 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "soft_barrier") {
     p.soft_barrier = (uint32_t)std::max<int64_t>(0, value);
-    return PPCSR_OK;
-  }
-  if (k == "chain") {
-    if (value < 0 || value > 2) return fail(PPCSR_EINVAL, "chain must be 0 (off), 1 (auto) or 2 (always)");
-    p.chain = (uint32_t)value;
-    return PPCSR_OK;
-  }
-  if (k == "chain_grid") {
-    p.chain_grid = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 1 << 16));
-    return PPCSR_OK;
-  }
-  if (k == "chain_fence") {
-    p.chain_fence = (uint32_t)value;
-    return PPCSR_OK;
-  }
-  if (k == "chain_steps") {
-    p.chain_steps = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 64));
-    return PPCSR_OK;
-  }
-  if (k == "zone_factor") {
-    if (value < 0 || (value & (value - 1))) return fail(PPCSR_EINVAL, "zone_factor must be 0 or a power of two");
-    p.zone_factor = (uint32_t)std::min<int64_t>(value, 1 << 20);
     return PPCSR_OK;
   }
   if (k == "defer_barrier") {
@@ -951,26 +883,6 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       p.bigscratch_cap = need;
     }
   }
-  if (p.chain && p.bk_cap < (uint64_t)p.opt_horizon + 8) {  // per-region lists of the in-round chains
-    for (void *q : {(void *)p.d_bk_cnt, (void *)p.d_bk_base, (void *)p.d_bk_list, (void *)p.d_bk_pos, (void *)p.d_bk_reg, (void *)p.d_owners, (void *)p.d_bk_flag})
-      if (q) gpu::dfree(q);
-    p.d_bk_cnt = nullptr;
-    p.d_bk_base = p.d_bk_list = p.d_bk_pos = p.d_bk_reg = p.d_owners = p.d_bk_flag = nullptr;
-    p.bk_cap = 0;
-    const uint64_t cap = (uint64_t)p.opt_horizon + 8;
-    GCHK(gpu::dmalloc((void **)&p.d_bk_cnt, (uint64_t)kChainBuckets * sizeof(unsigned long long)));
-    GCHK(gpu::dmalloc((void **)&p.d_bk_base, (uint64_t)kChainBuckets * sizeof(uint32_t)));
-    GCHK(gpu::dmalloc((void **)&p.d_bk_list, cap * sizeof(uint32_t)));
-    GCHK(gpu::dmalloc((void **)&p.d_bk_pos, cap * sizeof(uint32_t)));
-    GCHK(gpu::dmalloc((void **)&p.d_bk_reg, cap * sizeof(uint32_t)));
-    GCHK(gpu::dmalloc((void **)&p.d_owners, 8 * cap * sizeof(uint32_t)));
-    GCHK(gpu::dmalloc((void **)&p.d_bk_flag, (uint64_t)kChainBuckets * sizeof(uint32_t)));
-    GCHK(gpu::dset(p.d_bk_flag, 0, (uint64_t)kChainBuckets * sizeof(uint32_t), p.stream));
-    p.bk_cap = cap;
-    GCHK(gpu::dset(p.d_bk_cnt, 0, (uint64_t)kChainBuckets * sizeof(unsigned long long), p.stream));
-    GCHK(gpu::dset(p.d_bk_pos, 0xFF, cap * sizeof(uint32_t), p.stream));
-    if (p.round) GCHK(reset_tags(p));  // (the counts are tagged with the round: one clean start for everything that is)
-  }
   if (p.diag >= 2) {
     if (p.dg_cap < n) {
       if (p.d_dg) GPU_DFREE(p.d_dg);
@@ -1061,22 +973,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       a.regshift = rs;
       a.diag = p.diag;
       a.defer_barrier = p.defer_barrier;
-      a.zone_factor = p.zone_factor;
-      const bool use_chain = p.chain == 2 || (p.chain == 1 && p.chain_on);
-      // the round kernels come in two instantiations: without / with the opt-in experiments and the diagnostics compiled in
-      const bool extras = p.chain != 0 || p.diag != 0 || p.zone_factor != 0 || p.chain_fence != 0;
-      a.chain = use_chain ? std::max<uint32_t>(1u, p.chain_steps) : 0u;
-      a.chain_fence = p.chain_fence;
-      a.chshift = std::max(0, 10 - p.v.g.sh);
-      a.bk_cnt = p.d_bk_cnt;
-      a.bk_base = p.d_bk_base;
-      a.bk_list = p.d_bk_list;
-      a.bk_pos = p.d_bk_pos;
-      a.bk_reg = p.d_bk_reg;
-      a.owners = p.d_owners;
-      a.owners_cap = (uint32_t)p.bk_cap;
-      a.bk_flag = p.d_bk_flag;
-      a.xmin = p.d_xmin;
+      // the round kernels come in two instantiations: without / with the diagnostics compiled in
+      const bool extras = p.diag != 0;
       a.dg = p.diag >= 2 ? p.d_dg : (uint32_t *)nullptr;
       a.soft_barrier = p.soft_barrier ? p.soft_barrier : a.v.big_window / 2u;
       // while the rare-rollback rule keeps regions wide, overtakers are kept off a growing window by the region rule itself and
@@ -1118,12 +1016,10 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         a.round = ++p.round;
         if (p.profile) p.events[5 * r + 0].record(p.stream);
         if (extras) GPU_LAUNCH(p.stream, o_plan_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_plan, blocks, 256, a);
-        if (use_chain) GPU_LAUNCH(p.stream, o_bscan, 1, 1024, a);  // (profile: counted with o_plan)
         if (p.profile) p.events[5 * r + 1].record(p.stream);
         if (extras) GPU_LAUNCH(p.stream, o_check_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_check, blocks, 256, a);
         if (p.profile) p.events[5 * r + 2].record(p.stream);
         if (extras) GPU_LAUNCH(p.stream, o_apply_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
-        if (use_chain) GPU_LAUNCH(p.stream, o_chain, p.chain_grid, 64, a);  // one wave per workgroup; (profile: counted with o_apply)
         if (p.profile) p.events[5 * r + 3].record(p.stream);
         GPU_LAUNCH(p.stream, o_compact, 1u + (use_big ? p.big_grid : 0u), 1024, a);  // workgroup 0 compacts, the others rebalance big windows
         if (p.profile) p.events[5 * r + 4].record(p.stream);
@@ -1142,29 +1038,12 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       }
       p.st.round_syncs++;
       if (c.error) return fail(PPCSR_EINTERNAL, "device-side error " + std::to_string(c.error));
-      {  // which regime were these rounds in?  Chains pay when a round commits little of what it plans (conflict chains:
-         // every round re-plans the same waiting updates), and cost a launch per round when nearly everything commits
-        const unsigned long long dp = c.planned - chunk_planned0, dc = c.committed - chunk_committed0;
-        if (dp >= 2048) {
-          if (dc * 100ull < dp * 60ull) p.chain_on = true;
-          else if (dc * 100ull > dp * 92ull) p.chain_on = false;
-        }
-        chunk_planned0 = c.planned;
-        chunk_committed0 = c.committed;
-      }
       if (p.diag && (c.violation || c.excl || c.done))
         fprintf(stderr, "[ppcsr diag] epoch [%llu,%llu) %s after %llu rounds: committed %llu planned %llu | not committed because: excl-kind %llu, "
                 "behind-barrier %llu, dup %llu, W-W %llu, W-after-R %llu, R-after-W %llu, sentinel-read %llu, sentinel-move %llu, region %llu, "
                 "growth-zone %llu, stamp %llu\n",
                 (unsigned long long)e0, (unsigned long long)e1, c.violation ? "ROLLBACK" : (c.excl ? "exclusive" : "done"), c.rounds, c.committed,
                 c.planned, c.why[0], c.why[1], c.why[2], c.why[3], c.why[4], c.why[5], c.why[6], c.why[7], c.why[8], c.why[9], c.why[10]);
-      if (p.diag && (c.violation || c.excl || c.done) && c.chain_why[9])
-        fprintf(stderr, "[ppcsr diag]   chains: heads %llu steps %llu | ended by: list-end %llu, stop-index %llu, step-limit %llu, excl-kind %llu, many-ranges %llu, "
-                "leaves-region %llu, big-window %llu, stamps %llu | regions under a queued window %llu\n", c.chain_why[9], c.chain_why[10], c.chain_why[0],
-                c.chain_why[1], c.chain_why[2], c.chain_why[3], c.chain_why[4], c.chain_why[5], c.chain_why[6], c.chain_why[7], c.chain_why[8]);
-      if (p.diag && (c.violation || c.excl || c.done) && c.chain_why[9])
-        fprintf(stderr, "[ppcsr diag]   stop index from: exclusive %llu, global barrier %llu, foreign update %llu, list overflow %llu, zone %llu | list errors %llu\n", c.chain_stop[1],
-                c.chain_stop[2], c.chain_stop[3], c.chain_stop[4], c.chain_stop[5], c.chain_why[11]);
       if (p.diag >= 2 && (c.violation || c.done) && getenv("PPCSR_DIAG_DUMP")) {
         const uint64_t cnt = e1 - e0;
         std::vector<uint32_t> tr(cnt * 4);
@@ -1483,23 +1362,11 @@ int Engine::rebalance_fused(const View &nv, const Edge *src_items, uint64_t src_
   if (rc != PPCSR_OK) return rc;
   // (inplace: a window of the live array, src_cnt = its slice of the live leaf counts -> the matching slice of the dirty tags)
   const int dsh = nv.g.sh;
-  const bool gather = p.rb_gather && dsh >= 2 && dsh <= 10 && (tb_index & ((1ull << dsh) - 1)) == 0 && (tb_len & ((1ull << dsh) - 1)) == 0;
   GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, src_cnt, nleaves, tile, p.d_tiles, inplace ? p.d_rank : (uint32_t *)nullptr,
-             inplace ? (uint32_t *)nullptr : dst_cnt, (inplace || gather) ? (uint64_t)0 : dst_nleaves,
+             inplace ? (uint32_t *)nullptr : dst_cnt, inplace ? (uint64_t)0 : dst_nleaves,
              inplace ? p.v.ldirty + (src_cnt - p.v.leafcnt) : (uint32_t *)nullptr, p.serial);
   GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, tb_index, tb_len, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
-  const uint64_t ntd = (tb_len + kGtSlots - 1) / kGtSlots;
-  const uint32_t run = p.rb_run ? p.rb_run : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ntd / p.rb_run_wgs, 64));  // destination tiles per workgroup
-  if (gather && tb_index != 0)  // every destination leaf count is stored by the one workgroup that owns the leaf
-    GPU_LAUNCH(p.stream, k_rb_gather, (ntd + run - 1) / run, 256, nv, src_items, src_lo, src_len, src_sh,
-               inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, tile, ntiles, (const uint32_t *)p.d_tiles,
-               (const ChainTable *)p.d_table, dst, dst_bias, dst_cnt, dsh, (uint64_t)0, run);
-  else if (gather)  // (a window from slot 0 crosses a binade per doubling: the long position table)
-    GPU_LAUNCH(p.stream, k_rb_gather_from0, (ntd + run - 1) / run, 256, nv, src_items, src_lo, src_len, src_sh,
-               inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, tile, ntiles, (const uint32_t *)p.d_tiles,
-               (const ChainTable *)p.d_table, dst, dst_bias, dst_cnt, dsh, (uint64_t)0, run);
-  else
-    GPU_LAUNCH(p.stream, k_rb_scatter, ntiles, 256, nv, src_items, src_lo, src_len, src_sh,
+  GPU_LAUNCH(p.stream, k_rb_scatter, ntiles, 256, nv, src_items, src_lo, src_len, src_sh,
                inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, tile, p.rb_prefetch ? 4u : 1u, (const uint32_t *)p.d_tiles,
                (const ChainTable *)p.d_table, dst, dst_bias, dst_cnt, nv.g.sh, (uint64_t)0);
   return PPCSR_OK;
@@ -2218,7 +2085,6 @@ int Engine::stats(EngineStats *out) {
     s.duplicates += h.duplicates;
     s.noops += h.noops;
     s.slide_slots += h.slide_slots;
-    s.chained += h.chained;
   }
   *out = s;
   return PPCSR_OK;

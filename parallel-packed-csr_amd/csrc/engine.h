@@ -28,7 +28,6 @@ struct EngineStats {
   uint64_t prof_launches;  // launches of EACH of the three kernels
   uint64_t wasted_rounds;  // rounds of speculative epochs that were rolled back (not part of `rounds`)
   uint64_t narrow_lost;    // times add_node-after-doubling switched the structure to the sequential regime
-  uint64_t chained;        // updates committed by the in-round chains (o_chain)
   uint64_t narrow;         // 1: sorted, disjoint vertex ranges (64-ary search narrowing + parallel rounds); 0: sequential regime
 };
 

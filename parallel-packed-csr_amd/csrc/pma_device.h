@@ -32,10 +32,6 @@ struct View {
   uint32_t *ldirty;  // per leaf
   uint32_t *vdirty;  // per vertex (node record: beginning, end, num_neighbors)
   uint32_t serial;
-  // exclusive bound of the gap search to the right (0: the end of the array).  The in-round chains work on a copy of ONE region
-  // held in LDS (items / leafcnt then point into that copy, biased so that absolute slot / leaf numbers index it): nothing beyond
-  // the region may be touched, and a gap that is not found inside it counts as "none" (the update is not for the chain)
-  uint64_t gap_end;
   Geometry g;
   // largest rebalance window a round accepts (larger ones make the update exclusive).  Strict rounds: kBigWindow (one
   // wave rebalances it); speculative rounds: up to kBigLeaves leaves, rebalanced by a workgroup (o_big)
@@ -48,7 +44,7 @@ constexpr int kStatShards = 256;
 constexpr uint32_t kLdsWindow = 512;   // windows up to this many slots are rebalanced inside one wave's LDS tile (12 KB)
 
 struct StatShard {
-  unsigned long long redistribute_calls, redistribute_slots, not_found, duplicates, noops, slide_slots, committed, chained;
+  unsigned long long redistribute_calls, redistribute_slots, not_found, duplicates, noops, slide_slots, committed;
 };
 
 namespace dev {
@@ -107,7 +103,7 @@ PMA_DEV void mark_leaves(const View &v, uint64_t lo, uint64_t hi) {
 }
 
 constexpr uint32_t kLongRange = 8;  // read ranges spanning more leaves are walked by the whole wave
-struct RangeRec {  // read-leaf ranges collected by lane 0 into the plan record
+struct RangeRec {  // read-leaf ranges collected into the plan record
   Plan *plan;
   uint32_t nr;
   uint32_t nlong = 0;
@@ -117,34 +113,34 @@ struct RangeRec {  // read-leaf ranges collected by lane 0 into the plan record
   // at the first slot of the range), bit 1 = nodes[src].end (it still ends at the end of the range)
   uint32_t sdep = 0;
 };
+// (slot_lo, slot_hi: wave-uniform)
 PMA_DEV void rec_range(RangeRec &rr, const View &v, uint32_t slot_lo, uint32_t slot_hi) {
   if (!rr.plan) return;
-  uint32_t lo = slot_lo >> v.g.sh, hi = slot_hi >> v.g.sh;
+  const uint32_t lo = slot_lo >> v.g.sh, hi = slot_hi >> v.g.sh;
   if (rr.nr < (uint32_t)kMaxR) {
-    if (wv::lane() == 0) {
-      rr.plan->rlo[rr.nr] = lo;
-      rr.plan->rhi[rr.nr] = hi;
-    }
+    if (wv::lane() == 0) rr.plan->r[rr.nr] = PlanRange{lo, hi};
     if ((uint32_t)wv::lane() == rr.nr) {
       rr.my_lo = lo;
       rr.my_hi = hi;
     }
     if (hi - lo >= kLongRange) rr.nlong++;
     rr.nr++;
-  } else if (wv::lane() == 0) {
-    // overflow: widen the last range (conservative)
-    uint32_t plo = rr.plan->rlo[kMaxR - 1], phi = rr.plan->rhi[kMaxR - 1];
-    rr.plan->rlo[kMaxR - 1] = lo < plo ? lo : plo;
-    rr.plan->rhi[kMaxR - 1] = hi > phi ? hi : phi;
-    rr.nlong++;
   } else {
+    if (wv::lane() == 0) {  // overflow: widen the last range (conservative)
+      const PlanRange pr = rr.plan->r[kMaxR - 1];
+      rr.plan->r[kMaxR - 1] = PlanRange{lo < pr.lo ? lo : pr.lo, hi > pr.hi ? hi : pr.hi};
+    }
     rr.nlong++;
   }
 }
 
-// Gap-aware lower bound of `dest` in slots [start,end) (PCSR.cpp:427-502), one wave.
-// Lane p probes the p-th slot of the reference's probe sequence mid, mid+1, mid-1, mid+2, ... so the
-// first set bit of the ballot is exactly the slot the reference's scalar walk would stop at.
+// Gap-aware lower bound of `dest` in slots [start,end) (PCSR.cpp:427-502), one wave; dest / start / end are wave-uniform and
+// so is everything derived from them: the walk itself runs on scalars.
+// The reference probes mid, mid+1, mid-1, mid+2, ... until it meets a live slot.  Once the interval fits one wave (<= 64
+// slots) it is loaded ONCE, lane l holding slot cbase + l, and "the first live slot in probe order" is bit arithmetic on the
+// ballot of the live lanes (nearest set bit right of mid against nearest set bit at or left of it; at equal distance the
+// right one is probed first) — no memory round trips, no shuffles.  Longer intervals (only without the narrowing: unsorted
+// ranges) probe memory, lane p taking the p-th slot of the sequence.
 // *hit: what the search already knows about the slot it returns (saves the caller a dependent load): known = 1 with
 // value/dest of that slot, or known = 0.
 struct SearchHit {
@@ -172,23 +168,19 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
     const uint32_t _hi = (end == range_end && end > start) ? end - 1u : end;                \
     rec_range(rr, v, start < _hi ? start : _hi, start < _hi ? _hi : start);                 \
   } while (0)
-  if (!v.g.narrow || end <= start) rr.sdep |= 3u;  // unsorted / inverted ranges (add_node after a doubling): no theorem
-  // Once the interval fits one wave (<= 64 slots) it is loaded ONCE, lane l holding slot cbase + l, and the remaining
-  // levels probe that register copy through shuffles: same probes, same decisions, no further memory round trips.
-  bool cached = false;
-  uint32_t cbase = 0, cend = 0, cval = 0, cdst = 0;
+  const bool narrow = v.g.narrow != 0;
+  if (!narrow || end <= start) rr.sdep |= 3u;  // unsorted / inverted ranges (add_node after a doubling): no theorem
   // 64-ary narrowing.  The value the reference's walk returns does not depend on the walk: any bracket (start, end)
   // with "start is the range's first slot or a live slot whose dest < key" and "end is the range's end or a live slot
   // whose dest > key" leads to the same answer (the walk only ever tightens such a bracket, and every exit fires on
   // the tight one; tests/test_search_model.py checks this against the scalar walk).  So the bracket is first tightened
   // 64 samples at a time — one round trip per factor of ~64 instead of one per factor of 2 — and the reference's walk
   // then finishes it from registers.
-  while (v.g.narrow && end > start && end - start > 64) {  // (end < start happens: add_node after a doubling can leave a vertex whose
+  while (narrow && end > start && end - start > 64) {  // (end < start happens: add_node after a doubling can leave a vertex whose
                                              // recorded range is inverted, PCSR.cpp:533-540 + 681-703; the walk below copes)
     const uint32_t len = end - start;
     // samples sit on an ABSOLUTE power-of-two grid (multiples of 2^sshift), not at offsets from `start`
-    uint32_t sshift = 0;
-    while ((len >> sshift) >= 64u) sshift++;
+    const uint32_t sshift = 26u - (uint32_t)__builtin_clz(len);  // smallest shift with (len >> shift) < 64  (len > 64)
     const uint32_t first = ((start + (1u << sshift) - 1u) >> sshift) << sshift;
     const uint32_t sl = first + ((uint32_t)lane << sshift);
     uint32_t sv = 0, sd = 0;
@@ -202,24 +194,27 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
     uint32_t nstart = start, nend = end;
     if (mge) {
       const int lb = wv::ctz64(mge);
-      const uint32_t bslot = wv::shfl(sl, lb), bdst = wv::shfl(sd, lb);
+      const uint32_t bslot = first + ((uint32_t)lb << sshift), bdst = wv::bcast(sd, lb);
       if (bdst == dest) {  // the key itself: the walk returns its slot whenever it meets it
         rec_range(rr, v, bslot, bslot);
         hit->known = 1;
-        hit->value = wv::shfl(sv, lb);
+        hit->value = wv::bcast(sv, lb);
         hit->dest = bdst;
         return bslot;
       }
       nend = bslot;
     }
-    if (mlt) nstart = wv::shfl(sl, 63 - __builtin_clzll(mlt));
+    if (mlt) nstart = first + ((uint32_t)(63 - wv::clz64(mlt)) << sshift);
     const bool progress = (nend - nstart) <= len / 2u;
     start = nstart;
     end = nend;
     if (!progress) break;  // sparse samples: let the reference's walk take over from here
   }
+  bool cached = false;
+  uint32_t cbase = 0, cend = 0, cval = 0, cdst = 0;
+  uint64_t clive = 0;  // bit l: slot cbase + l is live
   while (start + 1 < end) {
-    if (!cached && end > start && end - start <= 64) {
+    if (!cached && end - start <= 64) {
       cbase = start;
       cend = end;
       const uint32_t s = start + (uint32_t)lane;
@@ -227,45 +222,78 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
         cval = items[s].value;
         cdst = items[s].dest;
       }
+      clive = wv::ballot(s < end && cval != 0);
       cached = true;
+      if (narrow) {
+        // one more narrowing step, on the register copy: the bracket comes out tight (or the key is found), and the walk
+        // below ends in its first iteration
+        const uint64_t mge = wv::ballot(s < end && cval != 0 && cdst >= dest);
+        const uint64_t mlt = clive & ~mge;
+        if (mge) {
+          const int lb = wv::ctz64(mge);
+          const uint32_t bdst = wv::bcast(cdst, lb);
+          if (bdst == dest) {
+            rec_range(rr, v, cbase + (uint32_t)lb, cbase + (uint32_t)lb);
+            hit->known = 1;
+            hit->value = wv::bcast(cval, lb);
+            hit->dest = bdst;
+            return cbase + (uint32_t)lb;
+          }
+          end = cbase + (uint32_t)lb;
+        }
+        if (mlt) start = cbase + (uint32_t)(63 - wv::clz64(mlt));
+        continue;
+      }
     }
     const uint32_t mid = (start + end) / 2;
     bool found = false;
     uint32_t check = mid, idest = 0, ival = 0;
-    for (uint32_t pbase = 0;; pbase += 64) {
-      const uint32_t p = pbase + (uint32_t)lane;
-      const uint32_t d = (p + 1) >> 1;
-      bool valid;
-      uint32_t slot;
-      if (p & 1u) {
-        slot = mid + d;
-        valid = (d < end - mid);  // mid + d < end
-      } else {
-        slot = mid - d;
-        valid = (d <= mid - start);  // mid - d >= start
-      }
-      uint32_t val = 0, dst = 0;
-      if (cached) {
-        const int from = valid ? (int)(slot - cbase) : 0;
-        const uint32_t tv = wv::shfl(cval, from), td = wv::shfl(cdst, from);
-        if (valid) {
-          val = tv;
-          dst = td;
-        }
-      } else if (valid) {
-        val = items[slot].value;
-        dst = items[slot].dest;
-      }
-      const uint64_t m = wv::ballot(valid && val != 0);
-      if (m) {
-        const int pl = wv::ctz64(m);
-        check = wv::shfl(slot, pl);
-        idest = wv::shfl(dst, pl);
-        ival = wv::shfl(val, pl);
+    if (cached) {
+      // even probes: mid - d for d = 0 .. mid - start; odd probes: mid + d for d = 1 .. end - mid - 1; probe 2d - 1 (right)
+      // comes before probe 2d (left)
+      const uint32_t s0 = start - cbase, m0 = mid - cbase, e0 = end - cbase;  // s0 <= m0 < e0 <= 64
+      const uint64_t upto_m = (m0 >= 63u) ? ~0ull : ((2ull << m0) - 1ull);           // bits 0 .. m0
+      const uint64_t below_s = (1ull << s0) - 1ull;                                    // bits 0 .. s0 - 1   (s0 <= 62)
+      const uint64_t below_e = (e0 >= 64u) ? ~0ull : ((1ull << e0) - 1ull);          // bits 0 .. e0 - 1
+      const uint64_t left = clive & upto_m & ~below_s, right = clive & ~upto_m & below_e;
+      if (left | right) {
         found = true;
-        break;
+        const uint32_t lpos = left ? (uint32_t)(63 - wv::clz64(left)) : 0u, rpos = right ? (uint32_t)wv::ctz64(right) : 0u;
+        const bool take_left = left && (!right || (m0 - lpos) < (rpos - m0));
+        const uint32_t at = take_left ? lpos : rpos;
+        check = cbase + at;
+        idest = wv::bcast(cdst, (int)at);
+        ival = wv::bcast(cval, (int)at);
       }
-      if (wv::ballot(valid) == 0) break;  // both sides exhausted: the whole range is null
+    } else {
+      for (uint32_t pbase = 0;; pbase += 64) {
+        const uint32_t p = pbase + (uint32_t)lane;
+        const uint32_t d = (p + 1) >> 1;
+        bool valid;
+        uint32_t slot;
+        if (p & 1u) {
+          slot = mid + d;
+          valid = (d < end - mid);  // mid + d < end
+        } else {
+          slot = mid - d;
+          valid = (d <= mid - start);  // mid - d >= start
+        }
+        uint32_t val = 0, dst = 0;
+        if (valid) {
+          val = items[slot].value;
+          dst = items[slot].dest;
+        }
+        const uint64_t m = wv::ballot(valid && val != 0);
+        if (m) {
+          const int pl = wv::ctz64(m);
+          check = wv::bcast(slot, pl);
+          idest = wv::bcast(dst, pl);
+          ival = wv::bcast(val, pl);
+          found = true;
+          break;
+        }
+        if (wv::ballot(valid) == 0) break;  // both sides exhausted: the whole range is null
+      }
     }
     if (!found || check == start) {
       // nothing live in (start, end): the bracket is tight
@@ -297,8 +325,8 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
   if (end < start) start = end;
   uint32_t ev, ed;
   if (cached && start >= cbase && start < cend) {
-    ev = wv::shfl(cval, (int)(start - cbase));
-    ed = wv::shfl(cdst, (int)(start - cbase));
+    ev = wv::bcast(cval, (int)(start - cbase));
+    ed = wv::bcast(cdst, (int)(start - cbase));
   } else {
     ev = items[start].value;
     ed = items[start].dest;
@@ -316,8 +344,8 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
   }
   if (cached && end >= cbase && end < cend) {
     hit->known = 1;
-    hit->value = wv::shfl(cval, (int)(end - cbase));
-    hit->dest = wv::shfl(cdst, (int)(end - cbase));
+    hit->value = wv::bcast(cval, (int)(end - cbase));
+    hit->dest = wv::bcast(cdst, (int)(end - cbase));
   }
   return end;
 #undef PMA_CERT_BRACKET
@@ -327,7 +355,7 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
 // pre / pre_nul / pre_w: the caller has already loaded the first pre_w slots (lane l < pre_w: slot from + l is null)
 PMA_DEV uint32_t find_gap_right(const View &v, uint32_t from, uint32_t limit, bool pre = false, bool pre_nul = false, uint32_t pre_w = 64) {
   const int lane = wv::lane();
-  const uint64_t N = v.gap_end ? v.gap_end : v.g.N;
+  const uint64_t N = v.g.N;
   for (uint64_t base = from; base < N; base += 64) {
     if (base - from > limit) return kMax;
     const uint64_t s = base + (uint64_t)lane;
@@ -886,20 +914,37 @@ PMA_DEV void slide_left_wave(const View &v, uint32_t gap, uint32_t last) {
 }
 
 // ---- full per-op planning (search + window plan) -------------------------------------------------------
-// What the planning kernels need from the plan right away (the full record goes to memory for the later kernels)
+// What the planning kernels need from the plan right away (the full record goes to memory for the later kernels).  Everything
+// but my_lo / my_hi is wave-uniform (scalar registers).
 struct PlanRegs {
   uint32_t kind, index, wstart, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, nr, nlong, sdep, sleaf_b, sleaf_e;
   uint32_t my_lo, my_hi;  // lane r: read range r (r < 64)
 };
-// LOCAL (the in-round chains, o_chain): everything is derived from the slots [r0, r1] of ONE region and from nothing else —
-// no node records, no slots or leaf counts of other regions — so that the waves that work on different regions at the same
-// time never read what another one is writing (XCDs do not see each other's stores inside a launch).  The vertex' range is
-// not looked up in nodes[]: one sweep over the region finds the tight bracket directly — the last live slot of `src` with
-// dest < key (or the slot after sentinel src), the first with dest > key (or sentinel src + 1), or the key itself — and the
-// reference's walk on that bracket returns what it returns on the whole range (pma_search: the result is a function of the
-// final tight bracket).  Updates whose bracket is not inside the region come back as K_FOREIGN.
-template <bool LOCAL>
-PMA_DEV PlanRegs plan_op_t(const View &v, const Op op, Plan *plan, uint32_t r0 = 0, uint32_t r1 = 0) {
+// the 16 header words of a plan record, lane i holding word i: one wave-wide store (the record's first 64 bytes)
+PMA_DEV void store_plan_header(Plan *plan, uint32_t kind, uint32_t index, uint32_t gap, uint32_t wstart, uint32_t wlen, uint32_t wl, uint32_t wh,
+                               uint32_t mv_lo, uint32_t mv_hi, uint32_t sleaf_b, uint32_t sleaf_e, uint32_t acalls, uint32_t aslots, uint32_t nr,
+                               uint32_t nlong, uint32_t sdep) {
+  uint32_t w = 0;
+  w = wv::setlane<PW_KIND>(w, kind);
+  w = wv::setlane<PW_INDEX>(w, index);
+  w = wv::setlane<PW_GAP>(w, gap);
+  w = wv::setlane<PW_WSTART>(w, wstart);
+  w = wv::setlane<PW_WLEN>(w, wlen);
+  w = wv::setlane<PW_WLEAF_LO>(w, wl);
+  w = wv::setlane<PW_WLEAF_HI>(w, wh);
+  w = wv::setlane<PW_MV_LO>(w, mv_lo);
+  w = wv::setlane<PW_MV_HI>(w, mv_hi);
+  w = wv::setlane<PW_SLEAF_B>(w, sleaf_b);
+  w = wv::setlane<PW_SLEAF_E>(w, sleaf_e);
+  w = wv::setlane<PW_ALG_CALLS>(w, acalls);
+  w = wv::setlane<PW_ALG_SLOTS>(w, aslots);
+  w = wv::setlane<PW_NR>(w, nr);
+  w = wv::setlane<PW_NLONG>(w, nlong);
+  w = wv::setlane<PW_SDEP>(w, sdep);
+  if (wv::lane() < (int)PW_HEADER_WORDS) reinterpret_cast<uint32_t *>(plan)[wv::lane()] = w;
+}
+// op: wave-uniform
+PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
   const int lane = wv::lane();
   const Geometry &g = v.g;
   RangeRec rr;
@@ -907,71 +952,35 @@ PMA_DEV PlanRegs plan_op_t(const View &v, const Op op, Plan *plan, uint32_t r0 =
   rr.nr = 0;
   uint32_t kind = K_NOOP, index = 0, gap = 0, wstart = 0, wlen = 0, wl = 1, wh = 0, acalls = 0, aslots = 0;
   uint32_t sleaf_b = 0, sleaf_e = 0, mv_lo = 1, mv_hi = 0;
-  uint32_t s_start = 0, s_end = 0, sdep_mask = 3u;
-  bool located = true;
+  // The node records around `src`, requested in ONE batch before anything depends on them: lanes 0 .. kW-1 hold the sentinel
+  // positions of src, src-1, ... (lane 0 also nodes[src].end), lanes kW .. 2kW-1 those of src+1, src+2, ... — the vertex' own
+  // range now, the sentinels inside the update's write range later (the loads do not depend on the window, only the
+  // comparisons do: asked for after the window plan they were one more round trip at the end of every plan)
+  constexpr uint32_t kW = 8;
+  uint32_t b0 = 0, e0 = 0;
+  bool v0 = false;
   if (op.src < g.n) {
-    if (!LOCAL) {
-      const Node nd = v.nodes[op.src];
-      // nodes[src].{beginning,end} are the positions of sentinels src / src+1: that dependency is tracked per vertex
-      // (Plan::mv_lo/mv_hi of the writers, View::vw/vr), not through the leaves that hold them
-      sleaf_b = nd.beginning >> g.sh;
-      sleaf_e = nd.end >> g.sh;
-      s_start = nd.beginning + 1;
-      s_end = nd.end;
-    } else {
-      // one sweep over the region: every lane looks at its share of the slots (independent loads, all in flight together)
-      uint32_t la = 0, lb = kMax, leq = kMax, ls0 = kMax, ls1 = kMax;  // la: 1 + slot
-      for (uint32_t s = r0 + (uint32_t)lane; s <= r1; s += 64u) {
-        const Edge e = v.items[s];
-        if (e.value == 0) continue;
-        if (is_sentinel(e)) {
-          if (e.src == op.src) ls0 = s;
-          if (e.src == op.src + 1u) ls1 = s;
-        } else if (e.src == op.src) {
-          if (e.dest < op.dst) la = s + 1u;            // (slots ascend with the trip count: the last one stays)
-          else if (e.dest == op.dst) leq = s;
-          else if (lb == kMax) lb = s;
-        }
-      }
-      for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t ya = wv::shfl(la, lane ^ o), yb = wv::shfl(lb, lane ^ o), ye = wv::shfl(leq, lane ^ o), y0 = wv::shfl(ls0, lane ^ o),
-                       y1 = wv::shfl(ls1, lane ^ o);
-        la = ya > la ? ya : la;
-        lb = yb < lb ? yb : lb;
-        leq = ye < leq ? ye : leq;
-        ls0 = y0 < ls0 ? y0 : ls0;
-        ls1 = y1 < ls1 ? y1 : ls1;
-      }
-      sdep_mask = 0u;
-      if (leq != kMax) {  // the key itself
-        s_start = leq;
-        s_end = leq + 1u;
-      } else {
-        if (la != 0u) s_start = la - 1u;
-        else if (ls0 != kMax) {
-          s_start = ls0 + 1u;
-          sdep_mask |= 1u;
-          sleaf_b = ls0 >> g.sh;
-        } else located = false;
-        if (lb != kMax) s_end = lb;
-        else if (ls1 != kMax) {
-          s_end = ls1;
-          sdep_mask |= 2u;
-          sleaf_e = ls1 >> g.sh;
-        } else located = false;
-        if (located && s_end <= s_start) located = false;  // (cannot happen in a sorted neighbourhood)
-      }
+    if ((uint32_t)lane < kW) {
+      v0 = (uint32_t)lane <= op.src;
+      if (v0) b0 = v.nodes[op.src - (uint32_t)lane].beginning;
+      if (lane == 0) e0 = v.nodes[op.src].end;
+    } else if ((uint32_t)lane < 2u * kW) {
+      const uint64_t u = (uint64_t)op.src + 1ull + ((uint64_t)lane - kW);
+      v0 = u < g.n;
+      if (v0) b0 = v.nodes[u].beginning;
     }
   }
-  if (op.src < g.n && !located) {
-    kind = K_FOREIGN;
-  } else if (op.src < g.n) {
+  if (op.src < g.n) {
+    // nodes[src].{beginning,end} are the positions of sentinels src / src+1: that dependency is tracked per vertex
+    // (Plan::mv_lo/mv_hi of the writers, View::vw/vr), not through the leaves that hold them
+    const uint32_t nd_beginning = wv::bcast(b0, 0), nd_end = wv::bcast(e0, 0);
+    sleaf_b = nd_beginning >> g.sh;
+    sleaf_e = nd_end >> g.sh;
     SearchHit hit;
-    index = pma_search(v, op.dst, s_start, s_end, rr, &hit);
-    rr.sdep &= sdep_mask;
+    index = pma_search(v, op.dst, nd_beginning + 1, nd_end, rr, &hit);
     const uint32_t leaf = index >> g.sh;
     // one batch of independent loads: the slot the search returned (unless the search already knows it), its leaf's
-    // count, and — for an occupied slot — the first 64 slots of the gap search to the right
+    // count, and — for an occupied slot — the first slots of the gap search to the right
     Edge at;
     at.src = 0;
     at.value = hit.value;
@@ -985,7 +994,7 @@ PMA_DEV PlanRegs plan_op_t(const View &v, const Op op, Plan *plan, uint32_t r0 =
     constexpr uint32_t kGapPre = 16;  // slots of the gap search requested with this batch (a null within 16 slots in 99.7 % of the cases at density 0.7)
     if (op.op != 0 && (uint32_t)lane < kGapPre) {
       const uint64_t g0 = (uint64_t)index + 1ull + (uint64_t)lane;
-      if (g0 < (v.gap_end ? v.gap_end : g.N)) nul0 = (v.items[g0].value == 0);
+      if (g0 < g.N) nul0 = (v.items[g0].value == 0);
     }
     const bool occupied = !is_null(at);
     if (op.op != 0) {
@@ -1121,55 +1130,16 @@ PMA_DEV PlanRegs plan_op_t(const View &v, const Op op, Plan *plan, uint32_t r0 =
   if (kind == K_INSERT || kind == K_REMOVE) {
     // sentinels inside [lo, hi] = slide range U window.  Sentinel positions increase with the vertex id and
     // beg(src) < index <= beg(src+1), so they are the vertices src, src-1, ... and src+1, src+2, ... around `src`.
+    // The first kW of both directions are in registers already (b0): no round trip for almost every update — a one-leaf
+    // window holds a handful of sentinels at most.
     const uint32_t lo = (wstart < index) ? wstart : index;
     const uint32_t whi = wstart + wlen - 1u;
     const uint32_t hi = (kind == K_INSERT && gap > whi) ? gap : whi;
-    uint32_t down = 0, up = 0;
-    if (LOCAL) {
-      // the sentinels inside [lo, hi], read off the slots themselves (ascending vertex ids with ascending positions)
-      uint32_t vfirst = kMax, vlast = 0, pfirst = 0;
-      bool anys = false;
-      for (uint32_t base = lo; base <= hi; base += 64u) {
-        const uint32_t s = base + (uint32_t)lane;
-        Edge e = null_edge();
-        if (s <= hi) e = v.items[s];
-        const uint64_t m = wv::ballot(s <= hi && e.value != 0 && is_sentinel(e));
-        if (m) {
-          const int lf = wv::ctz64(m), ll = 63 - __builtin_clzll(m);
-          if (!anys) {
-            vfirst = wv::shfl(e.src, lf);
-            pfirst = base + (uint32_t)lf;
-            anys = true;
-          }
-          vlast = wv::shfl(e.src, ll);
-        }
-        if (hi - base < 64u) break;
-      }
-      if (anys) {
-        mv_lo = vfirst;
-        mv_hi = vlast;
-        if (pfirst == wstart && (kind == K_REMOVE || index > wstart)) mv_lo++;
-      }
-    } else {
-    // both directions' first kW vertices are requested together, kW lanes each (one round trip for almost every update:
-    // a one-leaf window holds a handful of sentinels at most; 64 node records per direction cost 3 KB of fetches per update)
-    constexpr uint32_t kW = 8;
-    uint32_t b0 = 0;
-    bool v0 = false;
-    if ((uint32_t)lane < kW) {
-      v0 = (uint32_t)lane <= op.src;
-      if (v0) b0 = v.nodes[op.src - (uint32_t)lane].beginning;
-    } else if ((uint32_t)lane < 2u * kW) {
-      const uint64_t u = (uint64_t)op.src + 1ull + ((uint64_t)lane - kW);
-      v0 = u < g.n;
-      if (v0) b0 = v.nodes[u].beginning;
-    }
     const uint64_t mdn = wv::ballot((uint32_t)lane < kW && v0 && b0 >= lo);
     const uint64_t mup = wv::ballot((uint32_t)lane >= kW && (uint32_t)lane < 2u * kW && v0 && b0 <= hi) >> kW;
     uint32_t beg_lowest = 0;  // beginning of the lowest vertex found inside the range (vertex mv_lo)
-    down = (uint32_t)wv::popc64(mdn);
-    up = (uint32_t)wv::popc64(mup);
-    if (mdn) beg_lowest = wv::shfl(b0, 63 - __builtin_clzll(mdn));  // (the in-range vertices are a prefix of the lanes)
+    uint32_t down = (uint32_t)wv::popc64(mdn), up = (uint32_t)wv::popc64(mup);
+    if (mdn) beg_lowest = wv::bcast(b0, 63 - wv::clz64(mdn));  // (the in-range vertices are a prefix of the lanes)
     if (mdn == ((1ull << kW) - 1ull)) {
       for (uint32_t base = kW;; base += 64) {  // downwards: src - kW, ...
         const uint32_t k = base + (uint32_t)lane;
@@ -1180,7 +1150,7 @@ PMA_DEV PlanRegs plan_op_t(const View &v, const Op op, Plan *plan, uint32_t r0 =
           in = bg >= lo;
         }
         const uint64_t m = wv::ballot(in);
-        if (m) beg_lowest = wv::shfl(bg, 63 - __builtin_clzll(m));
+        if (m) beg_lowest = wv::bcast(bg, 63 - wv::clz64(m));
         down += (uint32_t)wv::popc64(m);
         if (m != ~0ull) break;
       }
@@ -1200,29 +1170,13 @@ PMA_DEV PlanRegs plan_op_t(const View &v, const Op op, Plan *plan, uint32_t r0 =
     // the element at the first slot of the rebalance window keeps its slot (PCSR.cpp:240: "already in the correct
     // position"); a sentinel sitting there does not move unless the insert/slide displaces it
     if (mv_lo <= mv_hi) {
-      const uint32_t b_lo = (down > 0) ? beg_lowest : v.nodes[mv_lo].beginning;
+      // (down == 0: the lowest vertex inside is src + 1, whose sentinel position is lane kW's)
+      const uint32_t b_lo = (down > 0) ? beg_lowest : wv::bcast(b0, (int)kW);
       if (b_lo == wstart && (kind == K_REMOVE || index > wstart)) mv_lo++;
     }
-    }
   }
-  if (lane == 0) {
-    plan->mv_lo = mv_lo;
-    plan->mv_hi = mv_hi;
-    plan->sleaf_b = sleaf_b;
-    plan->sleaf_e = sleaf_e;
-    plan->kind = kind;
-    plan->index = index;
-    plan->gap = gap;
-    plan->wstart = wstart;
-    plan->wlen = wlen;
-    plan->wleaf_lo = wl;
-    plan->wleaf_hi = wh;
-    plan->alg_calls = acalls;
-    plan->alg_slots = aslots;
-    plan->nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
-    plan->nlong = rr.nlong;
-    plan->sdep = rr.sdep;
-  }
+  const uint32_t nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
+  store_plan_header(plan, kind, index, gap, wstart, wlen, wl, wh, mv_lo, mv_hi, sleaf_b, sleaf_e, acalls, aslots, nr, rr.nlong, rr.sdep);
   PlanRegs pr;
   pr.sdep = rr.sdep;
   pr.kind = kind;
@@ -1235,13 +1189,49 @@ PMA_DEV PlanRegs plan_op_t(const View &v, const Op op, Plan *plan, uint32_t r0 =
   pr.wleaf_hi = wh;
   pr.mv_lo = mv_lo;
   pr.mv_hi = mv_hi;
-  pr.nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
+  pr.nr = nr;
   pr.nlong = rr.nlong;
   pr.my_lo = rr.my_lo;
   pr.my_hi = rr.my_hi;
   return pr;
 }
-PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) { return plan_op_t<false>(v, op, plan); }
+
+// The plan record's header and this lane's read range, requested in ONE batch: lane i loads header word i, lane r < kHeadRanges
+// range r — two wave-wide loads inside the record's first 128 bytes — and the fields are read off the lanes as scalars.
+constexpr int kHeadRanges = 8;
+struct PlanHead {
+  uint32_t kind, index, gap, wstart, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, sleaf_b, sleaf_e, alg_calls, alg_slots, nr, nlong, sdep;
+  uint32_t my_lo, my_hi;  // lane r: read range r (r < kHeadRanges; longer lists are walked from the record)
+};
+PMA_DEV PlanHead load_plan_head(const Plan *pl) {
+  const int lane = wv::lane();
+  uint32_t w = 0;
+  PlanRange rg{1u, 0u};
+  if (lane < (int)PW_HEADER_WORDS) w = reinterpret_cast<const uint32_t *>(pl)[lane];
+  if (lane < kHeadRanges) rg = pl->r[lane];
+  uint32_t f[PW_HEADER_WORDS];
+  wv::lanes16(w, f);
+  PlanHead h;
+  h.kind = f[PW_KIND];
+  h.index = f[PW_INDEX];
+  h.gap = f[PW_GAP];
+  h.wstart = f[PW_WSTART];
+  h.wlen = f[PW_WLEN];
+  h.wleaf_lo = f[PW_WLEAF_LO];
+  h.wleaf_hi = f[PW_WLEAF_HI];
+  h.mv_lo = f[PW_MV_LO];
+  h.mv_hi = f[PW_MV_HI];
+  h.sleaf_b = f[PW_SLEAF_B];
+  h.sleaf_e = f[PW_SLEAF_E];
+  h.alg_calls = f[PW_ALG_CALLS];
+  h.alg_slots = f[PW_ALG_SLOTS];
+  h.nr = f[PW_NR];
+  h.nlong = f[PW_NLONG];
+  h.sdep = f[PW_SDEP];
+  h.my_lo = rg.lo;
+  h.my_hi = rg.hi;
+  return h;
+}
 
 // A window too large for one wave is handed to a workgroup (o_big) through the round's job queue: the update's own wave
 // does everything up to the final rebalance (slide, write, counters) and leaves the leaf counts exact.
@@ -1249,7 +1239,8 @@ struct BigJob {
   uint32_t wstart, wlen;
 };
 // apply a planned op whose reservations were validated.  defer != nullptr: queue the rebalance instead of running it here.
-PMA_DEV void apply_op(const View &v, const Op op, const Plan *plan, uint32_t *lds, StatShard *st, BigJob *defer = nullptr) {
+PMA_DEV void apply_op(const View &v, const Op op, const PlanHead &h, uint32_t *lds, StatShard *st, BigJob *defer = nullptr) {
+  const PlanHead *plan = &h;
   const int lane = wv::lane();
   const Geometry &g = v.g;
   const uint32_t kind = plan->kind;

@@ -1,0 +1,669 @@
+// Speculative rounds of the update scheduler (o_plan / o_check / o_apply / o_compact).
+#pragma once
+#include "pma_rounds.h"
+
+namespace ppcsr {
+
+// =====================================================================================================================
+// Speculative rounds ("optimistic mode"): commit more than a strict prefix per round, validated, with rollback.
+//
+// A round plans the M lowest pending updates (the carry list of deferred updates, then fresh ones from the stream).
+// Every plan reserves its write leaves (wres) and read leaves (rres) with atomicMin(stream index).  An update PASSES
+// when no earlier pending update writes anything it reads or writes and no earlier pending update reads anything it
+// writes.  Passing updates commit unless an earlier update of the same REGION (aligned block of 2^regshift leaves)
+// failed this round — a per-region strict prefix, which keeps later updates from overtaking a deferred update inside
+// the block where its footprint can still move (rebalance windows are aligned power-of-two blocks no larger than a
+// region, so a deferred update's window cannot leave its region).
+//
+// Soundness does not rest on that heuristic: every committed update stamps the leaves it read (rstamp) and wrote
+// (wstamp) with its stream index, and an update may only commit if no LATER update has already written a leaf it
+// reads or writes, nor read a leaf it writes.  With that check the executed schedule is conflict-serialisable in
+// stream order (every conflicting pair ran in index order), i.e. identical to the reference's sequential result.  A
+// failed check raises `violation`: the host restores the epoch snapshot and replays the epoch with the strict prefix
+// rounds above.  K_EXCL updates are barriers: nothing later commits until the exclusive executor has run them.
+// =====================================================================================================================
+struct OptCtl {
+  uint32_t carry_n[2], next_fresh[2], hor[2];
+  uint32_t e1;  // end of the epoch (exclusive stream index)
+  uint32_t violation, excl, done, error;
+  uint32_t max_horizon, excl_idx;  // max_horizon: width of the launched grid (the next round's horizon never exceeds it)
+  uint32_t width_cap;              // upper bound of the adaptive width (the engine's opt_horizon)
+  uint32_t resident;               // waves the chip holds at once (0 = unknown): above it the width moves in whole multiples
+  uint32_t maxc;  // 1 + largest stream index committed in this epoch
+  uint32_t viol_idx;  // smallest stream index whose commit-time validation failed
+  uint32_t adaptive;     // 1: adapt cur_horizon to the share of a round that commits (see compact_block)
+  uint32_t cur_horizon;  // adaptive round width (<= max_horizon): grows while most of the round commits, shrinks otherwise
+  unsigned long long gbar[2];  // keyed min index of a K_EXCL update in the horizon
+  unsigned long long sbar[2];  // keyed min index of a SOFT barrier (a planned window close to the exclusive threshold): a word of
+                               // its own — folded into gbar as key + 1 it was indistinguishable from a real K_EXCL key of update
+                               // idx + 1, and o_compact then sent that update to the exclusive executor whatever its kind
+  unsigned long long rounds, committed, planned, blocked, failed;
+  uint32_t viol_info[8];  // debug: kind, leaf, stamp, what(1=wstamp on W,2=rstamp on W,3=wstamp on R), wleaf_lo, wleaf_hi, index, round
+  uint32_t hist[192];  // debug: (horizon << 16 | committed) >> of the first rounds of the epoch
+  // diagnostics (option "diag"): why planned updates did not commit, first reason found per update
+  // 0 exclusive kind, 1 behind a barrier (gbar), 2 duplicate-slot conflicts, 3 write leaf reserved by an earlier writer,
+  // 4 write leaf read by an earlier update, 5 read leaf written by an earlier update, 6 sentinel located by is moved earlier,
+  // 7 sentinel we move is needed earlier, 8 region prefix, 9 growth zone of a deferred reader/writer (pfail), 10 stamp violation
+  unsigned long long why[12];
+  uint32_t njobs[2];  // big-window rebalances queued by this round's o_apply (by round parity; the next round's entry is reset by o_compact)
+  uint32_t jobs_round[2];  // the round that queued them (launches that follow an exclusive / final round must not run them again)
+  uint32_t skip;   // stream index the exclusive executor has just run inside this epoch (kMax: none); its slot commits as nothing
+  uint32_t resume_par;  // round parity whose double-buffered entries (hor / carry_n / next_fresh / carry list) are current: the
+                        // launches queued behind an exclusive update return at once and do not flip them
+};
+struct OptArgs {
+  View v;
+  const Op *ops;
+  Plan *plans;
+  uint32_t *opidx, *status, *vdbg;
+  uint32_t *carry0, *carry1;
+  OptCtl *ctl;
+  StatShard *stats;
+  unsigned long long *regfail;
+  unsigned long long *pfail;  // per-leaf: smallest deferred update whose footprint may still grow over this leaf
+  uint32_t *wstamp, *rstamp;
+  uint32_t *vws, *vrs;  // per vertex: 1 + latest committed update that moved / read the position of its sentinel
+  uint32_t round;
+  int regshift;
+  uint32_t diag;
+  uint32_t defer_barrier;  // 0: off
+  uint32_t soft_barrier;   // slots: see o_plan
+  // windows above big_min slots are rebalanced by a workgroup of o_big (job queue + one scratch stretch per workgroup)
+  uint32_t big_min;
+  dev::BigJob *jobs;
+  Edge *bigscratch;
+  uint32_t bigscratch_stride;  // slots per workgroup
+  // diag >= 2: per update of the batch {rounds it failed in, code of the last failure, stream index of what blocked it,
+  // planned window}: the dependency chains of an epoch can be followed afterwards (tools/diag_chains.py)
+  uint32_t *dg;
+};
+constexpr uint32_t kBigJobs = 256;  // capacity of the round's job queue
+constexpr uint32_t kRegionPadLeaves = 2u;
+constexpr uint32_t kGrowLeaves = 8u;
+constexpr uint32_t OS_PASS = 1u, OS_STAMP_BAD = 2u, OS_COMMITTED = 4u;
+
+
+PMA_DEV bool key_earlier(unsigned long long k, uint32_t tag, uint32_t idx) { return (uint32_t)(k >> 32) == tag && (uint32_t)k < idx; }
+
+// (dev::load_plan_head: the plan record's header and this lane's read range, requested in ONE batch and before the kernel's
+// early-exit tests — the per-wave arrays are padded to the launch grid, so the loads are always in bounds.  The round kernels
+// are chains of dependent loads; what can be asked for together is asked for together.)
+using dev::PlanHead;
+using dev::kHeadRanges;
+#define PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, LEAFVAR, BODY)                                  \
+  do {                                                                                        \
+    if ((h).nr <= (uint32_t)kHeadRanges && (h).nlong == 0u) {                                 \
+      if ((uint32_t)(lane) < (h).nr)                                                          \
+        for (uint32_t LEAFVAR = (h).my_lo; LEAFVAR <= (h).my_hi; LEAFVAR++) { BODY; }         \
+    } else {                                                                                  \
+      PMA_FOR_EACH_READ_LEAF(pl, lane, LEAFVAR, BODY);                                        \
+    }                                                                                         \
+  } while (0)
+
+template <bool EXTRAS>
+PMA_DEV void o_plan_t(const OptArgs &a) {
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  // (one wave = one update: the wave's slot and everything that follows from it is the same in all lanes — see wv::uni)
+  const uint32_t wid = wv::uni(wv::block_idx() * 4u + (uint32_t)wv::wave_in_block());  // (256-thread workgroups)
+  const uint32_t *carry = par ? a.carry1 : a.carry0;
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error, f_skip = c->skip;
+  const uint32_t hor = c->hor[par], cn = c->carry_n[par], nf = c->next_fresh[par];
+  const uint32_t cw = carry[wid];  // (requested with the control block; the carry lists are padded to the launch grid)
+  if (f_done || f_viol || f_excl || f_err) return;
+  if (wid >= hor) return;
+  const uint32_t used = cn < hor ? cn : hor;
+  const uint32_t idx = wv::uni((wid < used) ? cw : nf + (wid - used));
+  Op op = a.ops[idx];
+  op.src = wv::uni(op.src);
+  op.dst = wv::uni(op.dst);
+  op.op = wv::uni(op.op);
+  Plan *pl = &a.plans[wid];
+  const int lane = wv::lane();
+  if (idx == f_skip) {  // executed by the exclusive executor in the middle of this epoch: nothing left to do, commits at once
+    if (lane == 0) a.opidx[wid] = idx;
+    dev::store_plan_header(pl, K_SKIP, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0);
+    return;
+  }
+  // the plan record goes to memory for o_check / o_apply; this kernel reserves straight from the registers
+  const dev::PlanRegs pr = dev::plan_op(a.v, op, pl);
+  if (lane == 0) a.opidx[wid] = idx;
+  const unsigned long long key = make_key(a.round, idx);
+  const uint32_t kind = pr.kind;
+  if (kind == K_EXCL) {
+    if (lane == 0) wv::atomic_min_u64(&c->gbar[par], key);
+    return;
+  }
+  if (kind == K_DUP) {
+    if (lane == 0) wv::atomic_min_u64(&a.v.dres[pr.wleaf_lo], key);
+  } else if (kind_strong(kind)) {
+    const uint32_t wl = pr.wleaf_lo, wh = pr.wleaf_hi;
+    for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_min_u64(&a.v.wres[leaf], key);
+    // an update whose window is already within two levels of the exclusive threshold is likely to turn exclusive
+    // once the earlier updates have landed: nothing later may overtake it (soft barrier)
+    // ... and so is an update that has ALREADY been deferred at least once and whose window is big (a.defer_barrier
+    // slots): its window keeps growing while it waits behind a hot range, and everything committed around it meanwhile
+    // is a candidate for a rollback
+    if ((pr.wlen >= a.soft_barrier || (a.defer_barrier && wid < used && pr.wlen >= a.defer_barrier)) && lane == 0) {
+      wv::atomic_min_u64(&c->sbar[par], key);
+    }
+    const uint32_t ml = pr.mv_lo, mh = pr.mv_hi;
+    for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_min_u64(&a.v.vw[u], key);
+  }
+  if (pr.nr <= 64u && pr.nlong == 0u) {  // lane r holds read range r
+    if ((uint32_t)lane < pr.nr)
+      for (uint32_t leaf = pr.my_lo; leaf <= pr.my_hi; leaf++) wv::atomic_min_u64(&a.v.rres[leaf], key);
+  } else {
+    wv::fence();  // (rare) more ranges than lanes, or long ranges: walk the record this wave has just written
+    PMA_FOR_EACH_READ_LEAF(pl, lane, leaf, wv::atomic_min_u64(&a.v.rres[leaf], key));
+  }
+  if (kind_real(kind) && op.src < a.v.g.n) {  // readers of the positions of sentinels src and src+1 (only when the result depends on them)
+    if (lane == 0 && (pr.sdep & 1u)) wv::atomic_min_u64(&a.v.vr[op.src], key);
+    if (lane == 1 && (pr.sdep & 2u) && op.src + 1u < a.v.g.n) wv::atomic_min_u64(&a.v.vr[op.src + 1u], key);
+  }
+}
+PMA_KERNEL void o_plan(OptArgs a) { o_plan_t<false>(a); }
+PMA_KERNEL void o_plan_x(OptArgs a) { o_plan_t<true>(a); }
+
+template <bool EXTRAS>
+PMA_DEV void o_check_t(const OptArgs &a) {
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  const uint32_t wid = wv::uni(wv::block_idx() * 4u + (uint32_t)wv::wave_in_block());
+  const int lane = wv::lane();
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  const uint32_t hor = c->hor[par];
+  const unsigned long long gbar = c->gbar[par], sbar = c->sbar[par];
+  const uint32_t idx = wv::uni(a.opidx[wid]);
+  const Plan *pl = &a.plans[wid];
+  const PlanHead h = dev::load_plan_head(pl);
+  if (f_done || f_viol || f_excl || f_err) return;
+  if (wid >= hor) return;
+  const uint32_t kind = h.kind;
+  const unsigned long long key = make_key(a.round, idx);
+  const uint32_t tag = (uint32_t)(key >> 32);
+  // (a soft barrier holds back everything AFTER the update that raised it, that update itself may commit)
+  bool fail = (kind == K_EXCL) || key_earlier(gbar, tag, idx) || key_earlier(sbar, tag, idx);
+  uint32_t why = (kind == K_EXCL) ? 0u : (fail ? 1u : 99u);  // diagnostics: first reason (lowest code wins below)
+  if (fail) {
+    // An exclusive update, or one behind this round's barrier: it does not commit now, and neither does anything after it
+    // (the barrier is earlier than all of them), so there is nobody to keep out of its regions and nothing to learn from
+    // its footprint — which, for a climb towards the root, is every leaf of the array (a 3.5 ms walk by one wave, while
+    // the rest of the launch waits).  Its stamps are looked at in the round that does check it.
+    if ((EXTRAS && a.diag) && lane == 0) wv::atomic_add_u64(&c->why[why], 1ull);
+    if (lane == 0 && (EXTRAS && a.diag) && a.dg != nullptr) {
+      uint32_t *r = a.dg + 4ull * idx;
+      r[0] += 1u;
+      r[1] = why;
+      r[2] = (kind == K_EXCL) ? idx : (uint32_t)(key_earlier(gbar, tag, idx) ? gbar : sbar);
+      r[3] = h.wlen;
+    }
+    if (lane == 0) a.status[wid] = 0u;
+    return;
+  }
+#define PMA_WHY(code) do { if ((EXTRAS && a.diag) && (code) < why) why = (code); } while (0)
+#define PMA_WHYB(code, bkey) do { if ((EXTRAS && a.diag) && (code) < why) { why = (code); blk = (uint32_t)(bkey); } } while (0)
+  uint32_t blk = kMax;
+  bool stamp_bad = false;
+  const uint32_t me1 = idx + 1u;  // stamps hold (index + 1) of the latest committed toucher
+  const bool writes = kind_writes(kind);
+  const bool strong = kind_strong(kind);
+  if (kind == K_DUP) {
+    const uint32_t leaf = h.wleaf_lo;
+    if (key_earlier(a.v.wres[leaf], tag, idx)) { fail = true; PMA_WHY(2u); }  // an earlier pending update moves slots of this leaf
+    if (a.v.dres[leaf] != key) { fail = true; PMA_WHY(2u); }                   // an earlier pending duplicate on this leaf
+  }
+  if (strong) {
+    const uint32_t wl = h.wleaf_lo, wh = h.wleaf_hi;
+    // (a big window spans thousands of leaves: four leaves per lane are requested together, 20 loads per trip)
+    for (uint32_t base = wl; base <= wh; base += 256u) {
+      unsigned long long kw[4], kd[4], kr[4];
+      uint32_t sw[4], sr[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t leaf = base + (uint32_t)q * 64u + (uint32_t)lane;
+        const bool in = leaf <= wh && leaf >= base;
+        kw[q] = in ? a.v.wres[leaf] : key;
+        kd[q] = in ? a.v.dres[leaf] : ~0ull;
+        kr[q] = in ? a.v.rres[leaf] : ~0ull;
+        sw[q] = in ? a.wstamp[leaf] : 0u;
+        sr[q] = in ? a.rstamp[leaf] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t leaf = base + (uint32_t)q * 64u + (uint32_t)lane;
+        if (kw[q] != key) { fail = true; PMA_WHYB(3u, kw[q]); }                   // an earlier pending update writes it
+        if (key_earlier(kd[q], tag, idx)) { fail = true; PMA_WHYB(2u, kd[q]); }   // an earlier pending duplicate overwrites a slot here
+        if (key_earlier(kr[q], tag, idx)) { fail = true; PMA_WHYB(4u, kr[q]); }   // an earlier pending update reads it
+        if (sw[q] > me1 || sr[q] > me1) {  // a LATER update already touched it
+          stamp_bad = true;
+          a.vdbg[4 * wid + 0] = leaf;
+          a.vdbg[4 * wid + 1] = sw[q] > me1 ? sw[q] : sr[q];
+          a.vdbg[4 * wid + 2] = sw[q] > me1 ? 1u : 2u;
+        }
+      }
+      if (wh - base < 256u) break;  // (no wrap-around at the top of the leaf range)
+    }
+  }
+  PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, {
+    if (key_earlier(a.v.wres[leaf], tag, idx)) { fail = true; PMA_WHYB(5u, a.v.wres[leaf]); }  // an earlier pending update writes what we read
+    if (a.wstamp[leaf] > me1) {                               // a LATER update already wrote what we read
+      stamp_bad = true;
+      a.vdbg[4 * wid + 0] = leaf;
+      a.vdbg[4 * wid + 1] = a.wstamp[leaf];
+      a.vdbg[4 * wid + 2] = 3u;
+    }
+  });
+  if (kind_real(kind)) {
+    const uint32_t src = a.ops[idx].src;
+    if (src < a.v.g.n && lane < 2 && ((h.sdep >> lane) & 1u) && src + (uint32_t)lane < a.v.g.n) {  // lane 0: sentinel src, lane 1: sentinel src+1
+      const uint32_t u = src + (uint32_t)lane;
+      if (key_earlier(a.v.vw[u], tag, idx)) { fail = true; PMA_WHYB(6u, a.v.vw[u]); }  // an earlier pending update moves a sentinel we located by
+      if (a.vws[u] > me1) {                                // a LATER update already moved it
+        stamp_bad = true;
+        a.vdbg[4 * wid + 0] = u;
+        a.vdbg[4 * wid + 1] = a.vws[u];
+        a.vdbg[4 * wid + 2] = 4u;
+      }
+    }
+    if (strong) {
+      const uint32_t ml = h.mv_lo, mh = h.mv_hi;
+      for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) {
+        if (key_earlier(a.v.vr[u], tag, idx)) { fail = true; PMA_WHYB(7u, a.v.vr[u]); }  // an earlier pending update still needs the old position
+        if (a.vrs[u] > me1 || a.vws[u] > me1) {              // a LATER update already used / moved it
+          stamp_bad = true;
+          a.vdbg[4 * wid + 0] = (uint32_t)u;
+          a.vdbg[4 * wid + 1] = a.vrs[u] > me1 ? a.vrs[u] : a.vws[u];
+          a.vdbg[4 * wid + 2] = 5u;
+        }
+      }
+    }
+  }
+  const bool anyfail = wv::ballot(fail) != 0;
+  const bool anybad = wv::ballot(stamp_bad) != 0;
+  if ((EXTRAS && a.diag) && anyfail) {
+    uint32_t w = why, wb = blk;
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t y = wv::shfl(w, lane ^ o), yb = wv::shfl(wb, lane ^ o);
+      if (y < w || (y == w && yb < wb)) {
+        w = y;
+        wb = yb;
+      }
+    }
+    if (lane == 0 && w < 12u) wv::atomic_add_u64(&c->why[w], 1ull);
+    if (lane == 0 && a.dg != nullptr) {
+      uint32_t *r = a.dg + 4ull * idx;
+      r[0] += 1u;
+      r[1] = w;
+      r[2] = wb;
+      r[3] = h.wlen;
+    }
+  }
+  if (anyfail && kind_real(kind)) {
+    // a deferred update keeps later updates out of its region(s); its footprint may still creep over a region edge
+    // by a slide, so the mark is padded by kRegionPadLeaves leaves on both sides
+    const uint32_t nleaves = (uint32_t)(a.v.g.N >> a.v.g.sh);
+    uint32_t ll = writes ? h.wleaf_lo : (h.index >> a.v.g.sh), lh = writes ? h.wleaf_hi : ll;
+    ll = (ll > kRegionPadLeaves) ? ll - kRegionPadLeaves : 0u;
+    lh = (lh + kRegionPadLeaves < nleaves) ? lh + kRegionPadLeaves : nleaves - 1u;
+    const uint32_t pglo = ll >> a.regshift, pghi = lh >> a.regshift;
+    for (uint32_t g = pglo + (uint32_t)lane; g <= pghi; g += 64) wv::atomic_min_u64(&a.regfail[g], key);
+    // leaf-level mark for later READERS: the deferred update's window can still grow to an ancestor block; cover
+    // the aligned block of 4x its tentative window (at least kGrowLeaves leaves) plus the slide pad
+    uint32_t wleaves = writes && h.wlen ? (h.wlen >> a.v.g.sh) : 1u;
+    if (wleaves < 1u) wleaves = 1u;
+    uint32_t blk = wleaves * 4u;
+    if (blk < kGrowLeaves) blk = kGrowLeaves;
+    const uint32_t anchor = writes && h.wlen ? (h.wstart >> a.v.g.sh) : (h.index >> a.v.g.sh);
+    uint32_t bl = anchor & ~(blk - 1u), bh = bl + blk - 1u;
+    if (ll < bl) bl = ll;
+    if (lh > bh) bh = lh;
+    if (bh >= nleaves) bh = nleaves - 1u;
+    for (uint32_t leaf = bl + (uint32_t)lane; leaf <= bh; leaf += 64) wv::atomic_min_u64(&a.pfail[leaf], key);
+  }
+  if (lane == 0) a.status[wid] = (anyfail ? 0u : OS_PASS) | (anybad ? OS_STAMP_BAD : 0u);
+}
+
+PMA_KERNEL void o_check(OptArgs a) { o_check_t<false>(a); }
+PMA_KERNEL void o_check_x(OptArgs a) { o_check_t<true>(a); }
+
+// EXTRAS = false: the opt-in experiments (chains, zones) and the diagnostics are compiled out — carried along as run-time
+// branches they cost the calm stream 4 % (config #2: 179 vs 187 M updates/s); the engine launches the *_x kernels when one is on
+template <bool EXTRAS>
+PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  const uint32_t wid = wv::uni(wv::block_idx() * 4u + (uint32_t)wv::wave_in_block());
+  const int lane = wv::lane();
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  const uint32_t hor = c->hor[par];
+  const uint32_t st = wv::uni(a.status[wid]);
+  const uint32_t idx = wv::uni(a.opidx[wid]);
+  const Plan *pl = &a.plans[wid];
+  const PlanHead h = dev::load_plan_head(pl);
+  // the update itself: requested as soon as its index is known (unconditionally — slot 0 for waves beyond the horizon), so
+  // that it travels while the region checks below wait for their own loads instead of after them
+  Op op = a.ops[(wid < hor) ? idx : 0u];
+  op.src = wv::uni(op.src);
+  op.dst = wv::uni(op.dst);
+  op.op = wv::uni(op.op);
+  if (f_done || f_viol || f_excl || f_err) return;
+  if (wid >= hor) return;
+  if (!(st & OS_PASS)) return;
+  const uint32_t kind = h.kind;
+  const unsigned long long key = make_key(a.round, idx);
+  const uint32_t tag = (uint32_t)(key >> 32);
+  const bool writes = kind_writes(kind);
+  if (kind_real(kind)) {
+    uint32_t glo, ghi;
+    if (writes) {
+      glo = h.wleaf_lo >> a.regshift;
+      ghi = h.wleaf_hi >> a.regshift;
+    } else {
+      glo = ghi = (h.index >> a.v.g.sh) >> a.regshift;
+    }
+    bool blocked = false, blocked_r = false;
+    uint32_t rblk = kMax;
+    for (uint32_t g = glo + (uint32_t)lane; g <= ghi; g += 64)
+      if (key_earlier(a.regfail[g], tag, idx)) {
+        blocked_r = true;
+        rblk = (uint32_t)a.regfail[g];
+      }
+    // ... nor may we have READ a leaf an earlier deferred update may still grow over
+    PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, { if (key_earlier(a.pfail[leaf], tag, idx)) blocked = true; });
+    // ... nor located our range by a sentinel inside the block a deferred earlier update may still grow over
+    if (lane == 0 && (h.sdep & 1u) && key_earlier(a.pfail[h.sleaf_b], tag, idx)) blocked = true;
+    if (lane == 1 && (h.sdep & 2u) && key_earlier(a.pfail[h.sleaf_e], tag, idx)) blocked = true;
+    const bool any_r = wv::ballot(blocked_r) != 0, any_p = wv::ballot(blocked) != 0;
+    if ((EXTRAS && a.diag) && (any_r || any_p) && lane == 0) wv::atomic_add_u64(&c->why[any_r ? 8 : 9], 1ull);
+    if ((EXTRAS && a.diag) && a.dg != nullptr && (any_r || any_p)) {
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t y = wv::shfl(rblk, lane ^ o);
+        rblk = y < rblk ? y : rblk;
+      }
+      if (lane == 0) {
+        uint32_t *r = a.dg + 4ull * idx;
+        r[0] += 1u;
+        r[1] = any_r ? 8u : 9u;
+        r[2] = rblk;
+        r[3] = h.wlen;
+      }
+    }
+    if (any_r || any_p) {  // an earlier update of this region was deferred: keep stream order inside it
+      return;
+    }
+  }
+  if (st & OS_STAMP_BAD) {
+    if ((EXTRAS && a.diag) && lane == 0) wv::atomic_add_u64(&c->why[10], 1ull);
+    if (lane == 0) {
+      const uint32_t prev = wv::atomic_min_u32(&c->viol_idx, idx);
+      wv::atomic_exch_u32(&c->violation, 1u);
+      if (idx < prev) {
+        c->viol_info[0] = kind;
+        c->viol_info[1] = a.vdbg[4 * wid + 0];
+        c->viol_info[2] = a.vdbg[4 * wid + 1];
+        c->viol_info[3] = a.vdbg[4 * wid + 2];
+        c->viol_info[4] = h.wleaf_lo;
+        c->viol_info[5] = h.wleaf_hi;
+        c->viol_info[6] = h.index;
+        c->viol_info[7] = h.nr;
+      }
+    }
+    return;
+  }
+  // a window too large for one wave goes to a workgroup of o_big: take a queue slot BEFORE touching the state (a full queue
+  // leaves the update pending for the next round)
+  dev::BigJob *job = nullptr;
+  if (kind_strong(kind) && h.wlen > a.big_min && a.jobs) {
+    uint32_t slot = 0;
+    if (lane == 0) slot = wv::atomic_add_u32(&c->njobs[par], 1u);
+    slot = wv::first(slot);
+    if (slot >= kBigJobs) return;
+    job = &a.jobs[slot];
+    if (lane == 0) c->jobs_round[par] = a.round;
+  }
+#if defined(PPCSR_SIM)
+  if (lane == 0 && getenv("PPCSR_TRACE"))
+    fprintf(stderr, "R%u commit idx=%u op=(%u,%u,%u) kind=%u index=%u gap=%u win=(%u,%u) wleaf=[%u,%u] nr=%u\n", a.round, idx, op.src,
+            op.dst, op.op, kind, h.index, h.gap, h.wstart, h.wlen, h.wleaf_lo, h.wleaf_hi, h.nr);
+#endif
+  dev::apply_op(a.v, op, h, lds_wave, &a.stats[wv::block_idx() & (kStatShards - 1)], job);
+  const uint32_t me1 = idx + 1u;
+  if (kind_strong(kind)) {  // (a duplicate's value overwrite commutes with everything it can be reordered with: no stamp)
+    const uint32_t wl = h.wleaf_lo, wh = h.wleaf_hi;
+    for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_max_u32(&a.wstamp[leaf], me1);
+  }
+  PMA_FOR_EACH_READ_LEAF_H(h, pl, lane, leaf, wv::atomic_max_u32(&a.rstamp[leaf], me1));
+  if (kind_real(kind) && op.src < a.v.g.n) {
+    if (lane < 2 && ((h.sdep >> lane) & 1u) && op.src + (uint32_t)lane < a.v.g.n) wv::atomic_max_u32(&a.vrs[op.src + (uint32_t)lane], me1);
+    if (kind_strong(kind)) {
+      const uint32_t ml = h.mv_lo, mh = h.mv_hi;
+      for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_max_u32(&a.vws[u], me1);
+    }
+  }
+  if (lane == 0) a.status[wid] = OS_COMMITTED;  // (the epoch's max committed index is reduced in o_compact: a
+                                                // per-update atomicMax on one word would serialise the whole round)
+}
+
+
+// stable compaction of the deferred updates into the next carry list + next round's bookkeeping
+// ONE workgroup; everything it needs is requested in one batch of independent loads (control block, then each thread's
+// run of statuses and indices), because at ~6 K entries this step is nothing but load latency.
+// kC: 64-slot chunks per wave held in registers (covers a horizon of kC * blockDim).  wsum: 16 words of LDS, s_first_p: 1.
+template <uint32_t kC>
+PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p) {
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  const uint32_t hor = c->hor[par], cn = c->carry_n[par], nf = c->next_fresh[par];
+  const uint32_t cur_h = c->cur_horizon, max_h = c->max_horizon, wcap = c->width_cap, adaptive = c->adaptive, e1 = c->e1;
+  const unsigned long long gb = c->gbar[par];
+  const unsigned long long n_rounds = c->rounds, n_committed = c->committed, n_planned = c->planned;
+  if (f_done || f_viol || f_excl || f_err) return;
+  const uint32_t used = cn < hor ? cn : hor;
+  const uint32_t *cin = par ? a.carry1 : a.carry0;
+  uint32_t *cout = par ? a.carry0 : a.carry1;
+  const uint32_t tid = wv::thread_idx(), bd = wv::block_dim();
+  const int lane = wv::lane(), w = wv::wave_in_block();
+  const uint32_t nw = bd >> 6;
+  // Every wave owns a run of consecutive 64-slot chunks (lane l of chunk c: slot wbase + 64 c + l, so every load and every
+  // store is coalesced — with a run of consecutive slots per THREAD the 2 x kC loads of a wave touched 64 lines each, and
+  // at 18 K entries one CU's address path made this 15 us); a ballot per chunk counts and ranks, the waves' totals go
+  // through LDS.
+  const uint32_t cpw = (hor + nw * 64u - 1u) / (nw * 64u);  // chunks per wave
+  const uint32_t wbase = (uint32_t)w * cpw * 64u;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  uint32_t wkeep = 0, mymaxc = 0;
+  uint32_t st[kC], oi[kC];
+  const bool regs = cpw <= kC;
+  if (regs) {
+#pragma unroll
+    for (uint32_t q = 0; q < kC; q++) {
+      const uint32_t sl = wbase + q * 64u + (uint32_t)lane;
+      const bool in = q < cpw && sl < hor;
+      st[q] = in ? a.status[sl] : OS_COMMITTED;
+      oi[q] = in ? a.opidx[sl] : 0u;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kC; q++) {
+      if (q >= cpw) break;  // (wave-uniform)
+      const bool in = wbase + q * 64u + (uint32_t)lane < hor;
+      wkeep += (uint32_t)wv::popc64(wv::ballot(in && !(st[q] & OS_COMMITTED)));
+      if (in && (st[q] & OS_COMMITTED) && oi[q] + 1u > mymaxc) mymaxc = oi[q] + 1u;
+    }
+  } else {
+    for (uint32_t q = 0; q < cpw; q++) {
+      const uint32_t sl = wbase + q * 64u + (uint32_t)lane;
+      const bool in = sl < hor;
+      const uint32_t s1 = in ? a.status[sl] : OS_COMMITTED, x = in ? a.opidx[sl] : 0u;
+      wkeep += (uint32_t)wv::popc64(wv::ballot(in && !(s1 & OS_COMMITTED)));
+      if (in && (s1 & OS_COMMITTED) && x + 1u > mymaxc) mymaxc = x + 1u;
+    }
+  }
+  if (lane == 0) wsum[w] = wkeep;
+  if (tid == 0) *s_first_p = kMax;
+  wv::block_sync();
+  uint32_t woff = 0, tot = 0;
+  for (uint32_t q = 0; q < nw; q++) {
+    if (q < (uint32_t)w) woff += wsum[q];
+    tot += wsum[q];
+  }
+  uint32_t o = woff;
+  if (regs) {
+#pragma unroll
+    for (uint32_t q = 0; q < kC; q++) {
+      if (q >= cpw) break;
+      const bool keep = wbase + q * 64u + (uint32_t)lane < hor && !(st[q] & OS_COMMITTED);
+      const uint64_t m = wv::ballot(keep);
+      if (keep) {
+        const uint32_t pos = o + (uint32_t)wv::popc64(m & lt);
+        if (pos == 0) *s_first_p = oi[q];
+        cout[pos] = oi[q];
+      }
+      o += (uint32_t)wv::popc64(m);
+    }
+  } else {
+    for (uint32_t q = 0; q < cpw; q++) {
+      const uint32_t sl = wbase + q * 64u + (uint32_t)lane;
+      const bool in = sl < hor;
+      const uint32_t s1 = in ? a.status[sl] : OS_COMMITTED, x = in ? a.opidx[sl] : 0u;
+      const bool keep = in && !(s1 & OS_COMMITTED);
+      const uint64_t m = wv::ballot(keep);
+      if (keep) {
+        const uint32_t pos = o + (uint32_t)wv::popc64(m & lt);
+        if (pos == 0) *s_first_p = x;
+        cout[pos] = x;
+      }
+      o += (uint32_t)wv::popc64(m);
+    }
+  }
+  const uint32_t ncommitted = hor - tot;
+  const uint32_t kept = tot;
+  {  // one atomic per wave: a thousand same-address atomics would serialise in L2 for longer than the rest of this kernel
+    uint32_t wmax = mymaxc;
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+      const uint32_t y = wv::shfl(wmax, lane ^ o2);
+      wmax = y > wmax ? y : wmax;
+    }
+    if (lane == 0 && wmax) wv::atomic_max_u32(&c->maxc, wmax);
+  }
+  for (uint32_t i = used + tid; i < cn; i += bd) {  // carry entries beyond the horizon
+    const uint32_t x = cin[i];
+    if (kept + (i - used) == 0) *s_first_p = x;
+    cout[kept + (i - used)] = x;
+  }
+  wv::block_sync();
+  if (tid == 0) {
+    const uint32_t new_cn = kept + (cn - used);
+    const uint32_t new_nf = nf + (hor - used);
+    // adaptive width: dependency chains bound the number of commits per round (a hot vertex whose range sits at its
+    // density bounds yields a few hundred disjoint windows per round however many updates are planned), so planning far
+    // more than can commit only makes every round slower — but a round's time grows far slower than its width (~30 us
+    // + ~2.5 us per 1024 updates), so width is only given up when almost nothing of it commits.  Narrow by 1/4 when less
+    // than 10 % of a full-width round committed, widen by 1/4 when more than 30 % did.
+    // Above one chip-full of waves (`resident`) only whole multiples make sense (a partly filled second pass costs a
+    // full pass of latency), and a multiple is only worth its re-planning when nearly all of the round commits: up at
+    // > 85 %, back down at < 70 % (config #4's partitions at critical density commit 60-70 % of a chip-full: at twice the
+    // width they lost 5 %; configs #2 / #3 commit 93-97 % and gain 11-12 %).
+    uint32_t ch = cur_h ? cur_h : wcap;
+    const uint32_t res = c->resident;
+    if (adaptive && hor >= ch) {  // only full-width rounds carry information about the width
+      if (res && ch >= res) {
+        if (ncommitted * 100u > hor * 85u) ch += res;
+        else if (ch > res && ncommitted * 100u < hor * 70u) ch -= res;
+        else if (ch == res && ncommitted * 100u < hor * 10u) ch -= ch / 4u;
+      } else {
+        if (ncommitted * 100u > hor * 30u) ch += ch / 4u;
+        else if (ncommitted * 100u < hor * 10u) ch -= ch / 4u;
+        if (res && ch > res) ch = res;
+      }
+    }
+    if (res && ch > res) ch -= ch % res;
+    if (ch < 1024u) ch = 1024u;
+    if (ch > wcap) ch = wcap;  // (the launch grid — max_h — bounds the next round below, not the adapted width itself: the
+                               // host narrows the grid at the tail of an epoch)
+    c->cur_horizon = ch;
+    uint32_t nh = new_cn + (e1 - new_nf);
+    if (nh > ch) nh = ch;
+    if (nh > max_h) nh = max_h;
+    c->carry_n[par ^ 1u] = new_cn;
+    c->next_fresh[par ^ 1u] = new_nf;
+    c->hor[par ^ 1u] = nh;
+    c->gbar[par ^ 1u] = ~0ull;
+    c->gbar[par] = ~0ull;
+    c->sbar[par ^ 1u] = ~0ull;
+    c->sbar[par] = ~0ull;
+    c->njobs[par ^ 1u] = 0;
+    c->skip = kMax;
+    const bool done = (new_cn == 0 && new_nf == e1);
+    if (done) c->done = 1;
+    const uint32_t lowest = new_cn ? *s_first_p : new_nf;
+    const uint32_t tag = (uint32_t)(make_key(a.round, 0) >> 32);
+    c->resume_par = par ^ 1u;
+    if (!done && (uint32_t)(gb >> 32) == tag && (uint32_t)gb == lowest) {
+      c->excl = 1;
+      c->excl_idx = lowest;
+    }
+    if (n_rounds < 96) {
+      c->hist[2 * n_rounds] = hor;
+      c->hist[2 * n_rounds + 1] = ncommitted;
+    }
+    c->rounds = n_rounds + 1ull;
+    c->committed = n_committed + (unsigned long long)ncommitted;
+    c->planned = n_planned + (unsigned long long)hor;
+  }
+}
+
+// (Forcing 8 waves per SIMD — __launch_bounds__(256, 8) on o_plan / o_apply, a 256-slot LDS tile — for 8192-wide rounds was
+// measured again in round 2: 56 / 44 B of scratch per lane and 113-123 M updates/s against 141 at 6 waves per SIMD.)
+PMA_KERNEL void o_apply(OptArgs a) {
+  PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
+  o_apply_wave<false>(a, lds[wv::wave_in_block()]);
+}
+PMA_KERNEL void o_apply_x(OptArgs a) {
+  PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
+  o_apply_wave<true>(a, lds[wv::wave_in_block()]);
+}
+
+// (Folding the compaction into o_apply's last-finishing workgroup was measured and dropped: the device-scope fences the
+// ticket needs make every workgroup write back its XCD's L2, and the round got 3x slower than with a separate launch.)
+// markers: empty kernels with distinct names; `set_option("marker", i)` launches k_mark_<i> on the engine's stream so that
+// tools/roofline_summary.py can cut sections (timed region, one isolated rebalance, one scan) out of a rocprofv3 kernel
+// trace / counter collection of bench.py
+#define PMA_MARK(i) PMA_KERNEL void k_mark_##i(uint32_t *p) { if (p && wv::thread_idx() == 0xFFFFFFFFu) *p = i; }
+PMA_MARK(0) PMA_MARK(1) PMA_MARK(2) PMA_MARK(3) PMA_MARK(4) PMA_MARK(5) PMA_MARK(6) PMA_MARK(7)
+#undef PMA_MARK
+
+// test hook: one workgroup rebalances one window with the big-window routine (leaf counts must be exact)
+PMA_KERNEL void k_block_rebalance(View v, uint64_t wstart, uint64_t wlen, Edge *scratch) {
+  PMA_SHARED dev::BigShared sh;
+  dev::redistribute_block(v, wstart, wlen, scratch, sh);
+}
+
+// Workgroup 0: the compaction.  Workgroups 1 .. : the round's queued big-window rebalances, one workgroup per window
+// (dev::redistribute_block) — independent of the compaction (they only finish the rebalance of updates that have already
+// been committed), so they share its launch instead of paying a kernel boundary of their own.
+PMA_KERNEL void o_compact(OptArgs a) {
+  PMA_SHARED uint32_t wsum[16];
+  PMA_SHARED uint32_t s_first;
+  PMA_SHARED dev::BigShared sh;
+  if (wv::block_idx() == 0) {
+    compact_block<24>(a, wsum, &s_first);  // (24 x 1024 threads: rounds up to 24576 wide stay in registers)
+    return;
+  }
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  // (NOT c->done / c->excl: workgroup 0 sets them during this very launch.  A violation rolls the epoch back anyway.)
+  const uint32_t f_viol = c->violation, f_err = c->error;
+  uint32_t nj = c->njobs[par];
+  if (f_viol || f_err || nj == 0 || c->jobs_round[par] != a.round) return;
+  if (nj > kBigJobs) nj = kBigJobs;
+  const uint32_t nwg = wv::grid_dim() - 1u, me = wv::block_idx() - 1u;
+  for (uint32_t jb = me; jb < nj; jb += nwg) {
+    const dev::BigJob job = a.jobs[jb];
+    dev::redistribute_block(a.v, job.wstart, job.wlen, a.bigscratch + (uint64_t)me * a.bigscratch_stride, sh);
+    wv::block_sync();  // the shared prefix / table are reused by the next job
+  }
+}
+
+}  // namespace ppcsr

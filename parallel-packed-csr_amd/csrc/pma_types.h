@@ -65,11 +65,16 @@ enum Kind : uint32_t {
   K_NOTFOUND = 4,  // delete of a missing edge: only num_neighbors-- (PCSR.cpp:747-754)
   K_EXCL = 5,      // must run alone through the exclusive executor (global path, resize, big window)
   K_SKIP = 6,      // already executed by the exclusive executor inside this epoch: commits as nothing
-  K_FOREIGN = 7,   // (region-local planning only) the update cannot be located from the region's own slots
 };
 
 constexpr int kMaxR = 72;  // read-leaf ranges recorded per op (search certificate + one or two per level of the density climb + a few)
 
+// Layout: the 16-word header and the first 8 read ranges fill the record's first 128 bytes, which is all the round kernels touch
+// for almost every update (two or three ranges: the search certificate and the leaves of a short climb) — one wave-wide store
+// in o_plan, one wave-wide load in o_check / o_apply (lane i <-> word i; the fields are then read off the lanes as scalars).
+struct PlanRange {
+  uint32_t lo, hi;  // inclusive leaf range
+};
 struct Plan {
   uint32_t kind;
   uint32_t index;             // slot returned by the gap-aware search
@@ -85,8 +90,12 @@ struct Plan {
   uint32_t nr;
   uint32_t nlong;  // number of read ranges spanning >= kLongRange leaves (0 for almost every update)
   uint32_t sdep;   // bit 0 / 1: the search result depends on the position of sentinel src / src + 1 (pma_search)
-  uint32_t rlo[kMaxR], rhi[kMaxR];  // inclusive leaf ranges read by the search / vertex range lookup
+  PlanRange r[kMaxR];  // leaf ranges read by the search / the density climb
 };
+// word index of a header field inside the record (lane <-> word in the wave-wide accesses)
+enum PlanWord : int { PW_KIND = 0, PW_INDEX, PW_GAP, PW_WSTART, PW_WLEN, PW_WLEAF_LO, PW_WLEAF_HI, PW_MV_LO, PW_MV_HI, PW_SLEAF_B, PW_SLEAF_E,
+                      PW_ALG_CALLS, PW_ALG_SLOTS, PW_NR, PW_NLONG, PW_SDEP, PW_HEADER_WORDS };
+static_assert(sizeof(Plan) == 640 && PW_HEADER_WORDS == 16, "plan record layout");
 
 // scheduler control block (device memory, mirrored to pinned host memory between round chunks)
 struct Control {

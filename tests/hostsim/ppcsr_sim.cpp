@@ -6,6 +6,9 @@
 #include "engine.cc"
 #include "capi.cc"
 
+// test hook (emulator build only): every wv::uni / wv::bcast call verifies that its value / source lane really is wave-uniform
+extern "C" void ppcsr_sim_check_uniform(int on) { sim::check_uniform = on != 0; }
+
 // test hook (emulator build only): the exact position table evaluated for every element of a window, so the table
 // construction and its look-ups can be checked against the oracle's serial fp64 chain without running an engine
 extern "C" int ppcsr_sim_chain_positions(uint64_t index, uint64_t len, uint64_t j, uint64_t *out, int *nseg, int *linear_ok) {

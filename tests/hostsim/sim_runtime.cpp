@@ -106,6 +106,30 @@ uint64_t shfl64(uint64_t v, int src) {
   src &= 63;
   return w.present[par][src] ? w.in[par][src] : 0;  // inactive source lane: undefined on HW, 0 here
 }
+uint64_t first64(uint64_t v) {
+  int par = arrive(OP_SHFL, v, false);
+  Wave &w = waves[cur->tid >> 6];
+  for (int l = 0; l < 64; l++)
+    if (w.present[par][l]) return w.in[par][l];
+  return v;
+}
+uint64_t uniform64(uint64_t v) {
+  int par = arrive(OP_SHFL, v, false);
+  Wave &w = waves[cur->tid >> 6];
+  for (int l = 0; l < 64; l++)
+    if (w.present[par][l] && w.in[par][l] != v) {
+      fprintf(stderr, "sim: a value declared wave-uniform differs between lanes (%d: %llu, %d: %llu)\n", cur->tid & 63, (unsigned long long)v, l,
+              (unsigned long long)w.in[par][l]);
+      abort();
+    }
+  return v;
+}
+void gather64(uint64_t v, uint64_t *all64) {
+  int par = arrive(OP_SHFL, v, false);
+  Wave &w = waves[cur->tid >> 6];
+  for (int l = 0; l < 64; l++) all64[l] = w.present[par][l] ? w.in[par][l] : 0;
+}
+bool check_uniform = false;
 uint64_t reduce_add64(uint64_t v) {
   int par = arrive(OP_SUM, v, false);
   return waves[cur->tid >> 6].result[par];

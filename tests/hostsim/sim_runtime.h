@@ -12,7 +12,6 @@
 #include <functional>
 
 #define PMA_DEV inline
-#define PMA_DEV_CALL inline
 #define PMA_KERNEL
 #define PMA_LAUNCH_BOUNDS(threads, waves_per_simd)
 #define PMA_SHARED static
@@ -30,6 +29,10 @@ int cur_grid_dim();
 uint64_t ballot(bool p);
 uint64_t shfl64(uint64_t v, int src);
 uint64_t reduce_add64(uint64_t v);
+uint64_t first64(uint64_t v);    // value of the first live lane
+uint64_t uniform64(uint64_t v);  // aborts unless every live lane passes the same value
+void gather64(uint64_t v, uint64_t *all64);  // every lane's value (0 for lanes that are not live)
+extern bool check_uniform;
 void block_sync();
 void launch(uint32_t grid, uint32_t block, const std::function<void()> &body);
 }  // namespace sim
@@ -47,7 +50,20 @@ inline float shfl_f32(float v, int src) {
   memcpy(&v, &b, 4);
   return v;
 }
-inline uint32_t first(uint32_t v) { return v; }  // callers only pass wave-uniform values
+inline uint32_t first(uint32_t v) { return (uint32_t)sim::first64(v); }  // (the first LIVE lane's value)
+// uni / bcast: the caller claims the value (the source lane) is the same in every live lane of the wave — checked here
+inline uint32_t uni(uint32_t v) { return (uint32_t)sim::uniform64(v); }
+inline int uni(int v) { return (int)(uint32_t)sim::uniform64((uint32_t)v); }
+inline bool uni(bool b) { return sim::uniform64(b ? 1u : 0u) != 0; }
+inline uint64_t uni(uint64_t v) { return sim::uniform64(v); }
+template <int K>
+inline uint32_t setlane(uint32_t v, uint32_t x) { return lane() == K ? x : v; }
+inline void lanes16(uint32_t v, uint32_t *out) {
+  uint64_t all[64];
+  sim::gather64(v, all);
+  for (int i = 0; i < 16; i++) out[i] = (uint32_t)all[i];
+}
+inline uint32_t bcast(uint32_t v, int src) { return (uint32_t)sim::shfl64(v, (int)(uint32_t)sim::uniform64((uint32_t)src)); }
 inline uint32_t reduce_add(uint32_t v) { return (uint32_t)sim::reduce_add64(v); }
 inline void fence() { (void)sim::shfl64(0, 0); }  // lanes run sequentially between collectives: a fence must be a rendezvous
 inline void lds_fence() { (void)sim::shfl64(0, 0); }
@@ -61,14 +77,8 @@ inline uint32_t atomic_max_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; if (v
 inline unsigned long long atomic_max_u64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 inline uint32_t atomic_exch_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = v; return o; }
 inline uint32_t atomic_cas_u32(uint32_t *p, uint32_t expect, uint32_t v) { uint32_t o = *p; if (o == expect) *p = v; return o; }
-template <class T>
-inline T *opaque_ptr(T *p) { return p; }
 inline void wait_loads() {}
-inline void fence_heavy() { (void)sim::shfl64(0, 0); }
-inline void fence_mode(uint32_t) { (void)sim::shfl64(0, 0); }
 inline void flag_publish(uint32_t *p, uint32_t v) { *p = v; }
-inline void store_agent_u32(uint32_t *p, uint32_t v) { *p = v; }
-inline uint32_t load_agent_u32(const uint32_t *p) { return *(const volatile uint32_t *)p; }
 inline uint32_t flag_read(const uint32_t *p) { return *(const volatile uint32_t *)p; }
 inline void flag_acquire() {}
 inline uint32_t xcc_id() { return (uint32_t)sim::cur_block() & 7u; }

@@ -24,9 +24,6 @@ MODES = {
     "speculative": dict(mode=1, small_batch=0),  # (small_batch=0: even tiny batches go through the speculative rounds)
     "speculative-small": dict(mode=1, opt_horizon=1024, epoch_ops=4096, region_slots=256, small_batch=0),
     "default": dict(),  # engine defaults: speculative rounds, batches of <= 256 updates through the strict rounds
-    # round 3: in-round chains forced on (a region's waiting updates executed by one wave from an LDS copy of the region) and
-    # soft barriers with an extent (zones); both are off by default
-    "chains+zones": dict(mode=1, small_batch=0, chain=2, chain_steps=16, zone_factor=8, epoch_ops=8192),
 }
 
 
@@ -115,37 +112,7 @@ def test_random_mixed_vs_oracle(mk, streams, seed, n, lock):
     _stats_match(eng, o)
 
 
-@pytest.mark.parametrize("steps", [2, 16, 64])
-def test_chains_hot_vertices_and_rmat_load(pkg, streams, steps):
-    """in-round chains (option chain=2): hub streams whose updates pile up on a few regions, and an RMAT load from an empty
-    graph (doublings, rollbacks); num_neighbors is compared too — it is the one word only atomics touch, and the one a
-    miscompiled o_chain got wrong while edges[] stayed right"""
-    for n, K, hubs in [(1000, 3000, 4), (64, 2500, 3), (20000, 30000, 50)]:
-        rng = np.random.default_rng(n + K)
-        src = np.where(rng.random(K) < 0.7, rng.integers(0, hubs, K), rng.integers(0, n, K)).astype(np.uint32)
-        ops = np.stack([src, rng.integers(0, 5000, K).astype(np.uint32), (rng.random(K) >= 0.1).astype(np.uint32)], 1).astype(np.uint32)
-        e, o = pkg.PCSR(n), Oracle(n)
-        for k, v in dict(chain=2, chain_steps=steps, small_batch=0).items():
-            e.set_option(k, v)
-        e.apply(ops)
-        o.apply(ops)
-        _same(e, o, f"hub stream n={n} steps={steps}")
-        assert e.stats()["chained"] > 0
-        _stats_match(e, o)
-    s, d = streams.rmat_edges(14, 60000, seed=1)
-    core = streams.adds(s, d)
-    e, o = pkg.PCSR(1 << 14), Oracle(1 << 14)
-    for k, v in dict(chain=2, chain_steps=steps).items():
-        e.set_option(k, v)
-    for lo in range(0, len(core), 20000):
-        e.apply(core[lo:lo + 20000])
-        o.apply(core[lo:lo + 20000])
-        _same(e, o, f"rmat-14 load, chunk {lo}, steps={steps}")
-    assert e.stats()["chained"] > 1000 and e.stats()["rollbacks"] > 0
-
-
-@pytest.mark.parametrize("chain", [0, 2])
-def test_snapshot_restore_incremental(pkg, streams, chain):
+def test_snapshot_restore_incremental(pkg, streams):
     """snapshot() / restore() and the epoch rollback point are kept in step with the live state through dirty tags (only
     what was written since is copied): restore after batches with rollbacks and doublings, then continue"""
     for seed in range(3):
@@ -157,7 +124,7 @@ def test_snapshot_restore_incremental(pkg, streams, chain):
         upd = np.stack([src, rng.integers(0, 100000, m).astype(np.uint32), (rng.random(m) >= 0.1).astype(np.uint32)], 1).astype(np.uint32)
         upd2 = streams.random_stream(n, 1500, seed=seed + 7, p_delete=0.5)
         e, o = pkg.PCSR(n), Oracle(n)
-        for k, v in dict(chain=chain, small_batch=0, epoch_ops=1024, opt_horizon=1024, region_slots=256).items():
+        for k, v in dict(small_batch=0, epoch_ops=1024, opt_horizon=1024, region_slots=256).items():
             e.set_option(k, v)
         e.apply(core)
         o.apply(core)
@@ -779,37 +746,3 @@ def test_large_graph_properties(pkg, streams):
     # (6) the bulk scan agrees with the array
     rows, dests = eng.scan_all()
     assert rows[-1] == len(e) - (1 if (live[-1] and not sent[-1]) else 0)
-
-
-def test_rebalance_gather_variant(pkg, streams):
-    """option rb_gather=1 (destination-centric final pass of the big rebalances, an opt-in variant) leaves exactly the array the
-    default pass leaves: resizes of a growing and shrinking stream against the oracle, and whole / partial windows of a
-    loaded graph against the default pass"""
-    n = 3000
-    a = streams.random_stream(n, 400000, seed=77)
-    d = a.copy()
-    d[:, 2] = 0
-    ops = np.concatenate([a, d[::-1]])
-    e, o = pkg.PCSR(n), Oracle(n)
-    e.set_option("rb_gather", 1)
-    for lo in range(0, len(ops), 100000):
-        e.apply(ops[lo:lo + 100000])
-        o.apply(ops[lo:lo + 100000])
-        _same(e, o, f"after {lo + 100000}")
-    assert e.stats()["double_calls"] >= 3
-    e.close()
-    s_, d_ = streams.rmat_edges(16, 600000, seed=5)
-    g = pkg.PCSR(1 << 16)
-    g.apply(streams.adds(s_, d_))
-    N = g.geometry()[0]
-    states = []
-    for variant in (0, 1, 1):
-        g.set_option("rb_gather", variant)
-        g.set_option("rb_run", 0 if len(states) < 2 else 5)
-        g.set_option("rb_inplace_min", 0)  # partial windows through the scratch stretch: the pass under test
-        for w in (N, N // 2, N // 8):
-            g.bench_rebalance(w, 1)
-        states.append(digest(*g.state(), g.geometry()))
-        assert g.check_invariants() == 0
-    assert len(set(states)) == 1
-    g.close()

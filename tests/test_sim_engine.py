@@ -147,28 +147,6 @@ def test_sim_soft_barrier_with_ignored_adds(sim, soft):
         assert se["exclusive_ops"] == e2.stats()["exclusive_ops"]
 
 
-@pytest.mark.parametrize("seed", [0, 5, 9, 14])
-def test_sim_in_round_chains(sim, seed):
-    """in-round chains (o_chain, option chain=2): hot-vertex mixes with deletes; every chunk bit-exact incl. num_neighbors"""
-    rng = np.random.default_rng(seed)
-    n = int(rng.choice([30, 200, 1000]))
-    m = int(rng.choice([3000, 6000]))
-    src = np.where(rng.random(m) < 0.6, rng.integers(0, min(n, 8), m), rng.integers(0, n, m)).astype(np.uint32)
-    ops = np.stack([src, rng.integers(0, 5000, m).astype(np.uint32), (rng.random(m) >= 0.2).astype(np.uint32)], 1).astype(np.uint32)
-    opts = dict(chain_steps=int(rng.choice([1, 3, 8, 16])), region_slots=int(rng.choice([64, 128, 256])), opt_horizon=int(rng.choice([64, 256])),
-                zone_factor=int(rng.choice([0, 2, 8])), soft_barrier=int(rng.choice([0, 128, 512])), epoch_ops=int(rng.choice([512, 4096])))
-    e = sim(n, True, mode=1, opt_horizon=opts["opt_horizon"], epoch_ops=opts["epoch_ops"], region_slots=opts["region_slots"])
-    for k in ("chain_steps", "zone_factor", "soft_barrier"):
-        e.set_option(k, opts[k])
-    e.set_option("chain", 2)
-    o = Oracle(n)
-    for lo in range(0, m, 2000):
-        e.apply(ops[lo:lo + 2000])
-        o.apply(ops[lo:lo + 2000])
-        _same(e, o, f"seed {seed} {opts} after {lo + 2000}")
-    assert e.stats()["chained"] > 0
-
-
 def test_sim_snapshot_restore_incremental(sim, streams):
     """snapshot() / restore() through dirty tags across batches with rollbacks and doublings (see the GPU test of the same name)"""
     n = 40
@@ -558,22 +536,3 @@ def test_sim_xchg_steps_and_repartition(streams):
             parts[k].apply(sub)
         same(parts, f"updates after {new}")
         old = new
-
-
-@pytest.mark.parametrize("run", [1, 3])
-def test_sim_rebalance_gather_variant(sim, streams, run):
-    """k_rb_gather (option rb_gather=1: destination tiles staged in LDS, runs of `rb_run` tiles per workgroup) on a stream that
-    doubles and halves the array several times: same states as the oracle, like the default source-centric pass"""
-    n = 300
-    e, o = sim(n, big_window=4096), Oracle(n)
-    e.set_option("rb_gather", 1)
-    e.set_option("rb_run", run)
-    a = streams.random_stream(n, 9000, seed=2 + run)
-    d = a.copy()
-    d[:, 2] = 0
-    ops = np.concatenate([a, d[::-1]])
-    for lo in range(0, len(ops), 3000):
-        e.apply(ops[lo:lo + 3000])
-        o.apply(ops[lo:lo + 3000])
-        _same(e, o, f"after {lo + 3000}")
-    assert e.stats()["double_calls"] >= 3

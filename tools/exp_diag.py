@@ -20,7 +20,7 @@ sweeps = {}
 for kv in sys.argv[2:]:
     k, v = kv.split("=")
     sweeps[k] = [int(x) for x in v.split("/")]
-KEYS = ("rounds", "committed", "planned", "exclusive_ops", "rollbacks", "wasted_rounds", "big_redistributes", "round_syncs", "double_calls", "chained")
+KEYS = ("rounds", "committed", "planned", "exclusive_ops", "rollbacks", "wasted_rounds", "big_redistributes", "round_syncs", "double_calls")
 check = os.environ.get("EXP_CHECK", "1") == "1"
 reps = int(os.environ.get("EXP_REPS", "2"))
 
@@ -74,7 +74,7 @@ def run(name, n, core, upd):
             ok = "bit-exact" if g == ref else "MISMATCH"
         ms, d = best
         print(f"{name} {dict(zip(keys, combo))}: {len(upd)} updates {ms:.2f} ms = {len(upd) / ms / 1e3:.2f} M/s rounds {d['rounds']}+{d['wasted_rounds']}w commits/round "
-              f"{d['committed'] / max(d['rounds'], 1):.0f} replan {d['planned'] / max(d['committed'], 1):.2f} chained {d['chained']} excl {d['exclusive_ops']} "
+              f"{d['committed'] / max(d['rounds'], 1):.0f} replan {d['planned'] / max(d['committed'], 1):.2f} excl {d['exclusive_ops']} "
               f"bigrb {d['big_redistributes']} rollbacks {d['rollbacks']} syncs {d['round_syncs']} dbl {d['double_calls']} {ok}", flush=True)
         if prof:
             print(f"     per launch set (us): plan(+sort) {prof[0]:.1f} check {prof[1]:.1f} apply(+chain) {prof[2]:.1f} compact {prof[3]:.1f} over {prof[4]} sets", flush=True)

@@ -53,9 +53,8 @@ for c in range(cases):
         opts.update(resident_waves=int(rng.choice([0, 512, 6144])), big_window=int(rng.choice([2048, 8192, 32768])),
                     soft_barrier=int(rng.choice([0, 1024, 1 << 30])), rb_inplace_min=int(rng.choice([0, 2048, 1 << 19])),
                     epoch_short=int(rng.choice([512, 16384])), epoch_grow_after=int(rng.choice([1, 2, 8])))
-    if rng.integers(0, 3) == 0:  # round-3 knobs: in-round chains, zones, destination-centric rebalance pass, diagnostics on
-        opts.update(chain=int(rng.choice([0, 2])), chain_steps=int(rng.choice([2, 16, 64])), zone_factor=int(rng.choice([0, 2, 8])),
-                    rb_gather=int(rng.integers(0, 2)), rb_run=int(rng.choice([0, 1, 5])), diag=int(rng.choice([0, 0, 1])))
+    if rng.integers(0, 3) == 0:  # diagnostics on (the *_x instantiations of the round kernels)
+        opts.update(diag=int(rng.choice([0, 1])))
     if rng.integers(0, 3) == 0:  # round-3 policies: epoch length / region width that follow the rollback frequency
         opts.update(epoch_adapt=int(rng.choice([0, 2, 8, 32])), region_rare=int(rng.choice([0, 4096, 16384])),
                     region_rare_dist=int(rng.choice([1, 4096, 65536])), region_rare_cpr=int(rng.choice([0, 64, 1536])),
