@@ -196,7 +196,7 @@ Engine::Engine() : p_(new Impl()) {}
 // d_plans is shared by both schedulers: it must hold one record per wave of the widest grid either may launch
 // (+8: the per-wave arrays are padded to the launch grid, whose waves load their record before the early-exit tests)
 static int ensure_plans(Engine::Impl &p) {
-  const uint64_t need = (uint64_t)std::max(p.opt_horizon, p.max_horizon) + 8;
+  const uint64_t need = (uint64_t)std::max(p.opt_horizon, p.max_horizon) + 64;  // (padded to the launch grids: 4 / 64 slots per workgroup)
   if (p.plans_cap >= need) return 0;
   int e = gpu::sync(p.stream);
   if (e) return e;
@@ -1017,7 +1017,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         if (p.profile) p.events[5 * r + 0].record(p.stream);
         if (extras) GPU_LAUNCH(p.stream, o_plan_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_plan, blocks, 256, a);
         if (p.profile) p.events[5 * r + 1].record(p.stream);
-        if (extras) GPU_LAUNCH(p.stream, o_check_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_check, blocks, 256, a);
+        // (o_check: a LANE per update, one wave per workgroup; the diagnostics build keeps a wave per update)
+        if (extras) GPU_LAUNCH(p.stream, o_check_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_check, (gh + kCkThreads - 1) / kCkThreads, kCkThreads, a);
         if (p.profile) p.events[5 * r + 2].record(p.stream);
         if (extras) GPU_LAUNCH(p.stream, o_apply_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
         if (p.profile) p.events[5 * r + 3].record(p.stream);

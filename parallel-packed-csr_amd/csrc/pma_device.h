@@ -920,10 +920,10 @@ struct PlanRegs {
   uint32_t kind, index, wstart, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, nr, nlong, sdep, sleaf_b, sleaf_e;
   uint32_t my_lo, my_hi;  // lane r: read range r (r < 64)
 };
-// the 16 header words of a plan record, lane i holding word i: one wave-wide store (the record's first 64 bytes)
+// the header words of a plan record, lane i holding word i: one wave-wide store (the record's first 80 bytes)
 PMA_DEV void store_plan_header(Plan *plan, uint32_t kind, uint32_t index, uint32_t gap, uint32_t wstart, uint32_t wlen, uint32_t wl, uint32_t wh,
                                uint32_t mv_lo, uint32_t mv_hi, uint32_t sleaf_b, uint32_t sleaf_e, uint32_t acalls, uint32_t aslots, uint32_t nr,
-                               uint32_t nlong, uint32_t sdep) {
+                               uint32_t nlong, uint32_t sdep, uint32_t idx, const Op &op) {
   uint32_t w = 0;
   w = wv::setlane<PW_KIND>(w, kind);
   w = wv::setlane<PW_INDEX>(w, index);
@@ -936,15 +936,18 @@ PMA_DEV void store_plan_header(Plan *plan, uint32_t kind, uint32_t index, uint32
   w = wv::setlane<PW_MV_HI>(w, mv_hi);
   w = wv::setlane<PW_SLEAF_B>(w, sleaf_b);
   w = wv::setlane<PW_SLEAF_E>(w, sleaf_e);
-  w = wv::setlane<PW_ALG_CALLS>(w, acalls);
-  w = wv::setlane<PW_ALG_SLOTS>(w, aslots);
+  w = wv::setlane<PW_ALG>(w, (acalls << 28) | aslots);
   w = wv::setlane<PW_NR>(w, nr);
   w = wv::setlane<PW_NLONG>(w, nlong);
   w = wv::setlane<PW_SDEP>(w, sdep);
+  w = wv::setlane<PW_IDX>(w, idx);
+  w = wv::setlane<PW_SRC>(w, op.src);
+  w = wv::setlane<PW_DST>(w, op.dst);
+  w = wv::setlane<PW_OP>(w, op.op);
   if (wv::lane() < (int)PW_HEADER_WORDS) reinterpret_cast<uint32_t *>(plan)[wv::lane()] = w;
 }
-// op: wave-uniform
-PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
+// op, idx (the update's stream index): wave-uniform
+PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, uint32_t idx) {
   const int lane = wv::lane();
   const Geometry &g = v.g;
   RangeRec rr;
@@ -1176,7 +1179,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
     }
   }
   const uint32_t nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
-  store_plan_header(plan, kind, index, gap, wstart, wlen, wl, wh, mv_lo, mv_hi, sleaf_b, sleaf_e, acalls, aslots, nr, rr.nlong, rr.sdep);
+  store_plan_header(plan, kind, index, gap, wstart, wlen, wl, wh, mv_lo, mv_hi, sleaf_b, sleaf_e, acalls, aslots, nr, rr.nlong, rr.sdep, idx, op);
   PlanRegs pr;
   pr.sdep = rr.sdep;
   pr.kind = kind;
@@ -1197,10 +1200,13 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan) {
 }
 
 // The plan record's header and this lane's read range, requested in ONE batch: lane i loads header word i, lane r < kHeadRanges
-// range r — two wave-wide loads inside the record's first 128 bytes — and the fields are read off the lanes as scalars.
-constexpr int kHeadRanges = 8;
+// range r — two wave-wide loads inside the record's first 128 bytes — and the fields are read off the lanes as scalars.  The
+// update itself is in there too (idx, src, dst, op): o_check / o_apply need neither the op array nor the slot's index list.
+constexpr int kHeadRanges = 6;
 struct PlanHead {
   uint32_t kind, index, gap, wstart, wlen, wleaf_lo, wleaf_hi, mv_lo, mv_hi, sleaf_b, sleaf_e, alg_calls, alg_slots, nr, nlong, sdep;
+  uint32_t idx;  // stream index of the update
+  Op op;         // the update
   uint32_t my_lo, my_hi;  // lane r: read range r (r < kHeadRanges; longer lists are walked from the record)
 };
 PMA_DEV PlanHead load_plan_head(const Plan *pl) {
@@ -1210,7 +1216,7 @@ PMA_DEV PlanHead load_plan_head(const Plan *pl) {
   if (lane < (int)PW_HEADER_WORDS) w = reinterpret_cast<const uint32_t *>(pl)[lane];
   if (lane < kHeadRanges) rg = pl->r[lane];
   uint32_t f[PW_HEADER_WORDS];
-  wv::lanes16(w, f);
+  wv::lanes<PW_HEADER_WORDS>(w, f);
   PlanHead h;
   h.kind = f[PW_KIND];
   h.index = f[PW_INDEX];
@@ -1223,8 +1229,10 @@ PMA_DEV PlanHead load_plan_head(const Plan *pl) {
   h.mv_hi = f[PW_MV_HI];
   h.sleaf_b = f[PW_SLEAF_B];
   h.sleaf_e = f[PW_SLEAF_E];
-  h.alg_calls = f[PW_ALG_CALLS];
-  h.alg_slots = f[PW_ALG_SLOTS];
+  h.alg_calls = f[PW_ALG] >> 28;
+  h.alg_slots = f[PW_ALG] & 0x0FFFFFFFu;
+  h.idx = f[PW_IDX];
+  h.op = Op{f[PW_SRC], f[PW_DST], f[PW_OP]};
   h.nr = f[PW_NR];
   h.nlong = f[PW_NLONG];
   h.sdep = f[PW_SDEP];

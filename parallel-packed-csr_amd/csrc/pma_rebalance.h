@@ -87,6 +87,7 @@ PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint
   PMA_SHARED unsigned long long nr[kIpMaxTiles / 64], nl[kIpMaxTiles / 64];  // bit b: boundary b|b+1 is NOT "R" / NOT "L"
   PMA_SHARED uint32_t hist[kIpMaxTiles + 1];
   PMA_SHARED uint32_t wtot[kIpOrderThreads / 64];
+  PMA_SHARED uint32_t wsmall[kIpOrderThreads / 64][8];
   {
     const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
     uint32_t *sp = reinterpret_cast<uint32_t *>(&stb);
@@ -145,7 +146,37 @@ PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint
       }
     }
     key[r] = d_r > d_l ? d_r : d_l;
-    wv::atomic_add_u32(&hist[key[r]], 1u);  // (the keys of a wave's tiles are mostly distinct: electing leaders per key value was measured slower)
+  }
+  // Counting sort by key.  Almost every tile has a tiny key (a window whose elements barely move: 0 or 1 everywhere), so a
+  // histogram through LDS atomics is thousands of adds to two or three addresses, served one after the other (11 us of the
+  // launch).  Keys below kSmall are counted and ranked with ballots — per wave, combined through a small table — and only
+  // the rare larger keys go through atomics.
+  constexpr uint32_t kSmall = 8;
+  uint32_t wcnt[kSmall];
+#pragma unroll
+  for (uint32_t k = 0; k < kSmall; k++) wcnt[k] = 0;
+#pragma unroll
+  for (uint32_t r = 0; r < kPer; r++) {
+    const bool valid = r * kIpOrderThreads + wv::thread_idx() < ntiles;
+#pragma unroll
+    for (uint32_t k = 0; k < kSmall; k++) wcnt[k] += (uint32_t)wv::popc64(wv::ballot(valid && key[r] == k));
+    if (valid && key[r] >= kSmall) wv::atomic_add_u32(&hist[key[r]], 1u);
+  }
+  if ((uint32_t)lane < kSmall) {
+    uint32_t x = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kSmall; k++) x = ((uint32_t)lane == k) ? wcnt[k] : x;
+    wsmall[w][lane] = x;
+  }
+  wv::block_sync();
+  if (wv::thread_idx() < kSmall) {  // per key: the waves' counts -> exclusive prefix over the waves, total -> hist
+    uint32_t run = 0;
+    for (uint32_t q = 0; q < kIpOrderThreads / 64; q++) {
+      const uint32_t x = wsmall[q][wv::thread_idx()];
+      wsmall[q][wv::thread_idx()] = run;
+      run += x;
+    }
+    hist[wv::thread_idx()] = run;
   }
   wv::block_sync();
   {  // exclusive scan of hist[0 .. ntiles]
@@ -169,10 +200,22 @@ PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint
     }
   }
   wv::block_sync();
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (uint32_t k = 0; k < kSmall; k++) wcnt[k] = 0;  // (now: how many of this wave's tiles with key k have been placed)
 #pragma unroll
   for (uint32_t r = 0; r < kPer; r++) {
     const uint32_t i = r * kIpOrderThreads + wv::thread_idx();
-    if (i < ntiles) order[wv::atomic_add_u32(&hist[key[r]], 1u)] = i;
+    const bool valid = i < ntiles;
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kSmall; k++) {
+      const uint64_t mk = wv::ballot(valid && key[r] == k);
+      if (valid && key[r] == k) pos = hist[k] + wsmall[w][k] + wcnt[k] + (uint32_t)wv::popc64(mk & lt_mask);
+      wcnt[k] += (uint32_t)wv::popc64(mk);
+    }
+    if (valid && key[r] >= kSmall) pos = wv::atomic_add_u32(&hist[key[r]], 1u);
+    if (valid) order[pos] = i;
   }
 }
 
@@ -430,12 +473,13 @@ PMA_KERNEL void k_rb_tilesums(uint32_t *cnt, uint64_t nleaves, uint32_t tile_lea
 }
 // One chunk (64 source slots, already in registers) of the rebalance scatter: rank the live slots, look their exact
 // positions up, store element + trailing nulls, fix sentinels, add the destination leaf counts.
-PMA_DEV void rb_scatter_chunk(const View &v, const Edge &e, uint64_t k0, const ChainTable *stb, uint64_t j, uint64_t wend,
+PMA_DEV void rb_scatter_chunk(const View &v, const Edge &e, uint64_t k0 /* wave-uniform */, const ChainTable *stb, uint64_t j, uint64_t wend,
                               Edge *__restrict__ dst, uint64_t dst_bias, uint32_t *dst_leafcnt, int dst_sh, uint64_t dst_leaf_bias,
                               int lane, uint64_t lt_mask, int *hint, int *hint2, int *hint3) {
   const bool nn = e.value != 0;
   const uint64_t m = wv::ballot(nn);
   if (m == 0) return;
+  k0 = wv::uni(k0);  // (the chunk's first rank: one value per wave, as are the table look-ups that depend on it alone)
   const uint32_t cn = (uint32_t)wv::popc64(m);
   const uint64_t below = m & lt_mask;
   const uint32_t i = (uint32_t)wv::popc64(below);

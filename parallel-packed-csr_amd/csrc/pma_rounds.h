@@ -64,7 +64,7 @@ PMA_KERNEL void k_plan(RoundArgs a) {
   const uint32_t idx = base + wid;
   const Op op = a.ops[idx];
   Plan *pl = &a.plans[wid];
-  const dev::PlanRegs pr = dev::plan_op(a.v, op, pl);
+  const dev::PlanRegs pr = dev::plan_op(a.v, op, pl, idx);
   const uint32_t kind = pr.kind;
   if (kind == K_DUP) {
     if (wv::lane() == 0) wv::atomic_min_u64(&a.v.dres[pr.wleaf_lo], make_key(a.round, idx));
@@ -157,9 +157,8 @@ PMA_KERNEL void k_apply(RoundArgs a) {
   if (wid >= hor) return;
   const uint32_t idx = base + wid;
   if (idx >= limit) return;
-  const Op op = a.ops[idx];
   const dev::PlanHead h = dev::load_plan_head(&a.plans[wid]);
-  dev::apply_op(a.v, op, h, lds[wv::wave_in_block()], &a.stats[wv::block_idx() & (kStatShards - 1)]);
+  dev::apply_op(a.v, h.op, h, lds[wv::wave_in_block()], &a.stats[wv::block_idx() & (kStatShards - 1)]);
 }
 
 // ---- exclusive executor: one wave runs one update alone ---------------------------------------------------

@@ -122,11 +122,11 @@ PMA_DEV void o_plan_t(const OptArgs &a) {
   const int lane = wv::lane();
   if (idx == f_skip) {  // executed by the exclusive executor in the middle of this epoch: nothing left to do, commits at once
     if (lane == 0) a.opidx[wid] = idx;
-    dev::store_plan_header(pl, K_SKIP, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0);
+    dev::store_plan_header(pl, K_SKIP, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, idx, op);
     return;
   }
   // the plan record goes to memory for o_check / o_apply; this kernel reserves straight from the registers
-  const dev::PlanRegs pr = dev::plan_op(a.v, op, pl);
+  const dev::PlanRegs pr = dev::plan_op(a.v, op, pl, idx);
   if (lane == 0) a.opidx[wid] = idx;
   const unsigned long long key = make_key(a.round, idx);
   const uint32_t kind = pr.kind;
@@ -165,20 +165,14 @@ PMA_DEV void o_plan_t(const OptArgs &a) {
 PMA_KERNEL void o_plan(OptArgs a) { o_plan_t<false>(a); }
 PMA_KERNEL void o_plan_x(OptArgs a) { o_plan_t<true>(a); }
 
+// One update checked by one wave: `wid` its horizon slot, `h` its plan header (scalars; h.my_lo / my_hi: lane r holds read range
+// r), gbar / sbar this round's barriers.  The body of the wave-per-update kernel (o_check_x, the diagnostics build) and the slow
+// path of the lane-per-update kernel (o_check) for updates with long footprints.
 template <bool EXTRAS>
-PMA_DEV void o_check_t(const OptArgs &a) {
-  OptCtl *c = a.ctl;
-  const uint32_t par = a.round & 1u;
-  const uint32_t wid = wv::uni(wv::block_idx() * 4u + (uint32_t)wv::wave_in_block());
+PMA_DEV void o_check_one(const OptArgs &a, OptCtl *c, uint32_t par, uint32_t wid, const PlanHead &h, const Plan *pl, unsigned long long gbar,
+                         unsigned long long sbar) {
   const int lane = wv::lane();
-  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
-  const uint32_t hor = c->hor[par];
-  const unsigned long long gbar = c->gbar[par], sbar = c->sbar[par];
-  const uint32_t idx = wv::uni(a.opidx[wid]);
-  const Plan *pl = &a.plans[wid];
-  const PlanHead h = dev::load_plan_head(pl);
-  if (f_done || f_viol || f_excl || f_err) return;
-  if (wid >= hor) return;
+  const uint32_t idx = h.idx;
   const uint32_t kind = h.kind;
   const unsigned long long key = make_key(a.round, idx);
   const uint32_t tag = (uint32_t)(key >> 32);
@@ -255,7 +249,7 @@ PMA_DEV void o_check_t(const OptArgs &a) {
     }
   });
   if (kind_real(kind)) {
-    const uint32_t src = a.ops[idx].src;
+    const uint32_t src = h.op.src;
     if (src < a.v.g.n && lane < 2 && ((h.sdep >> lane) & 1u) && src + (uint32_t)lane < a.v.g.n) {  // lane 0: sentinel src, lane 1: sentinel src+1
       const uint32_t u = src + (uint32_t)lane;
       if (key_earlier(a.v.vw[u], tag, idx)) { fail = true; PMA_WHYB(6u, a.v.vw[u]); }  // an earlier pending update moves a sentinel we located by
@@ -323,9 +317,272 @@ PMA_DEV void o_check_t(const OptArgs &a) {
   }
   if (lane == 0) a.status[wid] = (anyfail ? 0u : OS_PASS) | (anybad ? OS_STAMP_BAD : 0u);
 }
+#undef PMA_WHY
+#undef PMA_WHYB
 
-PMA_KERNEL void o_check(OptArgs a) { o_check_t<false>(a); }
-PMA_KERNEL void o_check_x(OptArgs a) { o_check_t<true>(a); }
+// wave per update (the diagnostics build: every reason counted, the blocker traced)
+PMA_KERNEL void o_check_x(OptArgs a) {
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  const uint32_t wid = wv::uni(wv::block_idx() * 4u + (uint32_t)wv::wave_in_block());
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  const uint32_t hor = c->hor[par];
+  const unsigned long long gbar = c->gbar[par], sbar = c->sbar[par];
+  const Plan *pl = &a.plans[wid];
+  const PlanHead h = dev::load_plan_head(pl);
+  if (f_done || f_viol || f_excl || f_err) return;
+  if (wid >= hor) return;
+  o_check_one<true>(a, c, par, wid, h, pl, gbar, sbar);
+}
+
+// LANE per update (the default).  Checking an update is a dozen independent loads and compares — reservation keys and stamps of
+// the one or two leaves it writes, of the two or three it reads, of the sentinels around them — and, for the few that fail,
+// a handful of atomics that mark their region.  A wave per update spent ~370 instructions on that, most of them scalar
+// bookkeeping, and the scalar unit's issue rate (one instruction per SIMD every four cycles, shared by all its waves) was
+// what the kernel's time followed; 64 updates per wave share one instruction stream.  Lanes diverge only in trip counts, and
+// those are capped: an update with a long footprint (a big window, many read ranges, a wide growth mark) is left to the wave —
+// after the lanes' own pass the wave takes such updates one by one through o_check_one, fields broadcast from the owning lane.
+// What a lane checks itself has a FIXED shape — at most kCkWrite write leaves, kCkRanges read ranges of at most two leaves,
+// kCkMoved moved sentinels: every load is issued unconditionally (index 0 where the update has nothing there, the result
+// masked), all of them before the first compare, so the whole check is one round trip instead of one per loop.
+// One wave per workgroup: a lane's loads all go to lines of its own, so a wave-wide load is 64 requests to the CU's address unit —
+// 256 updates per workgroup put a whole round on 72 of the 256 CUs and the kernel took twice the time.
+constexpr uint32_t kCkThreads = 64;
+constexpr uint32_t kCkWrite = 2;   // write leaves
+constexpr int kCkRanges = 4;       // read ranges, each of one or two leaves
+constexpr uint32_t kCkMoved = 4;   // sentinels moved: checked with everything else ...
+constexpr uint32_t kCkMovedMax = 68;  // ... and up to this many in further trips of 8 (a leaf of isolated vertices is all sentinels)
+constexpr uint32_t kCkMark = 32;   // leaves of the growth mark (pfail) a failing lane writes itself
+PMA_KERNEL void o_check(OptArgs a) {
+  OptCtl *c = a.ctl;
+  const uint32_t par = a.round & 1u;
+  const int lane = wv::lane();
+  const uint32_t slot = wv::block_idx() * kCkThreads + wv::thread_idx();  // this LANE's horizon slot
+  const uint32_t wave_slot0 = wv::uni(slot - (uint32_t)lane);
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  const uint32_t hor = c->hor[par];
+  const unsigned long long gbar = c->gbar[par], sbar = c->sbar[par];
+  // my record's first 112 bytes: header (20 words) + read ranges 0 .. 3 — requested WITH the control words, before the early exits
+  // (the record array is padded to the launch grid)
+  const uint4 *rec = reinterpret_cast<const uint4 *>(&a.plans[slot]);
+  const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+  if (f_done || f_viol || f_excl || f_err) return;
+  if (wave_slot0 >= hor) return;
+  const bool active = slot < hor;
+  const uint32_t kind = active ? q0.x : (uint32_t)K_SKIP, index = q0.y, wstart = q0.w, wlen = q1.x, wl = q1.y, wh = q1.z, mv_lo = q1.w, mv_hi = q2.x,
+                 nr = q3.x, nlong = q3.y, sdep = q3.z, idx = q3.w, src = q4.x;
+  const uint32_t rlo[kCkRanges] = {q5.x, q5.z, q6.x, q6.z}, rhi[kCkRanges] = {q5.y, q5.w, q6.y, q6.w};
+  const unsigned long long key = make_key(a.round, idx);
+  const uint32_t tag = (uint32_t)(key >> 32);
+  const uint32_t me1 = idx + 1u;
+  const bool writes = kind_writes(kind), strong = kind_strong(kind), real = kind_real(kind);
+  const int sh = a.v.g.sh;
+  const uint32_t nleaves = (uint32_t)(a.v.g.N >> sh);
+  // (a soft barrier holds back everything AFTER the update that raised it, that update itself may commit)
+  const bool barred = (kind == K_EXCL) || key_earlier(gbar, tag, idx) || key_earlier(sbar, tag, idx);
+  // what a failing update marks (the same arithmetic as o_check_one): its regions, padded, and its growth block
+  uint32_t ll = writes ? wl : (index >> sh), lh = writes ? wh : ll;
+  ll = (ll > kRegionPadLeaves) ? ll - kRegionPadLeaves : 0u;
+  lh = (lh + kRegionPadLeaves < nleaves) ? lh + kRegionPadLeaves : nleaves - 1u;
+  const uint32_t pglo = ll >> a.regshift, pghi = lh >> a.regshift;
+  uint32_t wleaves = writes && wlen ? (wlen >> sh) : 1u;
+  if (wleaves < 1u) wleaves = 1u;
+  uint32_t gblk = wleaves * 4u;
+  if (gblk < kGrowLeaves) gblk = kGrowLeaves;
+  const uint32_t anchor = writes && wlen ? (wstart >> sh) : (index >> sh);
+  uint32_t bl = anchor & ~(gblk - 1u), bh = bl + gblk - 1u;
+  if (ll < bl) bl = ll;
+  if (lh > bh) bh = lh;
+  if (bh >= nleaves) bh = nleaves - 1u;
+  bool longr = false;
+#pragma unroll
+  for (int r = 0; r < kCkRanges; r++)
+    if ((uint32_t)r < nr && rhi[r] - rlo[r] >= 2u) longr = true;
+  const bool moves = strong && mv_lo <= mv_hi;
+  // long footprints go to the wave (a barred update's footprint is never walked: see o_check_one)
+  const bool complex = active && !barred && real &&
+                       (nlong != 0u || nr > (uint32_t)kCkRanges || longr || (writes && wh - wl >= kCkWrite) || (moves && mv_hi - mv_lo >= kCkMovedMax) ||
+                        bh - bl >= kCkMark || pghi - pglo >= 4u);
+  const bool mine = active && !barred && !complex;
+  bool fail = barred, stamp_bad = false;
+  uint32_t bad_where = 0, bad_stamp = 0, bad_what = 0;
+  {
+    // ---- every load, unconditionally ------------------------------------------------------------------------------------
+    const bool wany = mine && writes;  // (K_DUP: one leaf, wl == wh)
+    const uint32_t w0 = wany ? wl : 0u, w1 = (wany && wh > wl) ? wh : w0;
+    const unsigned long long kw0 = a.v.wres[w0], kd0 = a.v.dres[w0], kr0 = a.v.rres[w0], kw1 = a.v.wres[w1], kd1 = a.v.dres[w1], kr1 = a.v.rres[w1];
+    const uint32_t sw0 = a.wstamp[w0], sr0 = a.rstamp[w0], sw1 = a.wstamp[w1], sr1 = a.rstamp[w1];
+    unsigned long long rk[kCkRanges][2];
+    uint32_t rs[kCkRanges][2], rl[kCkRanges][2];
+#pragma unroll
+    for (int r = 0; r < kCkRanges; r++) {
+      const bool on = mine && (uint32_t)r < nr;
+      rl[r][0] = on ? rlo[r] : 0u;
+      rl[r][1] = on ? rhi[r] : 0u;
+      rk[r][0] = a.v.wres[rl[r][0]];
+      rk[r][1] = a.v.wres[rl[r][1]];
+      rs[r][0] = a.wstamp[rl[r][0]];
+      rs[r][1] = a.wstamp[rl[r][1]];
+    }
+    const bool vany = mine && real && src < a.v.g.n;
+    const bool von0 = vany && (sdep & 1u), von1 = vany && (sdep & 2u) && src + 1u < a.v.g.n;
+    const uint32_t u0 = von0 ? src : 0u, u1 = von1 ? src + 1u : 0u;
+    const unsigned long long kv0 = a.v.vw[u0], kv1 = a.v.vw[u1];
+    const uint32_t sv0 = a.vws[u0], sv1 = a.vws[u1];
+    const bool many = vany && moves;
+    unsigned long long mk[kCkMoved];
+    uint32_t m1[kCkMoved], m2[kCkMoved], mu[kCkMoved];
+#pragma unroll
+    for (uint32_t q = 0; q < kCkMoved; q++) {
+      mu[q] = (many && mv_lo + q <= mv_hi) ? mv_lo + q : 0u;
+      mk[q] = a.v.vr[mu[q]];
+      m1[q] = a.vrs[mu[q]];
+      m2[q] = a.vws[mu[q]];
+    }
+    // ---- every compare ------------------------------------------------------------------------------------------------
+    if (mine && kind == K_DUP) {
+      if (key_earlier(kw0, tag, idx)) fail = true;  // an earlier pending update moves slots of this leaf
+      if (kd0 != key) fail = true;                   // an earlier pending duplicate on this leaf
+    }
+    if (mine && strong) {
+      if (kw0 != key || kw1 != key) fail = true;                                  // an earlier pending update writes it
+      if (key_earlier(kd0, tag, idx) || key_earlier(kd1, tag, idx)) fail = true;  // an earlier pending duplicate overwrites a slot here
+      if (key_earlier(kr0, tag, idx) || key_earlier(kr1, tag, idx)) fail = true;  // an earlier pending update reads it
+      if (sw1 > me1 || sr1 > me1) {                                               // a LATER update already touched it
+        stamp_bad = true;
+        bad_where = w1;
+        bad_stamp = sw1 > me1 ? sw1 : sr1;
+        bad_what = sw1 > me1 ? 1u : 2u;
+      }
+      if (sw0 > me1 || sr0 > me1) {
+        stamp_bad = true;
+        bad_where = w0;
+        bad_stamp = sw0 > me1 ? sw0 : sr0;
+        bad_what = sw0 > me1 ? 1u : 2u;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kCkRanges; r++) {
+      if (mine && (uint32_t)r < nr) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          if (key_earlier(rk[r][e], tag, idx)) fail = true;  // an earlier pending update writes what we read
+          if (rs[r][e] > me1) {                               // a LATER update already wrote what we read
+            stamp_bad = true;
+            bad_where = rl[r][e];
+            bad_stamp = rs[r][e];
+            bad_what = 3u;
+          }
+        }
+      }
+    }
+    if (von0) {  // sentinel src — only when the search result depends on its position
+      if (key_earlier(kv0, tag, idx)) fail = true;  // an earlier pending update moves a sentinel we located by
+      if (sv0 > me1) {                              // a LATER update already moved it
+        stamp_bad = true;
+        bad_where = u0;
+        bad_stamp = sv0;
+        bad_what = 4u;
+      }
+    }
+    if (von1) {  // sentinel src + 1
+      if (key_earlier(kv1, tag, idx)) fail = true;
+      if (sv1 > me1) {
+        stamp_bad = true;
+        bad_where = u1;
+        bad_stamp = sv1;
+        bad_what = 4u;
+      }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kCkMoved; q++) {
+      if (many && mv_lo + q <= mv_hi) {
+        if (key_earlier(mk[q], tag, idx)) fail = true;  // an earlier pending update still needs the old position
+        if (m1[q] > me1 || m2[q] > me1) {               // a LATER update already used / moved it
+          stamp_bad = true;
+          bad_where = mu[q];
+          bad_stamp = m1[q] > me1 ? m1[q] : m2[q];
+          bad_what = 5u;
+        }
+      }
+    }
+  }
+  if (mine && real && src < a.v.g.n && moves && mv_hi - mv_lo >= kCkMoved) {  // the rest of a long run of moved sentinels, 8 per trip
+    for (uint32_t base = mv_lo + kCkMoved; base <= mv_hi && base >= mv_lo; base += 8u) {
+      unsigned long long mk[8];
+      uint32_t m1[8], m2[8];
+#pragma unroll
+      for (uint32_t q = 0; q < 8u; q++) {
+        const uint32_t u = (base + q <= mv_hi) ? base + q : mv_hi;
+        mk[q] = a.v.vr[u];
+        m1[q] = a.vrs[u];
+        m2[q] = a.vws[u];
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < 8u; q++) {
+        if (key_earlier(mk[q], tag, idx)) fail = true;
+        if (m1[q] > me1 || m2[q] > me1) {
+          stamp_bad = true;
+          bad_where = (base + q <= mv_hi) ? base + q : mv_hi;
+          bad_stamp = m1[q] > me1 ? m1[q] : m2[q];
+          bad_what = 5u;
+        }
+      }
+    }
+  }
+  {
+    // a deferred update keeps later updates out of its region(s); its footprint may still creep over a region edge by a
+    // slide, so the mark is padded (ll / lh above); and a leaf-level mark for later READERS over the block its window may
+    // still grow into.  Written by the WAVE, one failing update at a time, lane q taking the q-th leaf / region of the mark
+    // (a lane marking its own 12 leaves one atomic after the other waited for each to come back)
+    uint64_t fm = wv::ballot(mine && fail && real);
+    while (fm) {
+      const int l = wv::ctz64(fm);
+      fm &= fm - 1ull;
+      const uint32_t f_bl = wv::bcast(bl, l), f_bh = wv::bcast(bh, l), f_g0 = wv::bcast(pglo, l), f_g1 = wv::bcast(pghi, l);
+      const unsigned long long f_key = make_key(a.round, wv::bcast(idx, l));
+      if (f_bl + (uint32_t)lane <= f_bh) wv::atomic_min_u64(&a.pfail[f_bl + (uint32_t)lane], f_key);   // (bh - bl < kCkMark <= 64)
+      if (f_g0 + (uint32_t)lane <= f_g1) wv::atomic_min_u64(&a.regfail[f_g0 + (uint32_t)lane], f_key);  // (at most 4 regions)
+    }
+  }
+  if (mine && stamp_bad) {
+    a.vdbg[4 * slot + 0] = bad_where;
+    a.vdbg[4 * slot + 1] = bad_stamp;
+    a.vdbg[4 * slot + 2] = bad_what;
+  }
+  if (active && !complex) a.status[slot] = (fail ? 0u : OS_PASS) | (stamp_bad ? OS_STAMP_BAD : 0u);
+  // the long ones, by the whole wave, one after the other
+  uint64_t todo = wv::ballot(complex);
+  while (todo) {
+    const int l = wv::ctz64(todo);
+    todo &= todo - 1ull;
+    PlanHead h;
+    h.kind = wv::bcast(q0.x, l);
+    h.index = wv::bcast(q0.y, l);
+    h.gap = wv::bcast(q0.z, l);
+    h.wstart = wv::bcast(q0.w, l);
+    h.wlen = wv::bcast(q1.x, l);
+    h.wleaf_lo = wv::bcast(q1.y, l);
+    h.wleaf_hi = wv::bcast(q1.z, l);
+    h.mv_lo = wv::bcast(q1.w, l);
+    h.mv_hi = wv::bcast(q2.x, l);
+    h.sleaf_b = wv::bcast(q2.y, l);
+    h.sleaf_e = wv::bcast(q2.z, l);
+    h.alg_calls = h.alg_slots = 0;
+    h.nr = wv::bcast(q3.x, l);
+    h.nlong = wv::bcast(q3.y, l);
+    h.sdep = wv::bcast(q3.z, l);
+    h.idx = wv::bcast(q3.w, l);
+    h.op = Op{wv::bcast(q4.x, l), wv::bcast(q4.y, l), wv::bcast(q4.z, l)};
+    const uint32_t wid = wave_slot0 + (uint32_t)l;
+    const Plan *pl = &a.plans[wid];
+    PlanRange rg{1u, 0u};
+    if (lane < kHeadRanges) rg = pl->r[lane];
+    h.my_lo = rg.lo;
+    h.my_hi = rg.hi;
+    o_check_one<false>(a, c, par, wid, h, pl, gbar, sbar);
+  }
+}
 
 // EXTRAS = false: the opt-in experiments (chains, zones) and the diagnostics are compiled out — carried along as run-time
 // branches they cost the calm stream 4 % (config #2: 179 vs 187 M updates/s); the engine launches the *_x kernels when one is on
@@ -338,15 +595,10 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
   const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
   const uint32_t hor = c->hor[par];
   const uint32_t st = wv::uni(a.status[wid]);
-  const uint32_t idx = wv::uni(a.opidx[wid]);
   const Plan *pl = &a.plans[wid];
   const PlanHead h = dev::load_plan_head(pl);
-  // the update itself: requested as soon as its index is known (unconditionally — slot 0 for waves beyond the horizon), so
-  // that it travels while the region checks below wait for their own loads instead of after them
-  Op op = a.ops[(wid < hor) ? idx : 0u];
-  op.src = wv::uni(op.src);
-  op.dst = wv::uni(op.dst);
-  op.op = wv::uni(op.op);
+  const uint32_t idx = h.idx;
+  const Op op = h.op;
   if (f_done || f_viol || f_excl || f_err) return;
   if (wid >= hor) return;
   if (!(st & OS_PASS)) return;

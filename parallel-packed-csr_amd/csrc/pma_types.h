@@ -67,11 +67,12 @@ enum Kind : uint32_t {
   K_SKIP = 6,      // already executed by the exclusive executor inside this epoch: commits as nothing
 };
 
-constexpr int kMaxR = 72;  // read-leaf ranges recorded per op (search certificate + one or two per level of the density climb + a few)
+constexpr int kMaxR = 70;  // read-leaf ranges recorded per op (search certificate + one or two per level of the density climb + a few)
 
-// Layout: the 16-word header and the first 8 read ranges fill the record's first 128 bytes, which is all the round kernels touch
+// Layout: the 20-word header and the first 6 read ranges fill the record's first 128 bytes, which is all the round kernels touch
 // for almost every update (two or three ranges: the search certificate and the leaves of a short climb) — one wave-wide store
 // in o_plan, one wave-wide load in o_check / o_apply (lane i <-> word i; the fields are then read off the lanes as scalars).
+// The update itself (stream index, src, dst, op) travels in the header too: the later kernels of the round need nothing else.
 struct PlanRange {
   uint32_t lo, hi;  // inclusive leaf range
 };
@@ -86,16 +87,19 @@ struct Plan {
   // sentinels of vertices [mv_lo, mv_hi] (those inside its slide range / rebalance window; empty if mv_lo > mv_hi)
   uint32_t mv_lo, mv_hi;
   uint32_t sleaf_b, sleaf_e;  // leaves currently holding sentinel src / src+1 (growth-zone check of deferred writers)
-  uint32_t alg_calls, alg_slots;  // redistribute() calls / slots the reference performs for this op
+  uint32_t alg;               // redistribute() calls (bits 28..31) and slots (bits 0..27) the reference performs for this op
   uint32_t nr;
   uint32_t nlong;  // number of read ranges spanning >= kLongRange leaves (0 for almost every update)
   uint32_t sdep;   // bit 0 / 1: the search result depends on the position of sentinel src / src + 1 (pma_search)
+  uint32_t idx;    // stream index of the update
+  uint32_t src, dst, op;  // the update
+  uint32_t pad;
   PlanRange r[kMaxR];  // leaf ranges read by the search / the density climb
 };
 // word index of a header field inside the record (lane <-> word in the wave-wide accesses)
 enum PlanWord : int { PW_KIND = 0, PW_INDEX, PW_GAP, PW_WSTART, PW_WLEN, PW_WLEAF_LO, PW_WLEAF_HI, PW_MV_LO, PW_MV_HI, PW_SLEAF_B, PW_SLEAF_E,
-                      PW_ALG_CALLS, PW_ALG_SLOTS, PW_NR, PW_NLONG, PW_SDEP, PW_HEADER_WORDS };
-static_assert(sizeof(Plan) == 640 && PW_HEADER_WORDS == 16, "plan record layout");
+                      PW_ALG, PW_NR, PW_NLONG, PW_SDEP, PW_IDX, PW_SRC, PW_DST, PW_OP, PW_PAD, PW_HEADER_WORDS };
+static_assert(sizeof(Plan) == 640 && PW_HEADER_WORDS == 20, "plan record layout");
 
 // scheduler control block (device memory, mirrored to pinned host memory between round chunks)
 struct Control {

@@ -39,10 +39,11 @@ PMA_DEV uint32_t setlane(uint32_t v, uint32_t x) {
   asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(sx), "n"(K));
   return v;
 }
-// lanes 0 .. 15 of v as scalars (16 x v_readlane_b32; the emulator does it in one rendezvous)
-PMA_DEV void lanes16(uint32_t v, uint32_t *out) {
+// lanes 0 .. N-1 of v as scalars (N x v_readlane_b32; the emulator does it in one rendezvous)
+template <int N>
+PMA_DEV void lanes(uint32_t v, uint32_t *out) {
 #pragma unroll
-  for (int i = 0; i < 16; i++) out[i] = (uint32_t)__builtin_amdgcn_readlane((int)v, i);
+  for (int i = 0; i < N; i++) out[i] = (uint32_t)__builtin_amdgcn_readlane((int)v, i);
 }
 PMA_DEV uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src)); }
 PMA_DEV uint32_t reduce_add(uint32_t v) {

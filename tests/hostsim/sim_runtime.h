@@ -58,10 +58,11 @@ inline bool uni(bool b) { return sim::uniform64(b ? 1u : 0u) != 0; }
 inline uint64_t uni(uint64_t v) { return sim::uniform64(v); }
 template <int K>
 inline uint32_t setlane(uint32_t v, uint32_t x) { return lane() == K ? x : v; }
-inline void lanes16(uint32_t v, uint32_t *out) {
+template <int N>
+inline void lanes(uint32_t v, uint32_t *out) {
   uint64_t all[64];
   sim::gather64(v, all);
-  for (int i = 0; i < 16; i++) out[i] = (uint32_t)all[i];
+  for (int i = 0; i < N; i++) out[i] = (uint32_t)all[i];
 }
 inline uint32_t bcast(uint32_t v, int src) { return (uint32_t)sim::shfl64(v, (int)(uint32_t)sim::uniform64((uint32_t)src)); }
 inline uint32_t reduce_add(uint32_t v) { return (uint32_t)sim::reduce_add64(v); }
