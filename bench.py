@@ -387,6 +387,22 @@ def main():
         res = {"value": total_updates / elapsed, "ms_per_step": elapsed / steps * 1e3, "engine": dstat,
                "N_slots": [int(x) for x in s1["N"]], "logN": int(s1["logN"][0]), "last_k": (warmup + steps - 1) % nb,
                "core_blk": core_blk, "upd": upd, "es": es, "pp": pp, "step": step}
+        if single and N == 1:
+            # end to end (the reference's own clock covers its whole apply phase: thread_pool.cpp:79,110): the
+            # op array starts in HOST memory — ppcsr_apply_batch uploads it (12 B per update over PCIe) and applies it; wall clock
+            # around restore + upload + apply, same steps as the device-only figure above.  Never `value`.
+            t_e = time.perf_counter()
+            h2d = 0.0
+            for k in range(warmup, warmup + steps):
+                es[0].restore()
+                es[0].apply(upd[k % nb])
+                h2d += es[0].stats()["last_batch_h2d_ms"]
+            torch.cuda.synchronize()
+            t_e = time.perf_counter() - t_e
+            res["end_to_end"] = {"value": total_updates / t_e, "unit": "edge-updates/s", "ms_per_step": t_e / steps * 1e3,
+                                 "h2d_ms_per_step": h2d / steps, "op_bytes_per_step": 12 * len(upd[0]),
+                                 "note": "host-resident op array: upload (PCIe) + apply, wall clock incl. the snapshot restore; "
+                                         "the headline `value` is device-only (ops already in HBM)"}
         # ---- roofline of the dominant round kernel: HIP events on the engines' own streams around every round kernel.
         # Recording ~5 events per round costs 25-35 % of throughput, so `value` comes from the un-instrumented timed
         # region and the SAME steps are replayed here with the events on (same inputs, same state).
@@ -584,7 +600,7 @@ def main():
                 for label, thr, flags in ((f"pppcsrnuma_t{share}", share, ["-pppcsrnuma", "-partitions_per_domain=8"]),
                                           (f"ppcsr_t{share}", share, ["-ppcsr"])):
                     vals = []
-                    for _ in range(3):
+                    for _ in range(5):  # (5 repetitions)
                         r = subprocess.run([ref_cli, f"-threads={thr}", f"-size={len(res['upd'][0])}", "-insert"] + flags +
                                            [f"-core_graph={cf}", f"-update_file={uf}"], capture_output=True, text=True, timeout=600)
                         el = [int(l.split(":")[1]) for l in r.stdout.splitlines() if l.startswith("Elapsed wall clock time")]
@@ -636,6 +652,16 @@ def main():
                 extra[label] = {"window_slots": w, "ms_per_call": rms, "alg_GBps": 24.0 * w / (rms * 1e-3) / 1e9,
                                 "frac_of_peak": 24.0 * w / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "note": "device time (HIP events) of tile sums + position table + fused scatter/fill"}
+            # the other half-array window, [N/2, N): it lies in ONE binade of the position chain (a window that starts at slot 0
+            # crosses one per doubling, and one thread builds that table: ~9 us of the launch), and the quarter window in place
+            for label, w, upper in (("window_rebalance_half_upper", int(stt["N"]) // 2, 1), ("window_rebalance_quarter", int(stt["N"]) // 4, 1)):
+                eng.set_option("rb_bench_upper", upper)
+                eng.bench_rebalance(w, 1)
+                rms = eng.bench_rebalance(w, 5)
+                eng.set_option("rb_bench_upper", 0)
+                extra[label] = {"window_slots": w, "window_start": int(stt["N"]) - w, "ms_per_call": rms, "alg_GBps": 24.0 * w / (rms * 1e-3) / 1e9,
+                                "frac_of_peak": 24.0 * w / (rms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "note": "in place (tile sums + scan / position table / tile order + ticketed in-place pass)"}
             if single:
                 # graph-algorithm consumers on the device: BFS from vertex 0, one PageRank push
                 nv = int(stt["n"])
@@ -659,11 +685,22 @@ def main():
                                        "edges_per_s_device": len(res["core_blk"]) / (bb_ms * 1e-3), "N_slots": int(eb.geometry()[0]),
                                        "note": "NOT layout-identical to the one-by-one build (history dependent); same edge "
                                                "set, values, num_neighbors and invariants"}
+                # double_list / half_list alone (PCSR.cpp:251-320) on that engine: N -> 2N -> N, three times; algorithmic bytes per
+                # 12 (N/2) + 12 N = 18 N' for a doubling INTO N' slots, 12 (2N) + 12 N = 36 N' for a halving into N'
+                n0 = int(eb.geometry()[0])
+                dms, hms = eb.bench_resize(3)
+                extra["double_list"] = {"N_slots_from": n0, "N_slots_to": 2 * n0, "ms_per_call": dms, "alg_bytes": 18.0 * 2 * n0,
+                                        "alg_GBps": 18.0 * 2 * n0 / (dms * 1e-3) / 1e9, "frac_of_peak": 18.0 * 2 * n0 / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                extra["half_list"] = {"N_slots_from": 2 * n0, "N_slots_to": n0, "ms_per_call": hms, "alg_bytes": 36.0 * n0,
+                                      "alg_GBps": 36.0 * n0 / (hms * 1e-3) / 1e9, "frac_of_peak": 36.0 * n0 / (hms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "note": "device time of tile sums + position table + ONE fused pass from the old array into the fresh one "
+                                              "(the reference compacts, reallocates and redistributes: 36 N bytes; this pass moves 12 (2N) + 12 N)"}
                 eb.close()
         except Exception as e:  # never let a secondary measurement kill the headline
             extra["secondary_error"] = str(e)
     # release the headline engines before further workloads are built
     headline = {k: res[k] for k in ("value", "ms_per_step", "engine", "N_slots", "logN")}
+    end_to_end = res.get("end_to_end")
     roofline = res.get("roofline")
     for e in es:
         e.close() if single else None
@@ -675,6 +712,8 @@ def main():
         try:
             r = run_workload(wl_, key, steps, warmup, False, after_core=after_core)
             out = {"workload": wl_.name(P, N), "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": steps, "engine": r["engine"]}
+            if r.get("end_to_end"):
+                out["end_to_end"] = r["end_to_end"]
             if more:
                 out.update(more)
             if check and not args.no_check:
@@ -736,7 +775,7 @@ def main():
                        "distinct_update_batches": max(1, min(args.distinct_batches, args.warmup + args.steps)),
                        "semantics": "sequential stream order (bit-exact vs reference -threads=1)",
                        **({"exchange_note": carrier["note"]} if carrier["note"] else {})},
-            "roofline": roofline, "cpu_baseline": cpu, "engine": headline["engine"], **extra,
+            "roofline": roofline, "cpu_baseline": cpu, "engine": headline["engine"], "end_to_end": end_to_end, **extra,
         }
         print(json.dumps(out), flush=True)
     if N > 1:

@@ -133,6 +133,9 @@ int ppcsr_restore(ppcsr_t h);
 int ppcsr_check_invariants(ppcsr_t h, uint64_t *bad_leaves);
 int ppcsr_bench_scan_all(ppcsr_t h, double *ms, uint64_t *total);
 int ppcsr_bench_rebalance(ppcsr_t h, uint64_t window_slots, int iters, double *ms_per_call);
+/* PCSR::double_list / half_list (PCSR.cpp:251-282, 284-320) alone: the array is doubled and halved back `iters` times; device time
+ * per call of each (measurement helper: the array ends at its original size, evenly spread) */
+int ppcsr_bench_resize(ppcsr_t h, int iters, double *double_ms, double *half_ms);
 const char *ppcsr_strerror(int status);
 const char *ppcsr_last_error(void); /* message of the last failing call on this thread */
 int ppcsr_device_count(void);

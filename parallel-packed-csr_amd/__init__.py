@@ -40,7 +40,7 @@ EXPORTED = [
     "ppcsr_create", "ppcsr_destroy", "ppcsr_add_edge", "ppcsr_remove_edge", "ppcsr_add_node", "ppcsr_apply_batch",
     "ppcsr_apply_batch_device", "ppcsr_edge_exists", "ppcsr_get_n", "ppcsr_get_node", "ppcsr_geometry",
     "ppcsr_get_neighbourhood", "ppcsr_read_neighbourhood", "ppcsr_scan_all", "ppcsr_bulk_build", "ppcsr_bfs", "ppcsr_pagerank", "ppcsr_export_state", "ppcsr_stats",
-    "ppcsr_set_option", "ppcsr_snapshot", "ppcsr_restore", "ppcsr_check_invariants", "ppcsr_bench_scan_all", "ppcsr_bench_rebalance", "ppcsr_strerror",
+    "ppcsr_set_option", "ppcsr_snapshot", "ppcsr_restore", "ppcsr_check_invariants", "ppcsr_bench_scan_all", "ppcsr_bench_rebalance", "ppcsr_bench_resize", "ppcsr_strerror",
     "ppcsr_last_error", "ppcsr_device_count", "pppcsr_create", "pppcsr_destroy", "pppcsr_num_partitions",
     "pppcsr_get_partition", "pppcsr_partition_start", "pppcsr_partition", "pppcsr_add_edge", "pppcsr_remove_edge",
     "pppcsr_edge_exists", "pppcsr_get_neighbourhood", "pppcsr_get_node", "pppcsr_get_n", "pppcsr_add_node",
@@ -114,6 +114,7 @@ def load_library(path=None):
     L.ppcsr_check_invariants.argtypes = [c_vp, ctypes.POINTER(c_u64)]
     L.ppcsr_bench_scan_all.argtypes = [c_vp, ctypes.POINTER(c_dbl), ctypes.POINTER(c_u64)]
     L.ppcsr_bench_rebalance.argtypes = [c_vp, c_u64, c_int, ctypes.POINTER(c_dbl)]
+    L.ppcsr_bench_resize.argtypes = [c_vp, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl)]
     L.ppcsr_strerror.restype = ctypes.c_char_p
     L.ppcsr_strerror.argtypes = [c_int]
     L.ppcsr_last_error.restype = ctypes.c_char_p
@@ -297,6 +298,12 @@ class PCSR:
         ms, tot = c_dbl(), c_u64()
         self._chk(self.L.ppcsr_bench_scan_all(self.h, ctypes.byref(ms), ctypes.byref(tot)))
         return ms.value, tot.value
+
+    def bench_resize(self, iters=3):
+        """(double_list ms, half_list ms): device time per call, the array doubled and halved back `iters` times"""
+        d, h = c_dbl(), c_dbl()
+        self._chk(self.L.ppcsr_bench_resize(self.h, iters, ctypes.byref(d), ctypes.byref(h)))
+        return d.value, h.value
 
     def bench_rebalance(self, window_slots, iters=5):
         ms = c_dbl()

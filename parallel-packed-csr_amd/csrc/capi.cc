@@ -168,6 +168,11 @@ int ppcsr_set_option(ppcsr_t h, const char *key, int64_t value) { H_CHECK(); ret
 int ppcsr_check_invariants(ppcsr_t h, uint64_t *bad_leaves) { H_CHECK(); return ret(h->e, h->e->check_invariants(bad_leaves)); }
 int ppcsr_bench_scan_all(ppcsr_t h, double *ms, uint64_t *total) { H_CHECK(); return ret(h->e, h->e->scan_all_device(ms, total)); }
 int ppcsr_bench_rebalance(ppcsr_t h, uint64_t w, int iters, double *ms) { H_CHECK(); return ret(h->e, h->e->rebalance_bench(w, iters, ms)); }
+int ppcsr_bench_resize(ppcsr_t h, int iters, double *double_ms, double *half_ms) {
+  H_CHECK();
+  if (!double_ms || !half_ms) return bad("null output");
+  return ret(h->e, h->e->resize_bench(iters, double_ms, half_ms));
+}
 int ppcsr_snapshot(ppcsr_t h) { H_CHECK(); return ret(h->e, h->e->snapshot()); }
 int ppcsr_restore(ppcsr_t h) { H_CHECK(); return ret(h->e, h->e->restore()); }
 const char *ppcsr_strerror(int status) { return ppcsr::error_string(status); }

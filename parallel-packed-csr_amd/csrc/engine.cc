@@ -167,6 +167,9 @@ struct Engine::Impl {
   uint32_t rb_tile = 0;          // leaves per rebalance tile (power of two <= 256); 0 = pick per window
   uint32_t rb_min_tiles = 4096;  // auto tile: shrink the tile until the window has at least this many
   uint32_t rb_prefetch = 1;  // 1: four chunks in flight per wave, 0: one
+  bool time_resize = false;  // resize_bench: time the passes of resize() with events
+  double last_resize_ms = 0;
+  uint32_t rb_bench_upper = 0;  // rebalance_bench: 1 = the window [N - wlen, N) instead of [0, wlen)
   uint64_t rb_inplace_min = 1ull << 19;  // partial windows of at least this many slots are rebalanced in place (0 = never)
   uint32_t rb_inplace_cpw = 0;   // 64-slot chunks per wave of an in-place tile (8 or 16; 0 = by window size)
   uint32_t *d_ip = nullptr;      // in-place rebalance: header (sticky error, ticket counters), tile order, the tiles' flags
@@ -365,7 +368,7 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
   GCHK(gpu::dmalloc((void **)&p.d_xout, sizeof(ExclOut)));
   GCHK(gpu::hmalloc((void **)&p.h_xout, sizeof(ExclOut)));
   GCHK(gpu::hmalloc((void **)&p.h_op1, sizeof(Op)));
-  GCHK(gpu::dmalloc((void **)&p.d_total, sizeof(unsigned long long)));
+  GCHK(gpu::dmalloc((void **)&p.d_total, 32 * sizeof(unsigned long long)));  // ([0]: the total; the rest: scratch of debugging builds)
   GCHK(gpu::hmalloc((void **)&p.h_total, sizeof(unsigned long long)));
   GCHK(gpu::dmalloc((void **)&p.d_table, sizeof(ChainTable)));
   GCHK(gpu::dmalloc((void **)&p.d_ip, (kIpHdrWords + 2 * (uint64_t)kIpMaxTiles) * sizeof(uint32_t)));
@@ -594,6 +597,10 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "rb_inplace_min") {
     p.rb_inplace_min = value < 0 ? 0ull : (uint64_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "rb_bench_upper") {
+    p.rb_bench_upper = value ? 1u : 0u;
     return PPCSR_OK;
   }
   if (k == "rb_prefetch") {
@@ -1395,6 +1402,7 @@ int Engine::resize(uint64_t newN) {
   GCHK(gpu::dmalloc((void **)&nv.items, newN * sizeof(Edge)));
   GCHK(gpu::dmalloc((void **)&nv.leafcnt, new_leaves * sizeof(uint32_t)));
   int rc = PPCSR_OK;
+  if (p.time_resize) p.timer.start(p.stream);  // (resize_bench: device time of the passes alone, allocations outside)
   if (p.scatter_variant == 2 && old.g.logN <= 32) {
     rc = rebalance_fused(nv, old.items, 0, oldN, old.g.sh, old.leafcnt, false, 0, newN, nv.items, 0, nv.leafcnt, new_leaves);
     if (rc != PPCSR_OK) return rc;
@@ -1413,8 +1421,10 @@ int Engine::resize(uint64_t newN) {
     GPU_LAUNCH(p.stream, k_scatter_fill, grid_for((oldN + 63) / 64, 4), 256, nv, (const Edge *)old.items, (uint64_t)0, oldN,
                old.g.sh, (const uint32_t *)p.d_rank, (const ChainTable *)p.d_table, nv.items, (uint64_t)0, nv.leafcnt, nv.g.sh,
                (uint64_t)0);
+  if (p.time_resize) p.timer.stop(p.stream);
   GCHK(gpu::sync(p.stream));
   GCHK(gpu::last_error());
+  if (p.time_resize) p.last_resize_ms = p.timer.ms();
   guard.dismiss();
   GPU_DFREE(old.items);
   GPU_DFREE(old.leafcnt);
@@ -2217,18 +2227,55 @@ int Engine::rebalance_bench(uint64_t wlen, int iters, double *ms_per_call) {
   Impl &p = *p_;
   if (wlen == 0 || wlen > p.v.g.N || (wlen & (wlen - 1)) || wlen < (uint64_t)p.v.g.logN) return fail(PPCSR_EINVAL, "bad window");
   GCHK(gpu::set_device(device_));
-  int rc = big_redistribute(0, wlen, true);  // warm-up (also sizes the scratch array)
+  // (a window that starts at slot 0 crosses a binade of the position chain per doubling — a table of ~23 segments built by one
+  //  thread; every other aligned window lies in one binade: option rb_bench_upper times [N - wlen, N))
+  const uint64_t wstart = p.rb_bench_upper ? p.v.g.N - wlen : 0;
+  int rc = big_redistribute(wstart, wlen, true);  // warm-up (also sizes the scratch array)
   if (rc != PPCSR_OK) return rc;
   p.timer.start(p.stream);  // device time of the whole pipeline: rank scan, position table, fused scatter/fill (+ copy-back)
   for (int i = 0; i < iters; i++) {
-    rc = big_redistribute(0, wlen, false);
+    rc = big_redistribute(wstart, wlen, false);
     if (rc != PPCSR_OK) return rc;
   }
   p.timer.stop(p.stream);
   GCHK(gpu::sync(p.stream));
   GCHK(gpu::last_error());
   *ms_per_call = p.timer.ms() / iters;
+#if defined(PPCSR_SCAN_DEBUG)
+  {
+    unsigned long long t[32];
+    GCHK(gpu::d2h(t, p.d_total, sizeof(t), p.stream));
+    GCHK(gpu::sync(p.stream));
+    fprintf(stderr, "[scan] cycles: scan %llu, table %llu, order: table copy %llu, flags %llu, keys %llu, count %llu, hist scan %llu, scatter %llu (100 MHz ticks x ?)\n", t[9] - t[8], t[10] - t[9],
+            t[11] - t[10], t[12] - t[11], t[13] - t[12], t[14] - t[13], t[15] - t[14], t[16] - t[15]);
+  }
+#endif
   return inplace_fault_check();
+}
+
+// double_list / half_list alone (PCSR.cpp:251-320): the array is doubled and halved back `iters` times; device time of the
+// passes (tile sums, position table, fused scatter into the fresh array), allocations and the final synchronisation outside.
+// The array ends at its original size, evenly spread.
+int Engine::resize_bench(int iters, double *double_ms, double *half_ms) {
+  Impl &p = *p_;
+  GCHK(gpu::set_device(device_));
+  if (iters < 1) return fail(PPCSR_EINVAL, "bad iteration count");
+  const uint64_t N0 = p.v.g.N;
+  double d = 0, h = 0;
+  p.time_resize = true;
+  int rc = PPCSR_OK;
+  for (int i = 0; i < iters && rc == PPCSR_OK; i++) {
+    rc = resize(2 * N0);
+    d += p.last_resize_ms;
+    if (rc != PPCSR_OK) break;
+    rc = resize(N0);
+    h += p.last_resize_ms;
+  }
+  p.time_resize = false;
+  if (rc != PPCSR_OK) return rc;
+  *double_ms = d / iters;
+  *half_ms = h / iters;
+  return PPCSR_OK;
 }
 
 int bucket_ops_device(const uint32_t *starts, uint32_t n_parts, const Op *d_ops, uint64_t n, Op *d_out, unsigned long long *d_counts,

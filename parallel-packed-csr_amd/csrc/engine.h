@@ -60,6 +60,7 @@ class Engine {
   int stats(EngineStats *out);
   int set_option(const char *key, int64_t value);
   int rebalance_bench(uint64_t wlen, int iters, double *ms_per_call);
+  int resize_bench(int iters, double *double_ms, double *half_ms);
   int snapshot();  // device-side copy of the whole state (items, nodes, leaf counts, geometry)
   int restore();   // back to the last snapshot (device-to-device)  // whole-window rebalance kernel timing
 

@@ -127,7 +127,13 @@ PMA_HD inline double chain_sub(double x, double step) {
 // floor(a / b) for a, b < 2^53, b > 0: one fp64 division plus an exact integer fix-up (a 64-bit integer division is a
 // ~100-instruction software routine on the GPU and this sits on the table build's serial path)
 PMA_HD inline uint64_t div_floor_u53(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (the hardware reciprocal is an estimate; the fix-up below makes the quotient exact whatever the estimate is off by — an
+  //  IEEE division is ~40 dependent instructions, and one thread runs this once per binade of the chain)
+  uint64_t q = (uint64_t)((double)a * __builtin_amdgcn_rcp((double)b));
+#else
   uint64_t q = (uint64_t)((double)a / (double)b);
+#endif
   int64_t r = (int64_t)(a - q * b);
   while (r < 0) {
     q--;

@@ -79,15 +79,21 @@ PMA_KERNEL void k_scan_tiles(const uint32_t *cnt, uint64_t nleaves, uint32_t *ti
 // the tiles by key; k_rb_inplace workgroups draw tickets in that order — whoever a workgroup waits for drew an earlier ticket, is resident (or done) and
 // publishes without waiting for anybody: no deadlock whatever the number of resident workgroups.  (A bounded spin turns a
 // broken order into an error flag instead of a hang.)
+#if defined(PPCSR_SCAN_DEBUG)
+#define PMA_TSTAMP(dbg, i) do { if ((dbg) && wv::thread_idx() == 0) (dbg)[i] = (unsigned long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PMA_TSTAMP(dbg, i) do { } while (0)
+#endif
 constexpr uint32_t kIpMaxTiles = 8192, kIpOrderThreads = 1024;
 constexpr uint32_t kIpHdrWords = 32 * 9;  // words before the order list in the engine's buffer
 constexpr uint32_t kIpTicketStride = 32;  // ctl[1]: sticky error flag; ctl[kIpTicketStride * (1 + x)]: ticket counter of XCD x
-PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint32_t ntiles, uint32_t tile_slots, uint32_t *order, uint32_t *ctl) {
+PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint32_t ntiles, uint32_t tile_slots, uint32_t *order, uint32_t *ctl,
+                           unsigned long long *dbg = nullptr) {
   PMA_SHARED ChainTable stb;
   PMA_SHARED unsigned long long nr[kIpMaxTiles / 64], nl[kIpMaxTiles / 64];  // bit b: boundary b|b+1 is NOT "R" / NOT "L"
   PMA_SHARED uint32_t hist[kIpMaxTiles + 1];
   PMA_SHARED uint32_t wtot[kIpOrderThreads / 64];
-  PMA_SHARED uint32_t wsmall[kIpOrderThreads / 64][8];
+  PMA_SHARED uint32_t wsmall[kIpOrderThreads / 64][4];
   {
     const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
     uint32_t *sp = reinterpret_cast<uint32_t *>(&stb);
@@ -97,6 +103,7 @@ PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint
   for (uint32_t i = wv::thread_idx(); i <= ntiles; i += kIpOrderThreads) hist[i] = 0u;
   if (wv::thread_idx() < 8u) ctl[kIpTicketStride * (1u + wv::thread_idx())] = 0u;  // the ticket counters
   wv::block_sync();
+  PMA_TSTAMP(dbg, 11);
   const int lane = wv::lane(), w = wv::wave_in_block();
   const uint64_t j = stb.j, wend = stb.index + stb.len;
   const uint32_t nwords = (ntiles + 63u) / 64u;
@@ -118,6 +125,7 @@ PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint
     }
   }
   wv::block_sync();
+  PMA_TSTAMP(dbg, 12);
   constexpr uint32_t kPer = kIpMaxTiles / kIpOrderThreads;
   uint32_t key[kPer];
 #pragma unroll
@@ -147,11 +155,12 @@ PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint
     }
     key[r] = d_r > d_l ? d_r : d_l;
   }
+  PMA_TSTAMP(dbg, 13);
   // Counting sort by key.  Almost every tile has a tiny key (a window whose elements barely move: 0 or 1 everywhere), so a
   // histogram through LDS atomics is thousands of adds to two or three addresses, served one after the other (11 us of the
   // launch).  Keys below kSmall are counted and ranked with ballots — per wave, combined through a small table — and only
   // the rare larger keys go through atomics.
-  constexpr uint32_t kSmall = 8;
+  constexpr uint32_t kSmall = 4;
   uint32_t wcnt[kSmall];
 #pragma unroll
   for (uint32_t k = 0; k < kSmall; k++) wcnt[k] = 0;
@@ -179,6 +188,7 @@ PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint
     hist[wv::thread_idx()] = run;
   }
   wv::block_sync();
+  PMA_TSTAMP(dbg, 14);
   {  // exclusive scan of hist[0 .. ntiles]
     const uint32_t total = ntiles + 1u, per = (total + kIpOrderThreads - 1u) / kIpOrderThreads;
     const uint32_t lo = wv::thread_idx() * per, hi = lo + per < total ? lo + per : total;
@@ -200,6 +210,7 @@ PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint
     }
   }
   wv::block_sync();
+  PMA_TSTAMP(dbg, 15);
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (uint32_t k = 0; k < kSmall; k++) wcnt[k] = 0;  // (now: how many of this wave's tiles with key k have been placed)
@@ -217,6 +228,8 @@ PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint
     if (valid && key[r] >= kSmall) pos = wv::atomic_add_u32(&hist[key[r]], 1u);
     if (valid) order[pos] = i;
   }
+  wv::block_sync();
+  PMA_TSTAMP(dbg, 16);
 }
 
 
@@ -227,6 +240,7 @@ PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned lon
   // flight together); waves combine through LDS; the prefix is written back while one lane builds the rebalance's exact
   // position table from the grand total (saves a launch).
   PMA_SHARED uint32_t wtot[kTileSumThreads / 64];
+  PMA_TSTAMP(total, 8);
   const int lane = wv::lane(), w = wv::wave_in_block();
   const uint64_t per = (ntiles + kTileSumThreads - 1) / kTileSumThreads;
   const uint64_t lo = (uint64_t)wv::thread_idx() * per;
@@ -247,6 +261,8 @@ PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned lon
     grand += x;
   }
   if (wv::thread_idx() == kTileSumThreads - 1) {  // (this thread's own run is the shortest or empty)
+    // (one serial chain — a division and a true fp64 subtraction per binade the window crosses, 23 for a window that starts
+    //  at slot 0: ~9 us of this launch; run by the whole wave on wave-uniform inputs it measured the same)
     *total = grand;
     if (tb) build_chain_table(tb_index, tb_len, (uint64_t)grand, tb);
   }
@@ -256,9 +272,11 @@ PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned lon
     tilesum[i] = run;
     run += x;
   }
+  PMA_TSTAMP(total, 9);
   if (order != nullptr) {  // in-place window: the order in which its tiles may be taken (needs the scanned sums and the table)
     wv::block_sync();
-    rb_order_body(tilesum, tb, (uint32_t)ntiles, tile_slots, order, ctl);
+    PMA_TSTAMP(total, 10);
+    rb_order_body(tilesum, tb, (uint32_t)ntiles, tile_slots, order, ctl, total);
   }
 }
 PMA_KERNEL void k_scan_apply(const uint32_t *cnt, uint64_t nleaves, const uint32_t *tilesum, uint32_t *rank) {
