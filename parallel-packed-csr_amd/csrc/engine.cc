@@ -95,7 +95,7 @@ struct Engine::Impl {
   // speculative scheduler state
   OptCtl *d_octl = nullptr, *h_octl = nullptr;
   uint32_t *d_vdbg = nullptr;
-  uint32_t *d_opidx = nullptr, *d_status = nullptr, *d_carry0 = nullptr, *d_carry1 = nullptr;
+  uint32_t *d_status = nullptr, *d_carry0 = nullptr, *d_carry1 = nullptr;
   uint64_t carry_cap = 0, hslot_cap = 0;
   unsigned long long *d_regfail = nullptr, *d_pfail = nullptr;
   uint32_t *d_vws = nullptr, *d_vrs = nullptr;  // per-vertex sentinel stamps (capacity n_cap + 1)
@@ -166,6 +166,10 @@ struct Engine::Impl {
   uint64_t bigscratch_cap = 0;
   uint32_t rb_tile = 0;          // leaves per rebalance tile (power of two <= 256); 0 = pick per window
   uint32_t rb_min_tiles = 4096;  // auto tile: shrink the tile until the window has at least this many
+  // o_big (the launch that rebalances the windows a round queues for workgroups) is left out of the rounds while a stream queues
+  // none: a round that does queue one then stops the chunk (OptCtl::need_big), the host runs the launch and keeps it in for a while
+  bool big_on = false;
+  uint32_t big_idle_chunks = 0;
   uint32_t rb_prefetch = 1;  // 1: four chunks in flight per wave, 0: one
   bool time_resize = false;  // resize_bench: time the passes of resize() with events
   double last_resize_ms = 0;
@@ -177,7 +181,6 @@ struct Engine::Impl {
   uint32_t ip_lists = 1;         // ticket lists of the in-place rebalance: the XCD ids seen at creation (k_xcc_probe), else 1
   bool ip_used = false;          // an in-place rebalance ran since the error flag was last looked at
   uint32_t scatter_variant = 2;  // 0: LDS-staged k_scatter_fill, 1: register-run k_scatter_runs, 2: runs + in-tile leaf scan (3 launches)
-  bool carry_dumped = false;
   bool partial = false;
   bool profile = false;  // bracket every round kernel with HIP events on the engine's stream
   bool in_batch = false;  // inside apply_batch_device (which ends with inplace_fault_check)
@@ -435,7 +438,6 @@ Engine::~Engine() {
   if (p.v.vdirty) GPU_DFREE(p.v.vdirty);
   GPU_DFREE(p.d_octl);
   gpu::hfree(p.h_octl);
-  if (p.d_opidx) GPU_DFREE(p.d_opidx);
   if (p.d_status) GPU_DFREE(p.d_status);
   if (p.d_vdbg) GPU_DFREE(p.d_vdbg);
   if (p.d_carry0) GPU_DFREE(p.d_carry0);
@@ -855,24 +857,23 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
   GCHK(ensure_plans(p));
   // per-slot and carry arrays
   if (p.hslot_cap < p.opt_horizon) {
-    if (p.d_opidx) GPU_DFREE(p.d_opidx);
     if (p.d_status) GPU_DFREE(p.d_status);
-    p.d_opidx = p.d_status = nullptr;
+    p.d_status = nullptr;
     p.hslot_cap = 0;
-    GCHK(gpu::dmalloc((void **)&p.d_opidx, ((uint64_t)p.opt_horizon + 8) * sizeof(uint32_t)));  // (+8: padded to the launch grid)
-    GCHK(gpu::dmalloc((void **)&p.d_status, ((uint64_t)p.opt_horizon + 8) * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_status, ((uint64_t)p.opt_horizon + 64) * sizeof(uint32_t)));  // (+64: padded to the launch grids)
     if (p.d_vdbg) GPU_DFREE(p.d_vdbg);
-    GCHK(gpu::dmalloc((void **)&p.d_vdbg, ((uint64_t)p.opt_horizon + 8) * 4 * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_vdbg, ((uint64_t)p.opt_horizon + 64) * 4 * sizeof(uint32_t)));
     p.hslot_cap = p.opt_horizon;
   }
-  const uint64_t carry_need = (uint64_t)std::max<uint64_t>(p.epoch_ops, p.opt_horizon) + 8;  // (padded to the launch grid)
+  // carry lists: by round parity, kStripes sub-lists each (a round's deferred updates can all come from workgroups of one XCD)
+  const uint64_t carry_need = (uint64_t)p.opt_horizon + 8;
   if (p.carry_cap < carry_need) {
     if (p.d_carry0) GPU_DFREE(p.d_carry0);
     if (p.d_carry1) GPU_DFREE(p.d_carry1);
     p.d_carry0 = p.d_carry1 = nullptr;
     p.carry_cap = 0;
-    GCHK(gpu::dmalloc((void **)&p.d_carry0, carry_need * sizeof(uint32_t)));
-    GCHK(gpu::dmalloc((void **)&p.d_carry1, carry_need * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_carry0, kStripes * carry_need * sizeof(uint32_t)));
+    GCHK(gpu::dmalloc((void **)&p.d_carry1, kStripes * carry_need * sizeof(uint32_t)));
     p.carry_cap = carry_need;
   }
   // big-window path: windows of up to kBigLeaves leaves (and big_window slots) stay inside the round
@@ -910,7 +911,6 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     uint64_t e1 = std::min<uint64_t>(e0 + p.cur_epoch, n);
     if (forced_e1 > e0 && forced_e1 < e1) e1 = forced_e1;
     if (p.round > 0xFFFF0000u) GCHK(reset_tags(p));
-    p.carry_dumped = false;
     // rollback point of the epoch: the epoch snapshot catches up with what the previous epoch wrote (dirty tags) — a full
     // copy only the first time and after the array was replaced
     GCHK(snap_commit(p, p.esnap));
@@ -928,31 +928,37 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     }
     OptCtl &c = *p.h_octl;
     memset(&c, 0, sizeof(c));
-    const uint32_t par = (p.round + 1) & 1u;
-    c.carry_n[0] = c.carry_n[1] = 0;
-    c.next_fresh[0] = c.next_fresh[1] = (uint32_t)e0;
+    // the epoch's first round is p.round + 1: the words it reads as "the previous round" describe an empty round that ended at e0
+    const uint32_t pp0 = p.round & 1u;
+    c.hor[pp0] = 0;
+    c.used[pp0] = 0;
+    c.nf[pp0] = (uint32_t)e0;
     c.adaptive = p.adaptive;
-    c.cur_horizon = p.adaptive ? std::min(p.start_horizon, p.opt_horizon) : p.opt_horizon;
-    c.hor[par] = (uint32_t)std::min<uint64_t>(c.cur_horizon, e1 - e0);
+    c.cur_h[pp0] = p.adaptive ? std::min(p.start_horizon, p.opt_horizon) : p.opt_horizon;
+    c.book_round = p.round;  // (nothing to add to the counters for it)
+    for (int t = 0; t < 3; t++) {
+      c.minkept[t] = kMax;
+      c.gbar[t] = c.sbar[t] = ~0ull;
+    }
     c.e1 = (uint32_t)e1;
     c.max_horizon = p.opt_horizon;
     c.width_cap = p.opt_horizon;
     c.resident = p.resident_waves;
-    c.gbar[0] = c.gbar[1] = ~0ull;
-    c.sbar[0] = c.sbar[1] = ~0ull;
     c.viol_idx = kMax;
-    c.skip = kMax;
+    c.skip_idx = kMax;
+    c.skip_round = 0;
     GCHK(gpu::h2d(p.d_octl, p.h_octl, sizeof(OptCtl), p.stream));
     int rs = 0;
     if (p.region_eff < p.region_slots) p.region_eff = p.region_slots;
     while ((p.region_eff >> rs) > (uint32_t)p.v.g.logN) rs++;
     bool epoch_open = true;
-    uint32_t hint_hor = c.hor[par];
+    uint32_t cur_width = c.cur_h[pp0];  // the adapted width the device last reported
+    uint64_t carry_now = 0;            // deferred updates waiting in the carry list
+    unsigned long long jobs_seen = 0;  // OptCtl::jobs_total at the last look
     // tail sizing of the round chunks: updates still pending and updates committed per round (measured on the last chunk)
     uint64_t chunk_pending = e1 - e0;
-    double chunk_cpr = 0.9 * (double)c.hor[par];
+    double chunk_cpr = 0.9 * (double)std::min<uint64_t>(cur_width, e1 - e0);
     unsigned long long prev_rounds = 0, prev_committed = 0;
-    unsigned long long chunk_planned0 = 0, chunk_committed0 = 0;
     uint32_t excl_cooldown = 0;  // chunks to keep short after an exclusive update (the launches behind it in its chunk are wasted)
     while (epoch_open) {
       OptArgs a;
@@ -964,11 +970,11 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       a.bigscratch_stride = bigw;
       a.ops = d_ops;
       a.plans = p.d_plans;
-      a.opidx = p.d_opidx;
       a.status = p.d_status;
       a.vdbg = p.d_vdbg;
       a.carry0 = p.d_carry0;
       a.carry1 = p.d_carry1;
+      a.carry_cap = (uint32_t)p.carry_cap;
       a.ctl = p.d_octl;
       a.stats = p.d_stats;
       a.regfail = p.d_regfail;
@@ -992,10 +998,13 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       // grid: wide enough for the adapted width to grow during the chunk (x1.25 per full-width round), narrow at the tail
       uint32_t gh = p.opt_horizon;
       {
-        const uint64_t want = std::max<uint64_t>(1024, 4ull * (c.cur_horizon ? c.cur_horizon : p.opt_horizon));
+        const uint64_t want = std::max<uint64_t>(1024, 4ull * (cur_width ? cur_width : p.opt_horizon));
         if (want < gh) gh = (uint32_t)want;
         const uint64_t pend = (chunk_pending + 255) & ~255ull;
         if (pend < gh) gh = (uint32_t)std::max<uint64_t>(pend, 256);
+        // (a round plans the whole carry list: the grid is never narrower than it)
+        const uint64_t need = (carry_now + 255) & ~255ull;
+        if (gh < need) gh = (uint32_t)std::min<uint64_t>(need, p.opt_horizon);
       }
       const uint32_t blocks = (gh + 3) / 4;
       if (gh != c.max_horizon) {  // the device must never choose a horizon larger than the launched grid
@@ -1029,8 +1038,12 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         if (p.profile) p.events[5 * r + 2].record(p.stream);
         if (extras) GPU_LAUNCH(p.stream, o_apply_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
         if (p.profile) p.events[5 * r + 3].record(p.stream);
-        GPU_LAUNCH(p.stream, o_compact, 1u + (use_big ? p.big_grid : 0u), 1024, a);  // workgroup 0 compacts, the others rebalance big windows
+        if (use_big && p.big_on) GPU_LAUNCH(p.stream, o_big, p.big_grid, 1024, a);  // the round's queued big-window rebalances (profile: the 'compact' column)
         if (p.profile) p.events[5 * r + 4].record(p.stream);
+      }
+      {  // the last round's outcome, recorded for the host (the next round's o_plan will find the same)
+        a.round = p.round + 1;
+        GPU_LAUNCH(p.stream, o_settle, 1, 64, a);
       }
       GCHK(gpu::d2h(p.h_octl, p.d_octl, sizeof(OptCtl), p.stream));
       GCHK(gpu::sync(p.stream));
@@ -1046,6 +1059,32 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       }
       p.st.round_syncs++;
       if (c.error) return fail(PPCSR_EINTERNAL, "device-side error " + std::to_string(c.error));
+      if (use_big) {  // keep / drop the o_big launch: see Impl::big_on
+        if (c.jobs_total != jobs_seen) {
+          jobs_seen = c.jobs_total;
+          p.big_idle_chunks = 0;
+        } else if (p.big_on && ++p.big_idle_chunks >= 16u) {
+          p.big_on = false;
+        }
+      }
+      if (c.need_big && !c.violation) {
+        // the last round that ran (c.book_round) queued windows and no o_big followed: run it now, forget the launches that
+        // found the flag, go on from the next round with the launch back in
+        const uint32_t R = c.book_round;
+        a.round = R;
+        GPU_LAUNCH(p.stream, o_big, p.big_grid, 1024, a);
+        p.h_octl->need_big = 0;
+        GCHK(gpu::h2d(&p.d_octl->need_big, &p.h_octl->need_big, sizeof(uint32_t), p.stream));
+        GCHK(gpu::sync(p.stream));
+        p.round = R;
+        p.big_on = true;
+        p.big_idle_chunks = 0;
+        const uint32_t np2 = (R + 1u) & 1u;
+        cur_width = c.cur_h[np2];
+        carry_now = c.used[np2];
+        chunk_pending = (uint64_t)c.used[np2] + (uint64_t)(c.e1 - c.nf[np2]);
+        continue;
+      }
       if (p.diag && (c.violation || c.excl || c.done))
         fprintf(stderr, "[ppcsr diag] epoch [%llu,%llu) %s after %llu rounds: committed %llu planned %llu | not committed because: excl-kind %llu, "
                 "behind-barrier %llu, dup %llu, W-W %llu, W-after-R %llu, R-after-W %llu, sentinel-read %llu, sentinel-move %llu, region %llu, "
@@ -1068,7 +1107,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         }
         GCHK(gpu::dset(p.d_dg + 4 * e0, 0, cnt * 4 * sizeof(uint32_t), p.stream));  // (a retried epoch starts its trace over)
       }
-      const uint32_t npar = (p.round + 1) & 1u;
+      // (after o_settle: what the next round would plan, by ITS parity)
+      const uint32_t npar = (c.book_round + 1u) & 1u;
       // An exclusive update runs now, alone, in the middle of the epoch: it is the lowest pending update, so it sees exactly
       // the state sequential execution gives it unless a LATER update was committed earlier on something it reads or
       // writes — validated with the stamps like every other update (k_exclusive, XValid).  Only a resize (double_list /
@@ -1078,7 +1118,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       if (c.excl && !c.violation) {
         const uint64_t g = c.excl_idx;
         bool viol = false;
-        int rc = run_exclusive(Op{0, 0, 0}, 0, d_ops, (uint32_t)g, &viol, &excl_resized, c.maxc > c.excl_idx + 1u);
+        int rc = run_exclusive(Op{0, 0, 0}, 0, d_ops, (uint32_t)g, &viol, &excl_resized, c.excl_later != 0);
         if (rc != PPCSR_OK) return rc;
         if (viol) {
           c.violation = 1;
@@ -1091,8 +1131,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         // repeated failures replay the epoch with the strict prefix rounds
         p.st.rollbacks++;
         if (getenv("PPCSR_TRACE_EPOCH"))
-          fprintf(stderr, "[ppcsr] rollback: epoch [%llu,%llu) viol_idx=%u excl=%u maxc=%u after %llu rounds; kind=%u leaf=%u stamp=%u what=%u wleaf=[%u,%u] index=%u nr=%u\n",
-                  (unsigned long long)e0, (unsigned long long)e1, c.viol_idx, c.excl, c.maxc, c.rounds, c.viol_info[0],
+          fprintf(stderr, "[ppcsr] rollback: epoch [%llu,%llu) viol_idx=%u excl=%u later=%u after %llu rounds; kind=%u leaf=%u stamp=%u what=%u wleaf=[%u,%u] index=%u nr=%u\n",
+                  (unsigned long long)e0, (unsigned long long)e1, c.viol_idx, c.excl, c.excl_later, c.rounds, c.viol_info[0],
                   c.viol_info[1], c.viol_info[2], c.viol_info[3], c.viol_info[4], c.viol_info[5], c.viol_info[6], c.viol_info[7]);
         GCHK(snap_rollback(p, p.esnap, p.snap));
         p.stamps_clean = false;
@@ -1138,25 +1178,27 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         retries = 0;
         epoch_open = false;
       } else if (c.excl) {
-        // the epoch goes on: clear the flag and tell the next round which slot is already done
+        // the epoch goes on.  The launches queued behind the update's discovery did nothing; the next round takes the number
+        // after the last round that ran (c.book_round), finds that round's words as they were, minus the barrier the
+        // exclusive update raised (or it would be discovered again), and commits the update's slot as nothing (K_SKIP)
+        const uint32_t R = c.book_round;
         p.h_octl->excl = 0;
-        p.h_octl->skip = c.excl_idx;
+        p.h_octl->skip_idx = c.excl_idx;
+        p.h_octl->skip_round = R + 1u;
+        p.h_octl->gbar[R % 3u] = ~0ull;
         GCHK(gpu::h2d(&p.d_octl->excl, &p.h_octl->excl, sizeof(uint32_t), p.stream));
-        GCHK(gpu::h2d(&p.d_octl->skip, &p.h_octl->skip, sizeof(uint32_t), p.stream));
+        GCHK(gpu::h2d(&p.d_octl->skip_idx, &p.h_octl->skip_idx, 2 * sizeof(uint32_t), p.stream));
+        GCHK(gpu::h2d(&p.d_octl->gbar[R % 3u], &p.h_octl->gbar[R % 3u], sizeof(unsigned long long), p.stream));
         GCHK(gpu::sync(p.stream));  // (h_octl is the landing buffer of the next chunk's control block)
-        // the launches that were queued behind the exclusive update returned at once: the next round must carry the parity
-        // whose entries the last real round filled in
-        if (((p.round + 1) & 1u) != c.resume_par) p.round++;
-        hint_hor = c.hor[c.resume_par];
-        chunk_pending = (uint64_t)c.carry_n[c.resume_par] + (uint64_t)(c.e1 - c.next_fresh[c.resume_par]);
+        p.round = R;
+        cur_width = c.cur_h[npar];
+        carry_now = c.used[npar];
+        chunk_pending = (uint64_t)c.used[npar] + (uint64_t)(c.e1 - c.nf[npar]);
         excl_cooldown = 4;
       } else if (c.done) {
-        if (getenv("PPCSR_TRACE_EPOCH")) {
-          fprintf(stderr, "[ppcsr] epoch [%llu,%llu) rounds=%llu planned=%llu:", (unsigned long long)e0, (unsigned long long)e1,
-                  c.rounds, c.planned);
-          for (unsigned r = 0; r < 96 && r < c.rounds; r++) fprintf(stderr, " %u/%u", c.hist[2 * r + 1], c.hist[2 * r]);
-          fprintf(stderr, "\n");
-        }
+        if (getenv("PPCSR_TRACE_EPOCH"))
+          fprintf(stderr, "[ppcsr] epoch [%llu,%llu) rounds=%llu planned=%llu committed=%llu\n", (unsigned long long)e0, (unsigned long long)e1, c.rounds,
+                  c.planned, c.committed);
         p.st.rounds += c.rounds;
         p.st.committed += c.committed;
         p.st.planned += c.planned;
@@ -1179,35 +1221,14 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
           p.cur_epoch = (uint32_t)std::min<uint64_t>(p.epoch_ops, 2ull * p.cur_epoch);
           p.epoch_clean = 0;
         }
-        if (c.cur_horizon) p.start_horizon = c.cur_horizon;  // keep the adapted width for the next epoch
+        if (c.cur_h[npar]) p.start_horizon = c.cur_h[npar];  // keep the adapted width for the next epoch
       } else {
-        if (const char *tc = getenv("PPCSR_TRACE_CARRY")) {  // debug: who is stuck?  histogram of src over the carry list
-          const uint32_t cn = c.carry_n[npar];
-          if (c.rounds >= (unsigned long long)atoi(tc) && cn > 0 && !p.carry_dumped) {
-            p.carry_dumped = true;
-            std::vector<uint32_t> idxs(cn);
-            GCHK(gpu::d2h(idxs.data(), npar ? p.d_carry1 : p.d_carry0, cn * sizeof(uint32_t), p.stream));
-            GCHK(gpu::sync(p.stream));
-            std::vector<Op> hops(cn);
-            for (uint32_t i = 0; i < cn; i++) GCHK(gpu::d2h(&hops[i], d_ops + idxs[i], sizeof(Op), p.stream));
-            GCHK(gpu::sync(p.stream));
-            std::map<uint32_t, uint32_t> hist;
-            for (auto &o : hops) hist[o.src]++;
-            std::vector<std::pair<uint32_t, uint32_t>> hv(hist.begin(), hist.end());
-            std::sort(hv.begin(), hv.end(), [](auto &a, auto &b) { return a.second > b.second; });
-            fprintf(stderr, "[ppcsr] carry after %llu rounds: %u stuck updates over %zu sources; top:", c.rounds, cn, hv.size());
-            for (size_t i = 0; i < hv.size() && i < 24; i++) fprintf(stderr, " src%u:%u", hv[i].first, hv[i].second);
-            fprintf(stderr, "\n");
-          }
-        }
-        hint_hor = c.hor[npar];
-        chunk_pending = (uint64_t)c.carry_n[npar] + (uint64_t)(c.e1 - c.next_fresh[npar]);
+        cur_width = c.cur_h[npar];
+        carry_now = c.used[npar];
+        chunk_pending = (uint64_t)c.used[npar] + (uint64_t)(c.e1 - c.nf[npar]);
         if (c.rounds > prev_rounds) chunk_cpr = (double)(c.committed - prev_committed) / (double)(c.rounds - prev_rounds);
         prev_rounds = c.rounds;
         prev_committed = c.committed;
-        if (hint_hor > gh) {
-          // the grid of the next chunk must cover the horizon the device chose
-        }
       }
     }
   }

@@ -22,41 +22,60 @@ namespace ppcsr {
 // failed check raises `violation`: the host restores the epoch snapshot and replays the epoch with the strict prefix
 // rounds above.  K_EXCL updates are barriers: nothing later commits until the exclusive executor has run them.
 // =====================================================================================================================
+// Round r's bookkeeping — how many of round r-1's updates are still pending, the next horizon, the adapted width, is the epoch
+// done, does the lowest pending update need the exclusive executor — is a pure function of words that round r-1's launches left
+// behind, so EVERY wave of o_plan(r) evaluates it for itself (round_begin: two dozen scalar instructions on words it loads with
+// its other control words) and wave 0 alone records the outcome for the later launches and the host.  That replaced a launch of
+// its own per round (o_compact: one workgroup compacting the deferred updates into a sorted carry list, ~10 us of every round).
+// Deferred updates now append THEMSELVES to the carry list (o_apply: one returning atomic per deferred update, on the counter of
+// the XCD it runs on), in no particular order: stream order is carried by the reservation keys, not by the slots, and the one
+// thing the sorted list guaranteed — everything not planned is later than everything planned — holds because a round always plans
+// the WHOLE carry list (the adapted width only limits how many fresh updates join it).
+// Words written during round r and read during round r+1 are indexed r % 3 where round r+1's wave 0 must be able to reset the
+// set of round r+2 while its other waves still read that of round r; by parity where nobody writes what is being read.
+constexpr uint32_t kStripes = 8;  // carry sub-lists (one per XCD id: same-address returning atomics are served one after the other)
 struct OptCtl {
-  uint32_t carry_n[2], next_fresh[2], hor[2];
+  // by round parity (written by wave 0 of that round's o_plan, read by its o_check / o_apply and by the next round's o_plan)
+  uint32_t hor[2];    // updates planned by the round
+  uint32_t used[2];   // ... of which from the carry list (slots [0, used)); fresh ones take the slots behind
+  uint32_t nf[2];     // stream index of the round's first fresh update
+  uint32_t cur_h[2];  // adaptive round width in force (<= max_horizon): grows while most of a round commits, shrinks otherwise
+  // by round % 3 (accumulated during the round; the set of round r+2 is reset by wave 0 of o_plan(r+1))
+  uint32_t kept[3][kStripes];  // deferred updates appended to the carry list, per stripe
+  uint32_t minkept[3];         // smallest stream index among them (kMax: none)
+  unsigned long long gbar[3];  // keyed min index of a K_EXCL update in the horizon
+  unsigned long long sbar[3];  // keyed min index of a SOFT barrier (a planned window close to the exclusive threshold): a word of
+                               // its own — folded into gbar as key + 1 it was indistinguishable from a real K_EXCL key of update idx + 1
+  uint32_t njobs[3];           // big-window rebalances queued by the round's o_apply
   uint32_t e1;  // end of the epoch (exclusive stream index)
   uint32_t violation, excl, done, error;
-  uint32_t max_horizon, excl_idx;  // max_horizon: width of the launched grid (the next round's horizon never exceeds it)
+  uint32_t max_horizon, excl_idx;  // max_horizon: width of the launched grid (a round's horizon never exceeds it)
+  uint32_t excl_later;             // 1: an update later than excl_idx has already been committed in this epoch
   uint32_t width_cap;              // upper bound of the adaptive width (the engine's opt_horizon)
   uint32_t resident;               // waves the chip holds at once (0 = unknown): above it the width moves in whole multiples
-  uint32_t maxc;  // 1 + largest stream index committed in this epoch
   uint32_t viol_idx;  // smallest stream index whose commit-time validation failed
-  uint32_t adaptive;     // 1: adapt cur_horizon to the share of a round that commits (see compact_block)
-  uint32_t cur_horizon;  // adaptive round width (<= max_horizon): grows while most of the round commits, shrinks otherwise
-  unsigned long long gbar[2];  // keyed min index of a K_EXCL update in the horizon
-  unsigned long long sbar[2];  // keyed min index of a SOFT barrier (a planned window close to the exclusive threshold): a word of
-                               // its own — folded into gbar as key + 1 it was indistinguishable from a real K_EXCL key of update
-                               // idx + 1, and o_compact then sent that update to the exclusive executor whatever its kind
-  unsigned long long rounds, committed, planned, blocked, failed;
+  uint32_t adaptive;  // 1: adapt the width to the share of a round that commits (round_begin)
+  uint32_t book_round;  // the last round whose outcome has been added to the counters below (o_settle / a relaunch must not add it twice)
+  uint32_t need_big;        // 1: the last round queued big-window rebalances and no o_big launch followed it (the engine leaves that launch
+                            // out while a stream queues none): the host runs it and goes on
+  uint32_t big_done_round;  // the last round whose queued rebalances an o_big launch has looked at
+  unsigned long long jobs_total;  // big-window rebalances queued so far in this epoch
+  uint32_t skip_idx, skip_round;  // stream index the exclusive executor has just run inside this epoch: in round skip_round its slot commits as nothing
+  unsigned long long rounds, committed, planned;
   uint32_t viol_info[8];  // debug: kind, leaf, stamp, what(1=wstamp on W,2=rstamp on W,3=wstamp on R), wleaf_lo, wleaf_hi, index, round
-  uint32_t hist[192];  // debug: (horizon << 16 | committed) >> of the first rounds of the epoch
   // diagnostics (option "diag"): why planned updates did not commit, first reason found per update
   // 0 exclusive kind, 1 behind a barrier (gbar), 2 duplicate-slot conflicts, 3 write leaf reserved by an earlier writer,
   // 4 write leaf read by an earlier update, 5 read leaf written by an earlier update, 6 sentinel located by is moved earlier,
   // 7 sentinel we move is needed earlier, 8 region prefix, 9 growth zone of a deferred reader/writer (pfail), 10 stamp violation
   unsigned long long why[12];
-  uint32_t njobs[2];  // big-window rebalances queued by this round's o_apply (by round parity; the next round's entry is reset by o_compact)
-  uint32_t jobs_round[2];  // the round that queued them (launches that follow an exclusive / final round must not run them again)
-  uint32_t skip;   // stream index the exclusive executor has just run inside this epoch (kMax: none); its slot commits as nothing
-  uint32_t resume_par;  // round parity whose double-buffered entries (hor / carry_n / next_fresh / carry list) are current: the
-                        // launches queued behind an exclusive update return at once and do not flip them
 };
 struct OptArgs {
   View v;
   const Op *ops;
   Plan *plans;
-  uint32_t *opidx, *status, *vdbg;
-  uint32_t *carry0, *carry1;
+  uint32_t *status, *vdbg;
+  uint32_t *carry0, *carry1;  // by round parity: kStripes sub-lists of carry_cap entries, filled by that round's o_apply
+  uint32_t carry_cap;
   OptCtl *ctl;
   StatShard *stats;
   unsigned long long *regfail;
@@ -80,7 +99,7 @@ struct OptArgs {
 constexpr uint32_t kBigJobs = 256;  // capacity of the round's job queue
 constexpr uint32_t kRegionPadLeaves = 2u;
 constexpr uint32_t kGrowLeaves = 8u;
-constexpr uint32_t OS_PASS = 1u, OS_STAMP_BAD = 2u, OS_COMMITTED = 4u;
+constexpr uint32_t OS_PASS = 1u, OS_STAMP_BAD = 2u;
 
 
 PMA_DEV bool key_earlier(unsigned long long k, uint32_t tag, uint32_t idx) { return (uint32_t)(k >> 32) == tag && (uint32_t)k < idx; }
@@ -100,38 +119,162 @@ using dev::kHeadRanges;
     }                                                                                         \
   } while (0)
 
+// ---- the round's bookkeeping (see OptCtl) -------------------------------------------------------------------------------
+struct RoundState {
+  uint32_t hor, used, nf, ch;    // this round: updates planned, of which from the carry list, first fresh index, width in force
+  uint32_t pre[kStripes + 1];    // exclusive prefix of the previous round's stripe counts (pre[kStripes] = its deferred updates)
+  uint32_t done, excl, excl_idx, excl_later, error, need_big;
+  uint32_t prev_hor, prev_committed, prev_jobs;
+};
+// everything here is wave-uniform (loads from uniform addresses, scalar arithmetic)
+PMA_DEV RoundState round_begin(const OptArgs &a, const OptCtl *c) {
+  const uint32_t r = a.round, pp = (r - 1u) & 1u, pt = (r - 1u) % 3u;
+  const uint32_t p_hor = c->hor[pp], p_used = c->used[pp], p_nf = c->nf[pp], p_ch = c->cur_h[pp];
+  const uint32_t e1 = c->e1, max_h = c->max_horizon, wcap = c->width_cap, res = c->resident, adaptive = c->adaptive;
+  const unsigned long long gb = c->gbar[pt];
+  const uint32_t minkept = c->minkept[pt];
+  const uint32_t p_jobs = c->njobs[pt], big_done = c->big_done_round;
+  RoundState s;
+  uint32_t K = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < kStripes; q++) {
+    s.pre[q] = K;
+    K += c->kept[pt][q];
+  }
+  s.pre[kStripes] = K;
+  const uint32_t ncommitted = p_hor - K;
+  const uint32_t new_nf = p_nf + (p_hor - p_used);
+  // adaptive width: dependency chains bound the number of commits per round (a hot vertex whose range sits at its
+  // density bounds yields a few hundred disjoint windows per round however many updates are planned), so planning far
+  // more than can commit only makes every round slower — but a round's time grows far slower than its width (~30 us
+  // + ~2.5 us per 1024 updates), so width is only given up when almost nothing of it commits.  Narrow by 1/4 when less
+  // than 10 % of a full-width round committed, widen by 1/4 when more than 30 % did.
+  // Above one chip-full of waves (`resident`) only whole multiples make sense (a partly filled second pass costs a
+  // full pass of latency), and a multiple is only worth its re-planning when nearly all of the round commits: up at
+  // > 85 %, back down at < 70 % (config #4's partitions at critical density commit 60-70 % of a chip-full: at twice the
+  // width they lost 5 %; configs #2 / #3 commit 93-97 % and gain 11-12 %).
+  // The width limits how many FRESH updates join a round; the carry list is always planned whole (nothing that waits may
+  // be left without its reservations while later updates commit), so after a narrowing the rounds shrink as the list drains.
+  uint32_t ch = p_ch ? p_ch : wcap;
+  if (adaptive && p_hor >= ch && p_hor > 0u) {  // only full-width rounds carry information about the width
+    if (res && ch >= res) {
+      if (ncommitted * 100u > p_hor * 85u) ch += res;
+      else if (ch > res && ncommitted * 100u < p_hor * 70u) ch -= res;
+      else if (ch == res && ncommitted * 100u < p_hor * 10u) ch -= ch / 4u;
+    } else {
+      if (ncommitted * 100u > p_hor * 30u) ch += ch / 4u;
+      else if (ncommitted * 100u < p_hor * 10u) ch -= ch / 4u;
+      if (res && ch > res) ch = res;
+    }
+  }
+  if (res && ch > res) ch -= ch % res;
+  if (ch < 1024u) ch = 1024u;
+  if (ch > wcap) ch = wcap;
+  const uint32_t avail = e1 - new_nf, room = ch > K ? ch - K : 0u;
+  uint32_t nh = K + (avail < room ? avail : room);
+  if (nh > max_h) nh = max_h;  // (the launched grid; the host keeps it at least as wide as the carry list)
+  s.error = K > max_h ? 1u : 0u;
+  s.hor = nh;
+  s.used = K;
+  s.nf = new_nf;
+  s.ch = ch;
+  s.done = (K == 0u && new_nf == e1) ? 1u : 0u;
+  const uint32_t lowest = K ? minkept : new_nf;
+  const uint32_t tag = (uint32_t)(make_key(r - 1u, 0) >> 32);
+  s.excl = (!s.done && (uint32_t)(gb >> 32) == tag && (uint32_t)gb == lowest) ? 1u : 0u;
+  s.excl_idx = lowest;
+  // every planned update later than the lowest pending one is either still pending (in the carry list) or committed
+  s.excl_later = (K >= 1u && new_nf - lowest - 1u > K - 1u) ? 1u : 0u;
+  s.prev_hor = p_hor;
+  s.prev_committed = ncommitted;
+  s.prev_jobs = p_jobs;
+  s.need_big = (p_hor > 0u && p_jobs > 0u && big_done != r - 1u) ? 1u : 0u;  // (windows queued, and nobody has rebalanced them)
+  return s;
+}
+// by ONE lane of the launch: the outcome for the later launches of round r and for the host; the set of round r+1 reset
+PMA_DEV void round_record(const OptArgs &a, OptCtl *c, const RoundState &s) {
+  const uint32_t r = a.round, par = r & 1u, nt = (r + 1u) % 3u;
+  if (c->book_round != r - 1u) {
+    c->book_round = r - 1u;
+    c->rounds += 1ull;
+    c->committed += (unsigned long long)s.prev_committed;
+    c->planned += (unsigned long long)s.prev_hor;
+    c->jobs_total += (unsigned long long)s.prev_jobs;
+  }
+  c->hor[par] = s.hor;
+  c->used[par] = s.used;
+  c->nf[par] = s.nf;
+  c->cur_h[par] = s.ch;
+#pragma unroll
+  for (uint32_t q = 0; q < kStripes; q++) c->kept[nt][q] = 0u;
+  c->minkept[nt] = kMax;
+  c->gbar[nt] = ~0ull;
+  c->sbar[nt] = ~0ull;
+  c->njobs[nt] = 0u;
+  if (s.error) c->error = 77u;
+  if (s.need_big) {  // (first things first: whatever else the round's outcome is, it is looked at again once the windows are done)
+    c->need_big = 1u;
+    return;
+  }
+  if (s.done) c->done = 1u;
+  if (s.excl) {
+    c->excl_idx = s.excl_idx;
+    c->excl_later = s.excl_later;
+    c->excl = 1u;
+  }
+}
+// end of a chunk of rounds: the last round's outcome recorded (done / excl / counters / the next horizon) for the host, which is
+// about to read the control block; a.round = the round that WOULD come next (its o_plan repeats the evaluation with the same result)
+PMA_KERNEL void o_settle(OptArgs a) {
+  OptCtl *c = a.ctl;
+  if (c->done || c->violation || c->excl || c->error || c->need_big) return;
+  const RoundState s = round_begin(a, c);
+  if (wv::thread_idx() == 0) round_record(a, c, s);
+}
+
 template <bool EXTRAS>
 PMA_DEV void o_plan_t(const OptArgs &a) {
   OptCtl *c = a.ctl;
-  const uint32_t par = a.round & 1u;
+  const uint32_t rt = a.round % 3u;
   // (one wave = one update: the wave's slot and everything that follows from it is the same in all lanes — see wv::uni)
   const uint32_t wid = wv::uni(wv::block_idx() * 4u + (uint32_t)wv::wave_in_block());  // (256-thread workgroups)
-  const uint32_t *carry = par ? a.carry1 : a.carry0;
-  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error, f_skip = c->skip;
-  const uint32_t hor = c->hor[par], cn = c->carry_n[par], nf = c->next_fresh[par];
-  const uint32_t cw = carry[wid];  // (requested with the control block; the carry lists are padded to the launch grid)
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error | c->need_big;
+  const uint32_t skip_idx = c->skip_idx, skip_round = c->skip_round;
   if (f_done || f_viol || f_excl || f_err) return;
+  const RoundState rs = round_begin(a, c);
+  if (wid == 0u && wv::lane() == 0) round_record(a, c, rs);
+  if (rs.done || rs.excl || rs.error || rs.need_big) return;
+  const uint32_t hor = rs.hor, used = rs.used;
   if (wid >= hor) return;
-  const uint32_t used = cn < hor ? cn : hor;
-  const uint32_t idx = wv::uni((wid < used) ? cw : nf + (wid - used));
+  uint32_t idx;
+  if (wid < used) {  // the wid-th deferred update of the previous round: stripe by stripe
+    const uint32_t *carry = ((a.round - 1u) & 1u) ? a.carry1 : a.carry0;
+    uint32_t q = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < kStripes; k++) q += (wid >= rs.pre[k]) ? 1u : 0u;
+    uint32_t base = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kStripes; k++) base = (q == k) ? rs.pre[k] : base;
+    idx = wv::uni(carry[(uint64_t)q * a.carry_cap + (wid - base)]);
+  } else {
+    idx = rs.nf + (wid - used);
+  }
   Op op = a.ops[idx];
   op.src = wv::uni(op.src);
   op.dst = wv::uni(op.dst);
   op.op = wv::uni(op.op);
   Plan *pl = &a.plans[wid];
   const int lane = wv::lane();
-  if (idx == f_skip) {  // executed by the exclusive executor in the middle of this epoch: nothing left to do, commits at once
-    if (lane == 0) a.opidx[wid] = idx;
+  if (a.round == skip_round && idx == skip_idx) {  // executed by the exclusive executor in the middle of this epoch: nothing left to do, commits at once
     dev::store_plan_header(pl, K_SKIP, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, idx, op);
     return;
   }
   // the plan record goes to memory for o_check / o_apply; this kernel reserves straight from the registers
   const dev::PlanRegs pr = dev::plan_op(a.v, op, pl, idx);
-  if (lane == 0) a.opidx[wid] = idx;
   const unsigned long long key = make_key(a.round, idx);
   const uint32_t kind = pr.kind;
   if (kind == K_EXCL) {
-    if (lane == 0) wv::atomic_min_u64(&c->gbar[par], key);
+    if (lane == 0) wv::atomic_min_u64(&c->gbar[rt], key);
     return;
   }
   if (kind == K_DUP) {
@@ -145,7 +288,7 @@ PMA_DEV void o_plan_t(const OptArgs &a) {
     // slots): its window keeps growing while it waits behind a hot range, and everything committed around it meanwhile
     // is a candidate for a rollback
     if ((pr.wlen >= a.soft_barrier || (a.defer_barrier && wid < used && pr.wlen >= a.defer_barrier)) && lane == 0) {
-      wv::atomic_min_u64(&c->sbar[par], key);
+      wv::atomic_min_u64(&c->sbar[rt], key);
     }
     const uint32_t ml = pr.mv_lo, mh = pr.mv_hi;
     for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_min_u64(&a.v.vw[u], key);
@@ -325,9 +468,9 @@ PMA_KERNEL void o_check_x(OptArgs a) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
   const uint32_t wid = wv::uni(wv::block_idx() * 4u + (uint32_t)wv::wave_in_block());
-  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error | c->need_big;
   const uint32_t hor = c->hor[par];
-  const unsigned long long gbar = c->gbar[par], sbar = c->sbar[par];
+  const unsigned long long gbar = c->gbar[a.round % 3u], sbar = c->sbar[a.round % 3u];
   const Plan *pl = &a.plans[wid];
   const PlanHead h = dev::load_plan_head(pl);
   if (f_done || f_viol || f_excl || f_err) return;
@@ -359,9 +502,9 @@ PMA_KERNEL void o_check(OptArgs a) {
   const int lane = wv::lane();
   const uint32_t slot = wv::block_idx() * kCkThreads + wv::thread_idx();  // this LANE's horizon slot
   const uint32_t wave_slot0 = wv::uni(slot - (uint32_t)lane);
-  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error | c->need_big;
   const uint32_t hor = c->hor[par];
-  const unsigned long long gbar = c->gbar[par], sbar = c->sbar[par];
+  const unsigned long long gbar = c->gbar[a.round % 3u], sbar = c->sbar[a.round % 3u];
   // my record's first 112 bytes: header (20 words) + read ranges 0 .. 3 — requested WITH the control words, before the early exits
   // (the record array is padded to the launch grid)
   const uint4 *rec = reinterpret_cast<const uint4 *>(&a.plans[slot]);
@@ -586,22 +729,23 @@ PMA_KERNEL void o_check(OptArgs a) {
 
 // EXTRAS = false: the opt-in experiments (chains, zones) and the diagnostics are compiled out — carried along as run-time
 // branches they cost the calm stream 4 % (config #2: 179 vs 187 M updates/s); the engine launches the *_x kernels when one is on
+// returns the stream index of an update of this round that did NOT commit (it goes to the carry list), kMax otherwise
 template <bool EXTRAS>
-PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
+PMA_DEV uint32_t o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
   const uint32_t wid = wv::uni(wv::block_idx() * 4u + (uint32_t)wv::wave_in_block());
   const int lane = wv::lane();
-  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
+  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error | c->need_big;
   const uint32_t hor = c->hor[par];
   const uint32_t st = wv::uni(a.status[wid]);
   const Plan *pl = &a.plans[wid];
   const PlanHead h = dev::load_plan_head(pl);
   const uint32_t idx = h.idx;
   const Op op = h.op;
-  if (f_done || f_viol || f_excl || f_err) return;
-  if (wid >= hor) return;
-  if (!(st & OS_PASS)) return;
+  if (f_done || f_viol || f_excl || f_err) return kMax;
+  if (wid >= hor) return kMax;
+  if (!(st & OS_PASS)) return idx;
   const uint32_t kind = h.kind;
   const unsigned long long key = make_key(a.round, idx);
   const uint32_t tag = (uint32_t)(key >> 32);
@@ -642,7 +786,7 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
       }
     }
     if (any_r || any_p) {  // an earlier update of this region was deferred: keep stream order inside it
-      return;
+      return idx;
     }
   }
   if (st & OS_STAMP_BAD) {
@@ -661,18 +805,17 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
         c->viol_info[7] = h.nr;
       }
     }
-    return;
+    return idx;
   }
   // a window too large for one wave goes to a workgroup of o_big: take a queue slot BEFORE touching the state (a full queue
   // leaves the update pending for the next round)
   dev::BigJob *job = nullptr;
   if (kind_strong(kind) && h.wlen > a.big_min && a.jobs) {
     uint32_t slot = 0;
-    if (lane == 0) slot = wv::atomic_add_u32(&c->njobs[par], 1u);
+    if (lane == 0) slot = wv::atomic_add_u32(&c->njobs[a.round % 3u], 1u);
     slot = wv::first(slot);
-    if (slot >= kBigJobs) return;
+    if (slot >= kBigJobs) return idx;
     job = &a.jobs[slot];
-    if (lane == 0) c->jobs_round[par] = a.round;
   }
 #if defined(PPCSR_SIM)
   if (lane == 0 && getenv("PPCSR_TRACE"))
@@ -693,188 +836,51 @@ PMA_DEV void o_apply_wave(const OptArgs &a, uint32_t *lds_wave) {
       for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_max_u32(&a.vws[u], me1);
     }
   }
-  if (lane == 0) a.status[wid] = OS_COMMITTED;  // (the epoch's max committed index is reduced in o_compact: a
-                                                // per-update atomicMax on one word would serialise the whole round)
+  return kMax;
 }
 
 
-// stable compaction of the deferred updates into the next carry list + next round's bookkeeping
-// ONE workgroup; everything it needs is requested in one batch of independent loads (control block, then each thread's
-// run of statuses and indices), because at ~6 K entries this step is nothing but load latency.
-// kC: 64-slot chunks per wave held in registers (covers a horizon of kC * blockDim).  wsum: 16 words of LDS, s_first_p: 1.
-template <uint32_t kC>
-PMA_DEV void compact_block(const OptArgs &a, uint32_t *wsum, uint32_t *s_first_p) {
+// The updates of this round that did not commit append themselves to the round's carry list: one returning atomic per
+// WORKGROUP that has any (its waves' indices meet in LDS), on the counter of the XCD the workgroup runs on.
+PMA_DEV void carry_append(const OptArgs &a, uint32_t keep, uint32_t *s_keep /* [4] */) {
+  if (wv::lane() == 0) s_keep[wv::wave_in_block()] = keep;
+  wv::block_sync();
+  if (wv::thread_idx() != 0) return;
   OptCtl *c = a.ctl;
-  const uint32_t par = a.round & 1u;
-  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error;
-  const uint32_t hor = c->hor[par], cn = c->carry_n[par], nf = c->next_fresh[par];
-  const uint32_t cur_h = c->cur_horizon, max_h = c->max_horizon, wcap = c->width_cap, adaptive = c->adaptive, e1 = c->e1;
-  const unsigned long long gb = c->gbar[par];
-  const unsigned long long n_rounds = c->rounds, n_committed = c->committed, n_planned = c->planned;
-  if (f_done || f_viol || f_excl || f_err) return;
-  const uint32_t used = cn < hor ? cn : hor;
-  const uint32_t *cin = par ? a.carry1 : a.carry0;
-  uint32_t *cout = par ? a.carry0 : a.carry1;
-  const uint32_t tid = wv::thread_idx(), bd = wv::block_dim();
-  const int lane = wv::lane(), w = wv::wave_in_block();
-  const uint32_t nw = bd >> 6;
-  // Every wave owns a run of consecutive 64-slot chunks (lane l of chunk c: slot wbase + 64 c + l, so every load and every
-  // store is coalesced — with a run of consecutive slots per THREAD the 2 x kC loads of a wave touched 64 lines each, and
-  // at 18 K entries one CU's address path made this 15 us); a ballot per chunk counts and ranks, the waves' totals go
-  // through LDS.
-  const uint32_t cpw = (hor + nw * 64u - 1u) / (nw * 64u);  // chunks per wave
-  const uint32_t wbase = (uint32_t)w * cpw * 64u;
-  const uint64_t lt = (1ull << lane) - 1ull;
-  uint32_t wkeep = 0, mymaxc = 0;
-  uint32_t st[kC], oi[kC];
-  const bool regs = cpw <= kC;
-  if (regs) {
+  uint32_t v[4], n = 0, m = kMax;
 #pragma unroll
-    for (uint32_t q = 0; q < kC; q++) {
-      const uint32_t sl = wbase + q * 64u + (uint32_t)lane;
-      const bool in = q < cpw && sl < hor;
-      st[q] = in ? a.status[sl] : OS_COMMITTED;
-      oi[q] = in ? a.opidx[sl] : 0u;
-    }
-#pragma unroll
-    for (uint32_t q = 0; q < kC; q++) {
-      if (q >= cpw) break;  // (wave-uniform)
-      const bool in = wbase + q * 64u + (uint32_t)lane < hor;
-      wkeep += (uint32_t)wv::popc64(wv::ballot(in && !(st[q] & OS_COMMITTED)));
-      if (in && (st[q] & OS_COMMITTED) && oi[q] + 1u > mymaxc) mymaxc = oi[q] + 1u;
-    }
-  } else {
-    for (uint32_t q = 0; q < cpw; q++) {
-      const uint32_t sl = wbase + q * 64u + (uint32_t)lane;
-      const bool in = sl < hor;
-      const uint32_t s1 = in ? a.status[sl] : OS_COMMITTED, x = in ? a.opidx[sl] : 0u;
-      wkeep += (uint32_t)wv::popc64(wv::ballot(in && !(s1 & OS_COMMITTED)));
-      if (in && (s1 & OS_COMMITTED) && x + 1u > mymaxc) mymaxc = x + 1u;
+  for (int w = 0; w < 4; w++) {
+    const uint32_t x = s_keep[w];
+    if (x != kMax) {
+      v[n++] = x;
+      m = x < m ? x : m;
     }
   }
-  if (lane == 0) wsum[w] = wkeep;
-  if (tid == 0) *s_first_p = kMax;
-  wv::block_sync();
-  uint32_t woff = 0, tot = 0;
-  for (uint32_t q = 0; q < nw; q++) {
-    if (q < (uint32_t)w) woff += wsum[q];
-    tot += wsum[q];
+  if (n == 0) return;
+  const uint32_t rt = a.round % 3u, stripe = wv::xcc_id() % kStripes;
+  const uint32_t base = wv::atomic_add_u32(&c->kept[rt][stripe], n);
+  if (base + n > a.carry_cap) {
+    c->error = 78u;
+    return;
   }
-  uint32_t o = woff;
-  if (regs) {
-#pragma unroll
-    for (uint32_t q = 0; q < kC; q++) {
-      if (q >= cpw) break;
-      const bool keep = wbase + q * 64u + (uint32_t)lane < hor && !(st[q] & OS_COMMITTED);
-      const uint64_t m = wv::ballot(keep);
-      if (keep) {
-        const uint32_t pos = o + (uint32_t)wv::popc64(m & lt);
-        if (pos == 0) *s_first_p = oi[q];
-        cout[pos] = oi[q];
-      }
-      o += (uint32_t)wv::popc64(m);
-    }
-  } else {
-    for (uint32_t q = 0; q < cpw; q++) {
-      const uint32_t sl = wbase + q * 64u + (uint32_t)lane;
-      const bool in = sl < hor;
-      const uint32_t s1 = in ? a.status[sl] : OS_COMMITTED, x = in ? a.opidx[sl] : 0u;
-      const bool keep = in && !(s1 & OS_COMMITTED);
-      const uint64_t m = wv::ballot(keep);
-      if (keep) {
-        const uint32_t pos = o + (uint32_t)wv::popc64(m & lt);
-        if (pos == 0) *s_first_p = x;
-        cout[pos] = x;
-      }
-      o += (uint32_t)wv::popc64(m);
-    }
-  }
-  const uint32_t ncommitted = hor - tot;
-  const uint32_t kept = tot;
-  {  // one atomic per wave: a thousand same-address atomics would serialise in L2 for longer than the rest of this kernel
-    uint32_t wmax = mymaxc;
-    for (int o2 = 32; o2 > 0; o2 >>= 1) {
-      const uint32_t y = wv::shfl(wmax, lane ^ o2);
-      wmax = y > wmax ? y : wmax;
-    }
-    if (lane == 0 && wmax) wv::atomic_max_u32(&c->maxc, wmax);
-  }
-  for (uint32_t i = used + tid; i < cn; i += bd) {  // carry entries beyond the horizon
-    const uint32_t x = cin[i];
-    if (kept + (i - used) == 0) *s_first_p = x;
-    cout[kept + (i - used)] = x;
-  }
-  wv::block_sync();
-  if (tid == 0) {
-    const uint32_t new_cn = kept + (cn - used);
-    const uint32_t new_nf = nf + (hor - used);
-    // adaptive width: dependency chains bound the number of commits per round (a hot vertex whose range sits at its
-    // density bounds yields a few hundred disjoint windows per round however many updates are planned), so planning far
-    // more than can commit only makes every round slower — but a round's time grows far slower than its width (~30 us
-    // + ~2.5 us per 1024 updates), so width is only given up when almost nothing of it commits.  Narrow by 1/4 when less
-    // than 10 % of a full-width round committed, widen by 1/4 when more than 30 % did.
-    // Above one chip-full of waves (`resident`) only whole multiples make sense (a partly filled second pass costs a
-    // full pass of latency), and a multiple is only worth its re-planning when nearly all of the round commits: up at
-    // > 85 %, back down at < 70 % (config #4's partitions at critical density commit 60-70 % of a chip-full: at twice the
-    // width they lost 5 %; configs #2 / #3 commit 93-97 % and gain 11-12 %).
-    uint32_t ch = cur_h ? cur_h : wcap;
-    const uint32_t res = c->resident;
-    if (adaptive && hor >= ch) {  // only full-width rounds carry information about the width
-      if (res && ch >= res) {
-        if (ncommitted * 100u > hor * 85u) ch += res;
-        else if (ch > res && ncommitted * 100u < hor * 70u) ch -= res;
-        else if (ch == res && ncommitted * 100u < hor * 10u) ch -= ch / 4u;
-      } else {
-        if (ncommitted * 100u > hor * 30u) ch += ch / 4u;
-        else if (ncommitted * 100u < hor * 10u) ch -= ch / 4u;
-        if (res && ch > res) ch = res;
-      }
-    }
-    if (res && ch > res) ch -= ch % res;
-    if (ch < 1024u) ch = 1024u;
-    if (ch > wcap) ch = wcap;  // (the launch grid — max_h — bounds the next round below, not the adapted width itself: the
-                               // host narrows the grid at the tail of an epoch)
-    c->cur_horizon = ch;
-    uint32_t nh = new_cn + (e1 - new_nf);
-    if (nh > ch) nh = ch;
-    if (nh > max_h) nh = max_h;
-    c->carry_n[par ^ 1u] = new_cn;
-    c->next_fresh[par ^ 1u] = new_nf;
-    c->hor[par ^ 1u] = nh;
-    c->gbar[par ^ 1u] = ~0ull;
-    c->gbar[par] = ~0ull;
-    c->sbar[par ^ 1u] = ~0ull;
-    c->sbar[par] = ~0ull;
-    c->njobs[par ^ 1u] = 0;
-    c->skip = kMax;
-    const bool done = (new_cn == 0 && new_nf == e1);
-    if (done) c->done = 1;
-    const uint32_t lowest = new_cn ? *s_first_p : new_nf;
-    const uint32_t tag = (uint32_t)(make_key(a.round, 0) >> 32);
-    c->resume_par = par ^ 1u;
-    if (!done && (uint32_t)(gb >> 32) == tag && (uint32_t)gb == lowest) {
-      c->excl = 1;
-      c->excl_idx = lowest;
-    }
-    if (n_rounds < 96) {
-      c->hist[2 * n_rounds] = hor;
-      c->hist[2 * n_rounds + 1] = ncommitted;
-    }
-    c->rounds = n_rounds + 1ull;
-    c->committed = n_committed + (unsigned long long)ncommitted;
-    c->planned = n_planned + (unsigned long long)hor;
-  }
+  uint32_t *out = ((a.round & 1u) ? a.carry1 : a.carry0) + (uint64_t)stripe * a.carry_cap + base;
+  for (uint32_t i = 0; i < n; i++) out[i] = v[i];
+  if (m < c->minkept[rt]) wv::atomic_min_u32(&c->minkept[rt], m);  // (the word only ever goes down: a stale read costs one atomic)
 }
 
 // (Forcing 8 waves per SIMD — __launch_bounds__(256, 8) on o_plan / o_apply, a 256-slot LDS tile — for 8192-wide rounds was
 // measured again in round 2: 56 / 44 B of scratch per lane and 113-123 M updates/s against 141 at 6 waves per SIMD.)
 PMA_KERNEL void o_apply(OptArgs a) {
   PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
-  o_apply_wave<false>(a, lds[wv::wave_in_block()]);
+  PMA_SHARED uint32_t s_keep[4];
+  const uint32_t keep = o_apply_wave<false>(a, lds[wv::wave_in_block()]);
+  carry_append(a, keep, s_keep);
 }
 PMA_KERNEL void o_apply_x(OptArgs a) {
   PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
-  o_apply_wave<true>(a, lds[wv::wave_in_block()]);
+  PMA_SHARED uint32_t s_keep[4];
+  const uint32_t keep = o_apply_wave<true>(a, lds[wv::wave_in_block()]);
+  carry_append(a, keep, s_keep);
 }
 
 // (Folding the compaction into o_apply's last-finishing workgroup was measured and dropped: the device-scope fences the
@@ -892,25 +898,21 @@ PMA_KERNEL void k_block_rebalance(View v, uint64_t wstart, uint64_t wlen, Edge *
   dev::redistribute_block(v, wstart, wlen, scratch, sh);
 }
 
-// Workgroup 0: the compaction.  Workgroups 1 .. : the round's queued big-window rebalances, one workgroup per window
-// (dev::redistribute_block) — independent of the compaction (they only finish the rebalance of updates that have already
-// been committed), so they share its launch instead of paying a kernel boundary of their own.
-PMA_KERNEL void o_compact(OptArgs a) {
-  PMA_SHARED uint32_t wsum[16];
-  PMA_SHARED uint32_t s_first;
+// The round's queued big-window rebalances, one workgroup per window (dev::redistribute_block): they finish the rebalance of
+// updates that have already been committed, and must be done before the next round plans.  A launch of its own since the
+// compaction it used to share one with is gone: the engine leaves it out while a stream queues no windows (see run_speculative).
+PMA_KERNEL void o_big(OptArgs a) {
   PMA_SHARED dev::BigShared sh;
-  if (wv::block_idx() == 0) {
-    compact_block<24>(a, wsum, &s_first);  // (24 x 1024 threads: rounds up to 24576 wide stay in registers)
-    return;
-  }
   OptCtl *c = a.ctl;
-  const uint32_t par = a.round & 1u;
-  // (NOT c->done / c->excl: workgroup 0 sets them during this very launch.  A violation rolls the epoch back anyway.)
-  const uint32_t f_viol = c->violation, f_err = c->error;
-  uint32_t nj = c->njobs[par];
-  if (f_viol || f_err || nj == 0 || c->jobs_round[par] != a.round) return;
+  const uint32_t f_viol = c->violation, f_err = c->error, booked = c->book_round;
+  uint32_t nj = c->njobs[a.round % 3u];
+  // did round a.round run?  Inside a chunk the last round recorded is the one before it; launched by the host after a chunk
+  // (need_big) it is a.round itself; the launches queued behind a finished epoch / an exclusive update carry later numbers
+  if (f_viol || f_err || (booked != a.round && booked + 1u != a.round)) return;
+  if (wv::block_idx() == 0 && wv::thread_idx() == 0) c->big_done_round = a.round;
+  if (nj == 0) return;
   if (nj > kBigJobs) nj = kBigJobs;
-  const uint32_t nwg = wv::grid_dim() - 1u, me = wv::block_idx() - 1u;
+  const uint32_t nwg = wv::grid_dim(), me = wv::block_idx();
   for (uint32_t jb = me; jb < nj; jb += nwg) {
     const dev::BigJob job = a.jobs[jb];
     dev::redistribute_block(a.v, job.wstart, job.wlen, a.bigscratch + (uint64_t)me * a.bigscratch_stride, sh);
