@@ -21,7 +21,7 @@ int capi_dev_free(void *p);
 int capi_d2h_sync(void *dst, const void *src, size_t bytes);  // on the NULL stream, after whatever it holds
 int capi_h2d_sync(void *dst, const void *src, size_t bytes);
 int capi_dev_memset(void *p, int byte, size_t bytes, void *stream);
-#if !defined(PPCSR_SIM)
+// the carrier of the owner exchange: RCCL in the product (engine.cc); tests/hostsim provides a shared-memory one for the emulator
 struct ppcsr_xchg;
 int capi_xchg_unique_id(void *out128, std::string *err);
 int capi_xchg_create(const void *id128, int nranks, int rank, int device, ppcsr_xchg **out, std::string *err);
@@ -30,7 +30,6 @@ int capi_xchg_ranks(ppcsr_xchg *x, int *nranks, int *rank, int *device, void **s
 int capi_xchg_sendrecv(ppcsr_xchg *x, uint64_t nseg, const void *const *sptr, const uint64_t *sbytes, const int *speer, void *const *rptr,
                        const uint64_t *rbytes, const int *rpeer);
 const char *capi_xchg_error(ppcsr_xchg *x);
-#endif
 
 static thread_local std::string g_last_error;
 
@@ -650,7 +649,6 @@ int pppcsr_xchg_bulk_build(pppcsr_xchg_t x) { return xchg_finish(x, PARTS_BULK);
 }  // extern "C"
 
 // ---- the RCCL carrier: grouped ncclSend / ncclRecv on a HIP stream, no torch in the data path ----
-#if !defined(PPCSR_SIM)
 struct pppcsr_comm {
   ppcsr_xchg *t = nullptr;     // communicator + stream (engine.cc)
   pppcsr_xchg *x = nullptr;    // staging for the PPPCSR it was last used with
@@ -807,16 +805,6 @@ int pppcsr_exchange_set_num_neighbors(pppcsr_t h, pppcsr_comm_t c, const ppcsr_o
 }
 int pppcsr_exchange_bulk_build(pppcsr_t h, pppcsr_comm_t c, const ppcsr_op *d_adds, uint64_t n) { return exchange_run(h, c, d_adds, n, PARTS_BULK); }
 }  // extern "C"
-#else
-extern "C" {
-int pppcsr_comm_unique_id(void *) { return bad("no RCCL in the CPU emulator build"); }
-int pppcsr_comm_create(const void *, int, int, int, pppcsr_comm_t *) { return bad("no RCCL in the CPU emulator build"); }
-int pppcsr_comm_destroy(pppcsr_comm_t) { return 0; }
-int pppcsr_exchange_apply(pppcsr_t, pppcsr_comm_t, const ppcsr_op *, uint64_t) { return bad("no RCCL in the CPU emulator build"); }
-int pppcsr_exchange_set_num_neighbors(pppcsr_t, pppcsr_comm_t, const ppcsr_op *, uint64_t) { return bad("no RCCL in the CPU emulator build"); }
-int pppcsr_exchange_bulk_build(pppcsr_t, pppcsr_comm_t, const ppcsr_op *, uint64_t) { return bad("no RCCL in the CPU emulator build"); }
-}  // extern "C"
-#endif
 
 extern "C" {
 // ---- repartitioning (the reference only sketches it: PCSR.h:91-112 was never implemented) ----

@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "sim_runtime.h"
+extern int g_sim_fail_alloc;  // (tests/hostsim/sim_xchg.cpp: failure injection, the n-th device allocation from now fails)
 namespace gpu {
 typedef int stream_t;
 inline const char *err_str(int) { return "sim error"; }
@@ -20,7 +21,14 @@ inline int device_cus(int, int *n) { *n = 0; return 0; }  // (the emulator has n
 inline int stream_create(stream_t *s) { *s = 0; return 0; }
 inline stream_t stream_from_ptr(void *) { return 0; }
 inline int stream_destroy(stream_t) { return 0; }
-inline int dmalloc(void **p, size_t b) { *p = ::malloc(b ? b : 1); return *p ? 0 : 2; }
+inline int dmalloc(void **p, size_t b) {
+  if (g_sim_fail_alloc > 0 && --g_sim_fail_alloc == 0) {
+    *p = nullptr;
+    return 2;
+  }
+  *p = ::malloc(b ? b : 1);
+  return *p ? 0 : 2;
+}
 inline int dfree(void *p) { ::free(p); return 0; }
 inline int dfree_named(void *p, const char *, int) { ::free(p); return 0; }
 inline int hmalloc(void **p, size_t b) { *p = ::malloc(b ? b : 1); return *p ? 0 : 2; }

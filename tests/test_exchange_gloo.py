@@ -256,3 +256,83 @@ def test_native_exchange_and_repartition_world2_hostsim(n_global, n_parts):
         oi, on = parts[k].state()
         items, nodes = flat(2)[k]
         assert np.array_equal(items, oi) and np.array_equal(nodes, on), f"partition {k}: updates after the repartition"
+
+
+# ---- world 8, one partition per rank (the config #4 layout): pppcsr_exchange_apply itself, past one rank --------------------------
+# The emulator build carries the exchange over a shared-memory mailbox (tests/hostsim/sim_xchg.cpp) in place of RCCL: everything
+# in capi.cc's exchange_run — bucketing, the counts step, the status step, the rows, the per-partition apply, and what every rank
+# does when ONE rank fails — is the code the GPU runs.
+def _worker_exchange_run(rank, world, uid, n_global, blocks, q):
+    import ctypes
+    from helpers import load_pkg
+    from test_sim_engine import SIM_SO
+    pkg = load_pkg()
+    lib = pkg.load_library(SIM_SO)
+    lib.ppcsr_sim_fail_alloc_after.argtypes = [ctypes.c_int]
+    pp = pkg.PPPCSR(n_global, numDomain=world, partitionsPerDomain=1, lib=lib, local=(rank, 1, 0))
+    _sim_tune(pp, [rank])
+    pp.comm_create(uid, world, rank, 0)
+    log = []
+    for step, blk in enumerate(blocks[rank]):
+        kind, rows = blk
+        buf = np.ascontiguousarray(rows)
+        ptr, n = (buf.ctypes.data if len(buf) else 0), len(buf)
+        if kind == "bad_bucketing":   # a null block of non-zero length: this rank's bucketing fails before anything collective
+            ptr, n = 0, 5
+        if kind == "bad_layout":      # the receive buffers cannot be laid out (the next device allocation fails) after the counts step
+            lib.ppcsr_sim_fail_alloc_after(1)
+        try:
+            pp.exchange_apply(ptr, n)
+            log.append("ok")
+        except pkg.PpcsrError as e:
+            log.append("error: " + str(e)[:160])
+        lib.ppcsr_sim_fail_alloc_after(0)
+    q.put((rank, log, pp.partition(rank).state()))
+
+
+def test_exchange_apply_world8_one_partition_per_rank_and_failing_ranks():
+    from oracle_lib import OraclePPPCSR
+    from helpers import load_pkg
+    from test_sim_engine import SIM_SO, build_sim
+    build_sim()
+    pkg = load_pkg()
+    lib = pkg.load_library(SIM_SO)
+    streams = load_streams()
+    world, n_global = 8, 1003
+    sizes = [[900, 0, 700, 400], [0, 1200, 1, 400], [350, 350, 0, 400], [1, 0, 0, 400], [800, 10, 900, 400], [0, 0, 0, 400], [600, 600, 600, 400],
+             [77, 1500, 300, 400]]  # ragged and empty blocks, four good steps
+    good = [[streams.random_stream(n_global, sizes[r][k], seed=300 + 11 * k + r, p_delete=0.25) for k in range(4)] for r in range(world)]
+    # step order: good, good, [rank 3's bucketing fails], good, [rank 6 cannot lay out its receive buffers], good
+    blocks = []
+    for r in range(world):
+        b = [("good", good[r][0]), ("good", good[r][1]), ("bad_bucketing" if r == 3 else "good", streams.random_stream(n_global, 50, seed=900 + r)),
+             ("good", good[r][2]), ("bad_layout" if r == 6 else "good", streams.random_stream(n_global, 60 if r == 6 else 3000, seed=950 + r)), ("good", good[r][3])]
+        # (rank 6's own block is small — its send buffer is big enough already — and what the others send it is more than it has
+        #  ever received: the one allocation of its step is the receive buffer's)
+        blocks.append(b)
+    uid = pkg.PPPCSR.comm_unique_id(lib)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_exchange_run, args=(r, world, uid, n_global, blocks, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, log, st = q.get(timeout=900)
+        got[r] = (log, st)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        log = got[r][0]
+        assert [x == "ok" for x in log] == [True, True, False, True, False, True], (r, log)  # EVERY rank reports both failed batches — nobody hangs
+    assert "null ops" in got[3][0][2] and "peer rank failed to bucket" in got[0][0][2]
+    assert "memory" in got[6][0][4] and "could not lay out" in got[1][0][4]
+    # the failed batches moved nothing anywhere; the good ones arrived in global stream order per partition
+    pp = OraclePPPCSR(n_global, True, world, 1)
+    for k in range(4):
+        pp.apply(np.concatenate([good[r][k] for r in range(world)]))
+    for r in range(world):
+        oi, on = pp.partition(r).state()
+        items, nodes = got[r][1]
+        assert np.array_equal(items, oi) and np.array_equal(nodes, on), f"partition {r}"

@@ -17,13 +17,13 @@ CSRC = os.path.join(ROOT, "parallel-packed-csr_amd", "csrc")
 
 
 def build_sim():
-    srcs = [os.path.join(SIM_DIR, "ppcsr_sim.cpp"), os.path.join(SIM_DIR, "sim_runtime.cpp")]
+    srcs = [os.path.join(SIM_DIR, "ppcsr_sim.cpp"), os.path.join(SIM_DIR, "sim_runtime.cpp"), os.path.join(SIM_DIR, "sim_xchg.cpp")]
     deps = srcs + [os.path.join(SIM_DIR, "sim_runtime.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC)
                                                              if f.endswith((".h", ".cc"))]
     if os.path.exists(SIM_SO) and os.path.getmtime(SIM_SO) >= max(os.path.getmtime(d) for d in deps):
         return
     subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-ffp-contract=off", "-Wno-unknown-pragmas", "-fPIC", "-shared",
-                    "-I" + SIM_DIR, "-I" + CSRC] + srcs + ["-o", SIM_SO], check=True)
+                    "-I" + SIM_DIR, "-I" + CSRC] + srcs + ["-lrt", "-o", SIM_SO], check=True)
 
 
 @pytest.fixture(scope="module")
