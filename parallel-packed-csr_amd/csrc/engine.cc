@@ -169,7 +169,12 @@ struct Engine::Impl {
   // o_big (the launch that rebalances the windows a round queues for workgroups) is left out of the rounds while a stream queues
   // none: a round that does queue one then stops the chunk (OptCtl::need_big), the host runs the launch and keeps it in for a while
   bool big_on = false;
-  uint32_t big_idle_chunks = 0;
+  double big_rate = 0;
+  // o_check: a lane per update while updates have short footprints (one leaf, two or three read ranges); a wave per update for
+  // streams where more than ~1 in 64 has a long one (hot ranges, critical density: big windows, many-level climbs, runs of moved
+  // sentinels), which the lane kernel leaves to its wave one by one
+  bool check_lanes = true;
+  uint32_t check_wave_chunks = 0;
   uint32_t rb_prefetch = 1;  // 1: four chunks in flight per wave, 0: one
   bool time_resize = false;  // resize_bench: time the passes of resize() with events
   double last_resize_ms = 0;
@@ -954,7 +959,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
     bool epoch_open = true;
     uint32_t cur_width = c.cur_h[pp0];  // the adapted width the device last reported
     uint64_t carry_now = 0;            // deferred updates waiting in the carry list
-    unsigned long long jobs_seen = 0;  // OptCtl::jobs_total at the last look
+    unsigned long long jobs_seen = 0, rounds_seen = 0, planned_seen = 0, long_seen = 0;  // OptCtl counters at the last look
     // tail sizing of the round chunks: updates still pending and updates committed per round (measured on the last chunk)
     uint64_t chunk_pending = e1 - e0;
     double chunk_cpr = 0.9 * (double)std::min<uint64_t>(cur_width, e1 - e0);
@@ -1034,7 +1039,9 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         if (extras) GPU_LAUNCH(p.stream, o_plan_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_plan, blocks, 256, a);
         if (p.profile) p.events[5 * r + 1].record(p.stream);
         // (o_check: a LANE per update, one wave per workgroup; the diagnostics build keeps a wave per update)
-        if (extras) GPU_LAUNCH(p.stream, o_check_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_check, (gh + kCkThreads - 1) / kCkThreads, kCkThreads, a);
+        if (extras) GPU_LAUNCH(p.stream, o_check_x, blocks, 256, a);
+        else if (p.check_lanes) GPU_LAUNCH(p.stream, o_check, (gh + kCkThreads - 1) / kCkThreads, kCkThreads, a);
+        else GPU_LAUNCH(p.stream, o_check_w, blocks, 256, a);
         if (p.profile) p.events[5 * r + 2].record(p.stream);
         if (extras) GPU_LAUNCH(p.stream, o_apply_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
         if (p.profile) p.events[5 * r + 3].record(p.stream);
@@ -1059,13 +1066,28 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       }
       p.st.round_syncs++;
       if (c.error) return fail(PPCSR_EINTERNAL, "device-side error " + std::to_string(c.error));
-      if (use_big) {  // keep / drop the o_big launch: see Impl::big_on
-        if (c.jobs_total != jobs_seen) {
-          jobs_seen = c.jobs_total;
-          p.big_idle_chunks = 0;
-        } else if (p.big_on && ++p.big_idle_chunks >= 16u) {
-          p.big_on = false;
+      {  // which o_check for the next chunk: see Impl::check_lanes.  The lane kernel counts what it had to leave to the wave
+         // (each such update costs its wave a serial ~5 us): above ~1 in 64 a wave per update from the start is faster.  From the
+         // wave kernel the way back is a trial chunk every so often.
+        const unsigned long long dp = c.planned - planned_seen, dl = c.long_checks - long_seen;
+        planned_seen = c.planned;
+        long_seen = c.long_checks;
+        if (p.check_lanes) {
+          if (dp >= 1024 && dl * 64ull > dp) {
+            p.check_lanes = false;
+            p.check_wave_chunks = 0;
+          }
+        } else if (++p.check_wave_chunks >= 24u) {
+          p.check_lanes = true;
         }
+      }
+      if (use_big) {  // keep / drop the o_big launch: see Impl::big_on.  Kept while a stream queues a window every few rounds (an
+                      // empty launch costs ~4 us, a round that finds none where it needs one costs the rest of its chunk)
+        const unsigned long long dj = c.jobs_total - jobs_seen, dr = c.rounds - rounds_seen;
+        jobs_seen = c.jobs_total;
+        rounds_seen = c.rounds;
+        if (dr) p.big_rate = 0.5 * p.big_rate + 0.5 * (double)dj / (double)dr;  // queued windows per round, running mean
+        p.big_on = p.big_rate >= 1.0 / 12.0;
       }
       if (c.need_big && !c.violation) {
         // the last round that ran (c.book_round) queued windows and no o_big followed: run it now, forget the launches that
@@ -1077,8 +1099,6 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         GCHK(gpu::h2d(&p.d_octl->need_big, &p.h_octl->need_big, sizeof(uint32_t), p.stream));
         GCHK(gpu::sync(p.stream));
         p.round = R;
-        p.big_on = true;
-        p.big_idle_chunks = 0;
         const uint32_t np2 = (R + 1u) & 1u;
         cur_width = c.cur_h[np2];
         carry_now = c.used[np2];

@@ -60,6 +60,7 @@ struct OptCtl {
                             // out while a stream queues none): the host runs it and goes on
   uint32_t big_done_round;  // the last round whose queued rebalances an o_big launch has looked at
   unsigned long long jobs_total;  // big-window rebalances queued so far in this epoch
+  unsigned long long long_checks; // updates the lane-per-update o_check left to the wave (long footprints) so far in this epoch
   uint32_t skip_idx, skip_round;  // stream index the exclusive executor has just run inside this epoch: in round skip_round its slot commits as nothing
   unsigned long long rounds, committed, planned;
   uint32_t viol_info[8];  // debug: kind, leaf, stamp, what(1=wstamp on W,2=rstamp on W,3=wstamp on R), wleaf_lo, wleaf_hi, index, round
@@ -463,8 +464,11 @@ PMA_DEV void o_check_one(const OptArgs &a, OptCtl *c, uint32_t par, uint32_t wid
 #undef PMA_WHY
 #undef PMA_WHYB
 
-// wave per update (the diagnostics build: every reason counted, the blocker traced)
-PMA_KERNEL void o_check_x(OptArgs a) {
+// wave per update: the diagnostics build (o_check_x: every reason counted, the blocker traced), and the plain build for streams
+// whose updates have LONG footprints (o_check_w: big windows, many-level climbs, runs of moved sentinels — a hot vertex' range) —
+// the lane-per-update kernel below hands those to the wave one after the other, which is slower than a wave each from the start
+template <bool EXTRAS>
+PMA_DEV void o_check_wave(const OptArgs &a) {
   OptCtl *c = a.ctl;
   const uint32_t par = a.round & 1u;
   const uint32_t wid = wv::uni(wv::block_idx() * 4u + (uint32_t)wv::wave_in_block());
@@ -475,8 +479,10 @@ PMA_KERNEL void o_check_x(OptArgs a) {
   const PlanHead h = dev::load_plan_head(pl);
   if (f_done || f_viol || f_excl || f_err) return;
   if (wid >= hor) return;
-  o_check_one<true>(a, c, par, wid, h, pl, gbar, sbar);
+  o_check_one<EXTRAS>(a, c, par, wid, h, pl, gbar, sbar);
 }
+PMA_KERNEL void o_check_x(OptArgs a) { o_check_wave<true>(a); }
+PMA_KERNEL void o_check_w(OptArgs a) { o_check_wave<false>(a); }
 
 // LANE per update (the default).  Checking an update is a dozen independent loads and compares — reservation keys and stamps of
 // the one or two leaves it writes, of the two or three it reads, of the sentinels around them — and, for the few that fail,
@@ -696,6 +702,7 @@ PMA_KERNEL void o_check(OptArgs a) {
   if (active && !complex) a.status[slot] = (fail ? 0u : OS_PASS) | (stamp_bad ? OS_STAMP_BAD : 0u);
   // the long ones, by the whole wave, one after the other
   uint64_t todo = wv::ballot(complex);
+  if (todo && lane == 0) wv::atomic_add_u64(&c->long_checks, (unsigned long long)wv::popc64(todo));  // (the engine picks the kernel by this share)
   while (todo) {
     const int l = wv::ctz64(todo);
     todo &= todo - 1ull;
