@@ -420,7 +420,7 @@ def main():
             kern = {"plan": p1["prof_plan_ms"], "check": p1["prof_check_ms"], "apply": p1["prof_apply_ms"], "compact": p1["prof_compact_ms"]}
             spec = args.mode != 0
             names = {"plan": "o_plan" if spec else "k_plan", "check": "o_check" if spec else "k_check",
-                     "apply": "o_apply" if spec else "k_apply", "compact": "o_compact"}
+                     "apply": "o_apply" if spec else "k_apply", "compact": "o_big"}
             dom = max(kern, key=kern.get)
             d = {k: p1[k] - p0[k] for k in ("redistribute_slots", "ops_applied")}
             # algorithmic bytes: 12 B op record + 24 B per slot of every redistribute() the reference makes

@@ -175,6 +175,7 @@ struct Engine::Impl {
   // sentinels), which the lane kernel leaves to its wave one by one
   bool check_lanes = true;
   uint32_t check_wave_chunks = 0;
+  int check_force = -1;  // option "check_lanes": -1 by the share of long footprints (default), 0 always a wave per update, 1 always a lane
   uint32_t rb_prefetch = 1;  // 1: four chunks in flight per wave, 0: one
   bool time_resize = false;  // resize_bench: time the passes of resize() with events
   double last_resize_ms = 0;
@@ -604,6 +605,10 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "rb_inplace_min") {
     p.rb_inplace_min = value < 0 ? 0ull : (uint64_t)value;
+    return PPCSR_OK;
+  }
+  if (k == "check_lanes") {
+    p.check_force = value < 0 ? -1 : (value ? 1 : 0);
     return PPCSR_OK;
   }
   if (k == "rb_bench_upper") {
@@ -1040,7 +1045,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         if (p.profile) p.events[5 * r + 1].record(p.stream);
         // (o_check: a LANE per update, one wave per workgroup; the diagnostics build keeps a wave per update)
         if (extras) GPU_LAUNCH(p.stream, o_check_x, blocks, 256, a);
-        else if (p.check_lanes) GPU_LAUNCH(p.stream, o_check, (gh + kCkThreads - 1) / kCkThreads, kCkThreads, a);
+        else if (p.check_force >= 0 ? p.check_force == 1 : p.check_lanes) GPU_LAUNCH(p.stream, o_check, (gh + kCkThreads - 1) / kCkThreads, kCkThreads, a);
         else GPU_LAUNCH(p.stream, o_check_w, blocks, 256, a);
         if (p.profile) p.events[5 * r + 2].record(p.stream);
         if (extras) GPU_LAUNCH(p.stream, o_apply_x, blocks, 256, a); else GPU_LAUNCH(p.stream, o_apply, blocks, 256, a);
@@ -1060,7 +1065,7 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
           p.st.prof_plan_ms += gpu::Event::elapsed_ms(p.events[5 * r + 0], p.events[5 * r + 1]);
           p.st.prof_check_ms += gpu::Event::elapsed_ms(p.events[5 * r + 1], p.events[5 * r + 2]);
           p.st.prof_apply_ms += gpu::Event::elapsed_ms(p.events[5 * r + 2], p.events[5 * r + 3]);
-          p.st.prof_compact_ms += gpu::Event::elapsed_ms(p.events[5 * r + 3], p.events[5 * r + 4]);
+          if (use_big && p.big_on) p.st.prof_compact_ms += gpu::Event::elapsed_ms(p.events[5 * r + 3], p.events[5 * r + 4]);  // (o_big, when it is in)
           p.st.prof_launches += 1;
         }
       }
@@ -1094,9 +1099,9 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
         // found the flag, go on from the next round with the launch back in
         const uint32_t R = c.book_round;
         a.round = R;
-        GPU_LAUNCH(p.stream, o_big, p.big_grid, 1024, a);
         p.h_octl->need_big = 0;
-        GCHK(gpu::h2d(&p.d_octl->need_big, &p.h_octl->need_big, sizeof(uint32_t), p.stream));
+        GCHK(gpu::h2d(&p.d_octl->need_big, &p.h_octl->need_big, sizeof(uint32_t), p.stream));  // (first: o_big stands back while a flag is up)
+        GPU_LAUNCH(p.stream, o_big, p.big_grid, 1024, a);
         GCHK(gpu::sync(p.stream));
         p.round = R;
         const uint32_t np2 = (R + 1u) & 1u;

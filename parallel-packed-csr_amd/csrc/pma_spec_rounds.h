@@ -911,11 +911,12 @@ PMA_KERNEL void k_block_rebalance(View v, uint64_t wstart, uint64_t wlen, Edge *
 PMA_KERNEL void o_big(OptArgs a) {
   PMA_SHARED dev::BigShared sh;
   OptCtl *c = a.ctl;
-  const uint32_t f_viol = c->violation, f_err = c->error, booked = c->book_round;
+  const uint32_t f_viol = c->violation, f_err = c->error, f_done = c->done, f_excl = c->excl, f_need = c->need_big;
   uint32_t nj = c->njobs[a.round % 3u];
-  // did round a.round run?  Inside a chunk the last round recorded is the one before it; launched by the host after a chunk
-  // (need_big) it is a.round itself; the launches queued behind a finished epoch / an exclusive update carry later numbers
-  if (f_viol || f_err || (booked != a.round && booked + 1u != a.round)) return;
+  // did round a.round run?  The launches queued behind a finished epoch / an exclusive update / a round waiting for this very
+  // launch find a flag up and must not touch anything — least of all big_done_round: the round that takes their number later
+  // would look served.  (Launched by the host for a waiting round, it comes after the host has lowered need_big.)
+  if (f_viol || f_err || f_done || f_excl || f_need) return;
   if (wv::block_idx() == 0 && wv::thread_idx() == 0) c->big_done_round = a.round;
   if (nj == 0) return;
   if (nj > kBigJobs) nj = kBigJobs;

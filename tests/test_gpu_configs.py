@@ -8,13 +8,20 @@
   one that holds 44 % of the edges) and partition 3 with permuted labels (it owns the second-hottest Zipf vertex), the
   latter also under config #5's 10 M-update Zipf stream.
 The partitions of a PPPCSR are independent PCSRs, so one partition against the oracle at full size is the full-size
-check of that partition in the 8-GPU run; bench.py checks all resident partitions after its timed region as well."""
+check of that partition in the 8-GPU run; bench.py checks all resident partitions after its timed region as well.
+
+* EVERY partition of configs #4 / #5 (raw and permuted labels) and configs #2 / #3 once more, by digest: sha256(geometry, items[],
+  nodes[]) of the engine's state against tests/golden/config_digests.json, which holds the digests of the states the REAL
+  reference produced (tests/golden/make_config_digests.py, run in the build container where /root/reference exists) — no
+  100 M-edge CPU replay on the GPU box, and the comparison is with the reference itself, not its restatement."""
+import json
+import os
 import time
 
 import numpy as np
 import pytest
 
-from helpers import load_pkg
+from helpers import GOLDEN, digest, load_pkg
 from oracle_lib import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -107,7 +114,8 @@ def _partition_subsequence(streams, s, d, part, permute):
     return streams.adds(s[m] - np.uint32(part * ps), d[m])
 
 
-@pytest.mark.parametrize("labels,part", [("raw", 0), ("permuted", 3)])
+# (slot by slot against the oracle for ONE partition — it says where a difference is; the digests below cover all sixteen)
+@pytest.mark.parametrize("labels,part", [("permuted", 3)])
 def test_config4_one_partition_full_size(pkg, streams, graph4, labels, part):
     cs, cd, us, ud = graph4
     permute = labels == "permuted"
@@ -136,6 +144,74 @@ def test_config4_one_partition_full_size(pkg, streams, graph4, labels, part):
         _branch(eng, o, zupd, f"config #5 partition {part} (permuted): its share of the 10 M Zipf(1.2) updates")
     o.close()
     eng.close()
+
+
+# ---- every configuration, every partition, against digests held by the real reference --------------------------------------------
+def _digests():
+    return json.load(open(os.path.join(GOLDEN, "config_digests.json")))["digests"]
+
+
+def _dg(eng):
+    return digest(*eng.state(), eng.geometry())
+
+
+def test_configs_2_3_zipf_digests_of_the_reference(pkg, streams):
+    want = _digests()
+    n = 1 << 20
+    s, d = streams.rmat_edges(20, 10_000_000, seed=1)
+    core = streams.adds(s, d)
+    eng = pkg.PCSR(n)
+    eng.apply(core)
+    assert _dg(eng) == want["config2_core"], "state after the 10 M-edge core load"
+    eng.snapshot()
+    s2, d2 = streams.rmat_edges(20, 1_000_000, seed=2)
+    fresh = streams.adds(s2, d2)
+    zipf = streams.adds(streams.zipf_sources(n, 1_000_000, seed=4, alpha=1.2), streams.uniform_ints(11, 1_000_000, n))
+    for key, ops in (("config2_inserts", fresh), ("config3_mixed", streams.mixed_existing_stream(core, fresh[:500_000], seed=3)),
+                     ("config5_shape_zipf", zipf)):
+        eng.restore()
+        eng.apply(ops)
+        assert _dg(eng) == want[key], key
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def graph4_all(streams, graph4):
+    """config #4 / #5 inputs with raw and permuted labels (the permutation applied once for all partitions)"""
+    cs, cd, us, ud = graph4
+    zs, zd = streams.zipf_sources(N4, UPD4, seed=4, alpha=1.2), streams.uniform_ints(11, UPD4, N4)
+    raw = {"cs": cs, "cd": cd, "us": us, "ud": ud, "zs": zs, "zd": zd}
+    perm = {k: streams.permute_labels(v, N4) for k, v in raw.items()}
+    return {"raw": raw, "permuted": perm}
+
+
+def _sub(streams, s, d, part):
+    ps = N4 // P4
+    m = np.minimum(s // np.uint32(ps), P4 - 1) == part
+    return streams.adds(s[m] - np.uint32(part * ps), d[m])
+
+
+@pytest.mark.parametrize("labels", ["permuted", "raw"])
+def test_config4_and_5_every_partition_digests_of_the_reference(pkg, streams, graph4_all, labels):
+    want = _digests()
+    g = graph4_all[labels]
+    ps = N4 // P4
+    t0 = time.time()
+    for part in range(P4):
+        size = ps if part < P4 - 1 else N4 - part * ps
+        core = _sub(streams, g["cs"], g["cd"], part)
+        eng = pkg.PCSR(size)
+        eng.apply(core)
+        assert _dg(eng) == want[f"config4_{labels}_p{part}_core"], f"partition {part} ({labels}) after its core subsequence ({len(core)} edges)"
+        eng.snapshot()
+        eng.apply(_sub(streams, g["us"], g["ud"], part))
+        assert _dg(eng) == want[f"config4_{labels}_p{part}_inserts"], f"config #4 partition {part} ({labels}) after its share of the 10 M inserts"
+        if labels == "permuted":  # config #5: the partition's share of the 10 M Zipf(1.2) updates, from the same core
+            eng.restore()
+            eng.apply(_sub(streams, g["zs"], g["zd"], part))
+            assert _dg(eng) == want[f"config5_{labels}_p{part}_zipf"], f"config #5 partition {part} ({labels})"
+        eng.close()
+        print(f"partition {part} ({labels}): ok after {time.time() - t0:.0f} s", flush=True)
 
 
 def test_bench_two_ranks_on_one_gpu():

@@ -6,9 +6,11 @@
 #   3. rocprofv3 --pmc WRITE_SIZE              -> HBM written bytes per dispatch
 # bench.py --markers launches empty marker kernels (k_mark_0..7) around (i) the timed rounds, (ii) full-array rebalances,
 # (iii) half-array rebalances, (iv) one neighbour scan; tools/roofline_summary.py cuts those sections out of all three passes
-# and writes gpurun_out/roofline/r03_roofline.json (copy it to profiles/).
+# and writes gpurun_out/roofline/${ROUND}_roofline.json (copy it to profiles/).  ROUND defaults to r04; PPCSR_COMMIT (the box has no
+# .git) is recorded as the commit the record was measured on.
 set -o pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROUND="${ROUND:-r04}"
 OUT="$ROOT/gpurun_out/roofline"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -24,8 +26,8 @@ T=$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1)
 S=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
 F=$(find "$OUT/fetch" -name "*counter_collection.csv" | head -1)
 W=$(find "$OUT/write" -name "*counter_collection.csv" | head -1)
-python3 tools/roofline_summary.py "$T" "$F" "$W" "$OUT/bench_trace.json" "$OUT/r03_roofline.json" "python3 $ARGS" || exit 1
-[ -n "$S" ] && cp "$S" "$OUT/r03_kernel_stats.csv"
+python3 tools/roofline_summary.py "$T" "$F" "$W" "$OUT/bench_trace.json" "$OUT/${ROUND}_roofline.json" "python3 $ARGS" || exit 1
+[ -n "$S" ] && cp "$S" "$OUT/${ROUND}_kernel_stats.csv"
 # the raw per-dispatch files are large: keep only the summaries under gpurun_out/
 rm -rf "$OUT/trace" "$OUT/fetch" "$OUT/write"
 ls -la "$OUT"

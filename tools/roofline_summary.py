@@ -77,15 +77,17 @@ def main():
     derived = OrderedDict()
     # (i) timed rounds: the dominant kernel against the algorithmic bytes of the updates it planned / applied
     tr = res["timed_rounds"]["kernels"]
-    rk = [k for k in ("o_plan", "o_check", "o_apply", "o_compact") if k in tr]
+    rk = [k for k in ("o_plan", "o_check", "o_check_w", "o_apply", "o_big", "o_settle", "o_compact") if k in tr]
     if rk:
         alg_per_update = bj["roofline"]["alg_bytes_per_update"] if bj.get("roofline") else None
         updates = bj["config"]["updates_per_step"] * bj["steps"]
         dom = max(rk, key=lambda k: tr[k]["total_ms"])
         launches = tr[dom]["launches"]
         alg_launch = alg_per_update * updates / launches if alg_per_update else None
-        round_us = sum(tr[k]["avg_us"] for k in rk)
-        hbm_round = sum(tr[k].get("hbm_bytes_per_launch") or 0.0 for k in rk)
+        # per round: every kernel weighted by how often it ran per o_plan launch (o_settle: once per chunk; o_big: only while a stream queues windows)
+        nplan = max(tr["o_plan"]["launches"], 1) if "o_plan" in tr else launches
+        round_us = sum(tr[k]["total_ms"] * 1e3 for k in rk) / nplan
+        hbm_round = sum((tr[k].get("hbm_bytes_per_launch") or 0.0) * tr[k]["launches"] for k in rk) / nplan
         derived["timed_rounds"] = {"dominant_kernel": dom, "launches": launches, "avg_us": tr[dom]["avg_us"], "alg_bytes_per_launch": alg_launch,
                                    "achieved_GBps": alg_launch / (tr[dom]["avg_us"] * 1e-6) / 1e9 if alg_launch else None,
                                    "frac_of_8TBps": alg_launch / (tr[dom]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK if alg_launch else None,
