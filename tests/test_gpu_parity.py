@@ -24,6 +24,8 @@ MODES = {
     "speculative": dict(mode=1, small_batch=0),  # (small_batch=0: even tiny batches go through the speculative rounds)
     "speculative-small": dict(mode=1, opt_horizon=1024, epoch_ops=4096, region_slots=256, small_batch=0),
     "default": dict(),  # engine defaults: speculative rounds, batches of <= 256 updates through the strict rounds
+    # round 4: the wave-per-update o_check forced (by default the engine picks it for streams with long footprints)
+    "wave-check": dict(mode=1, small_batch=0, check_lanes=0, opt_horizon=2048),
 }
 
 
