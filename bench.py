@@ -232,33 +232,72 @@ def main():
 
     def preflight_native():
         """ragged blocks (one of them a single row) through both carriers into two small PPPCSRs; True when every local partition
-        agrees bit for bit on every rank"""
+        agrees bit for bit on every rank.  Every step that holds a collective is followed by an agreement (all-reduce MIN of "I am
+        fine"): a rank that failed locally never leaves its peers alone inside a collective of the NEXT step — all ranks stop
+        together and take the torch carrier."""
         n_small = 512 * P
-        ok, why = 1, ""
+        state = {"ok": 1, "why": ""}
+        objs = {"a": None, "b": None}
+
+        def agree():
+            flag = torch.tensor([state["ok"]], dtype=torch.int32, device=xdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+
+        def step(fn):
+            """run fn unless this rank has already failed; returns True when EVERY rank is still fine"""
+            if state["ok"]:
+                try:
+                    fn()
+                except Exception as ex:  # noqa: BLE001 — any failure of the native carrier selects the other one
+                    state["ok"], state["why"] = 0, f"{type(ex).__name__}: {ex}"
+            return agree()
+
+        def create():
+            objs["a"] = pkg.PPPCSR(n_small, numDomain=N, partitionsPerDomain=ppr, local=(rank * ppr, ppr, dev_id))
+            objs["b"] = pkg.PPPCSR(n_small, numDomain=N, partitionsPerDomain=ppr, local=(rank * ppr, ppr, dev_id))
+
         try:
-            a = pkg.PPPCSR(n_small, numDomain=N, partitionsPerDomain=ppr, local=(rank * ppr, ppr, dev_id))
-            b = pkg.PPPCSR(n_small, numDomain=N, partitionsPerDomain=ppr, local=(rank * ppr, ppr, dev_id))
-            a.comm_create(new_uid(), N, rank, dev_id)
+            good = step(create)
+            uid = [None]
+            if good:  # (the id itself: a broadcast every rank takes part in, whatever rank 0 managed)
+                try:
+                    uid[0] = new_uid()
+                except Exception as ex:  # noqa: BLE001
+                    state["ok"], state["why"] = 0, f"{type(ex).__name__}: {ex}"
+                good = agree()
+            if good:
+                good = step(lambda: objs["a"].comm_create(uid[0], N, rank, dev_id))  # (ncclCommInitRank: collective)
             for k in range(3):
+                if not good:
+                    break
                 m = [4096, 1 if (rank + k) % 2 else 3000, 257][k]
                 blk = streams.random_stream(n_small, m, seed=1000 + 17 * k + rank, p_delete=0.3)
                 t = to_dev(blk)
                 torch.cuda.synchronize()
-                a.exchange_apply(t.data_ptr(), m)
-                keep = torch_exchange_apply(b, t, n_small, cap=4096)
-                del keep
-            for q in range(ppr):
-                ea, eb = a.partition(rank * ppr + q), b.partition(rank * ppr + q)
-                sa, sb = ea.state(), eb.state()
-                if ea.geometry() != eb.geometry() or not (np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])):
-                    ok, why = 0, f"partition {rank * ppr + q} differs between the carriers"
-            a.close()
-            b.close()
-        except Exception as ex:  # noqa: BLE001 — any failure of the native carrier selects the other one
-            ok, why = 0, f"{type(ex).__name__}: {ex}"
-        flag = torch.tensor([ok], dtype=torch.int32, device=xdev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return bool(flag.item()), why
+                # (pppcsr_exchange_apply reports a failing rank on every rank — its steps stay collective — so the agreement after
+                #  it is about what it returned; the torch carrier's all_to_all follows only when all ranks got through)
+                good = step(lambda: objs["a"].exchange_apply(t.data_ptr(), m))
+                if good:
+                    good = step(lambda: torch_exchange_apply(objs["b"], t, n_small, cap=4096))
+
+            def compare():
+                for q in range(ppr):
+                    ea, eb = objs["a"].partition(rank * ppr + q), objs["b"].partition(rank * ppr + q)
+                    sa, sb = ea.state(), eb.state()
+                    if ea.geometry() != eb.geometry() or not (np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])):
+                        raise RuntimeError(f"partition {rank * ppr + q} differs between the carriers")
+
+            if good:
+                good = step(compare)
+        finally:
+            for o in objs.values():
+                if o is not None:
+                    try:
+                        o.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+        return good, state["why"]
 
     if N > 1 and args.exchange != "torch":
         if args.backend != "nccl":
@@ -572,15 +611,24 @@ def main():
                                               "runs": {k: {"threads": v["threads"], "updates_per_s_mean": v["updates_per_s_mean"],
                                                            "updates_per_s_std": v["updates_per_s_std"], "repetitions": v["repetitions"]}
                                                        for k, v in pj.get("runs", {}).items()}}
+                    # The live measurement stays cpu_baseline.value.  The recorded thread sweep is attached beside it and says whether
+                    # it was taken on a host like this one (CPU model and CPUs online): a record from another machine is marked stale.
+                    def _cpu_model():
+                        try:
+                            for ln in open("/proc/cpuinfo"):
+                                if ln.startswith("model name"):
+                                    return ln.split(":", 1)[1].strip()
+                        except Exception:  # noqa: BLE001
+                            pass
+                        return None
+                    same = (pj.get("cpu_model") == _cpu_model()) and (pj.get("cores_available_to_this_process") == cores)
+                    cpu["reference_pools"]["same_host_class"] = bool(same)
+                    if not same:
+                        cpu["reference_pools"]["stale"] = (f"recorded on '{pj.get('cpu_model')}' with {pj.get('cores_available_to_this_process')} CPUs, "
+                                                           f"this host is '{_cpu_model()}' with {cores}")
                     if best:
-                        cpu["one_thread_sequential"] = cpu["value"]
-                        cpu["value"] = pj["runs"][best]["updates_per_s_mean"]
-                        cpu["cores"] = pj["runs"][best]["threads"]
-                        cpu["kind"] = "reference"
-                        cpu["sample"] = (f"reference CLI -pppcsrnuma -partitions_per_domain=8 -threads={cpu['cores']} on this workload's text files "
-                                         f"(core = phase 1, untimed; first update batch = phase 2), mean of {pj['runs'][best]['repetitions']} runs, "
-                                         f"recorded by tools/cpu_baseline_protocol.py in {os.path.relpath(ppath, ROOT)}; live in this run: "
-                                         + cpu["sample"])
+                        cpu["reference_pools"]["best_updates_per_s"] = pj["runs"][best]["updates_per_s_mean"]
+                        cpu["reference_pools"]["best_threads"] = pj["runs"][best]["threads"]
                 except Exception as e:
                     cpu["reference_pools_error"] = str(e)
         ref_cli = os.path.join(ROOT, "oracle", "_ref", "ref_cli")
