@@ -160,7 +160,6 @@ struct Engine::Impl {
   // speculative rounds: windows up to big_window slots stay inside the round; those above big_min are rebalanced by a
   // workgroup each (o_big, big_grid workgroups, one scratch stretch of big_window slots per workgroup)
   uint32_t big_window = 32768, big_min = 512, big_grid = 64;
-  Plan *d_xplan = nullptr;  // read ranges of an exclusive update inside a speculative epoch (validation)
   dev::BigJob *d_jobs = nullptr;
   Edge *d_bigscratch = nullptr;
   uint64_t bigscratch_cap = 0;
@@ -468,7 +467,6 @@ Engine::~Engine() {
   if (p.d_scratch) GPU_DFREE(p.d_scratch);
   if (p.d_scan_state) GPU_DFREE(p.d_scan_state);
   if (p.d_jobs) GPU_DFREE(p.d_jobs);
-  if (p.d_xplan) GPU_DFREE(p.d_xplan);
   if (p.d_bigscratch) GPU_DFREE(p.d_bigscratch);
   if (p.d_dg) GPU_DFREE(p.d_dg);
   for (Impl::Snap *sp : {&p.snap, &p.esnap}) {
@@ -1265,7 +1263,6 @@ int Engine::run_exclusive(Op op, uint32_t flags, const Op *d_ops, uint32_t spec_
   if (violation) *violation = false;
   if (resized) *resized = false;
   const bool spec = spec_index != kMax;
-  if (spec && !p.d_xplan) GCHK(gpu::dmalloc((void **)&p.d_xplan, sizeof(Plan)));
   bool counted = false;  // exclusive_ops counts executed updates: not the attempts, not a run that is rolled back
   auto count_once = [&]() {
     if (!counted) p.st.exclusive_ops++;
@@ -1276,7 +1273,6 @@ int Engine::run_exclusive(Op op, uint32_t flags, const Op *d_ops, uint32_t spec_
     xv.wstamp = p.d_wstamp;
     xv.rstamp = p.d_rstamp;
     xv.vws = p.d_vws;
-    xv.scratch_plan = p.d_xplan;
     xv.me1 = (spec && attempt == 0) ? spec_index + 1u : 0u;  // (a retry follows a doubling: whole-array rule, see the caller)
     const auto tx0 = std::chrono::steady_clock::now();
     GPU_LAUNCH(p.stream, k_exclusive, 1, 64, p.v, op, d_ops, spec ? spec_index : kMax, flags, p.d_xout, p.d_stats, p.excl_in_wave, xv);

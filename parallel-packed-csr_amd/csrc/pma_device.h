@@ -55,8 +55,13 @@ PMA_DEV uint32_t lanemask_lt_count(uint64_t m, int lane) { return (uint32_t)wv::
 PMA_DEV uint32_t count_leaves(const View &v, uint32_t leaf_lo, uint32_t nleaves) {
   if (nleaves == 1) return v.leafcnt[leaf_lo];
   uint32_t s = 0;
+  // (nleaves is wave-uniform: a scalar trip count, the tail masked by a select instead of a per-lane loop)
 #pragma unroll 1  // (batching these loads by unrolling costs the planning kernel 6 -> 4 waves per SIMD: 76 -> 104 VGPRs)
-  for (uint32_t i = (uint32_t)wv::lane(); i < nleaves; i += 64) s += v.leafcnt[leaf_lo + i];
+  for (uint32_t base = 0; base < nleaves; base += 64) {
+    const uint32_t i = base + (uint32_t)wv::lane();
+    const uint32_t cnt = v.leafcnt[leaf_lo + (i < nleaves ? i : nleaves - 1u)];
+    s += (i < nleaves) ? cnt : 0u;
+  }
   return wv::reduce_add(s);
 }
 // the same for the exclusive executor, whose climbs go all the way to the root (2^19 leaves at 2^24 slots: one load per trip
@@ -103,35 +108,40 @@ PMA_DEV void mark_leaves(const View &v, uint64_t lo, uint64_t hi) {
 }
 
 constexpr uint32_t kLongRange = 8;  // read ranges spanning more leaves are walked by the whole wave
-struct RangeRec {  // read-leaf ranges collected into the plan record
-  Plan *plan;
-  uint32_t nr;
+// Read-leaf ranges of the update being planned.  They live in REGISTERS while the plan is made — lane r holds range r — and go to
+// the plan record in one wave-wide store at the end (store_ranges): recording a range is two selects, no branch, no store.  (One
+// lane-0 store per range was a divergent branch and an address computation apiece, a dozen times per plan.)
+struct RangeRec {
+  bool on = true;   // false: the caller wants no read set (single updates outside the rounds)
+  uint32_t nr = 0;  // ranges recorded (wave-uniform), <= kMaxR = 64
   uint32_t nlong = 0;
-  // register copy, lane r holding range r (r < 64): the planning kernel reserves from it without reading the record back
   uint32_t my_lo = 1, my_hi = 0;
   // which sentinel positions the search result depends on: bit 0 = nodes[src].beginning (the final bracket still starts
   // at the first slot of the range), bit 1 = nodes[src].end (it still ends at the end of the range)
   uint32_t sdep = 0;
 };
+static_assert(kMaxR == 64, "one read range per lane");
 // (slot_lo, slot_hi: wave-uniform)
 PMA_DEV void rec_range(RangeRec &rr, const View &v, uint32_t slot_lo, uint32_t slot_hi) {
-  if (!rr.plan) return;
+  if (!rr.on) return;
   const uint32_t lo = slot_lo >> v.g.sh, hi = slot_hi >> v.g.sh;
   if (rr.nr < (uint32_t)kMaxR) {
-    if (wv::lane() == 0) rr.plan->r[rr.nr] = PlanRange{lo, hi};
-    if ((uint32_t)wv::lane() == rr.nr) {
-      rr.my_lo = lo;
-      rr.my_hi = hi;
-    }
-    if (hi - lo >= kLongRange) rr.nlong++;
+    const bool mine = (uint32_t)wv::lane() == rr.nr;
+    rr.my_lo = mine ? lo : rr.my_lo;
+    rr.my_hi = mine ? hi : rr.my_hi;
+    rr.nlong += (hi - lo >= kLongRange) ? 1u : 0u;
     rr.nr++;
-  } else {
-    if (wv::lane() == 0) {  // overflow: widen the last range (conservative)
-      const PlanRange pr = rr.plan->r[kMaxR - 1];
-      rr.plan->r[kMaxR - 1] = PlanRange{lo < pr.lo ? lo : pr.lo, hi > pr.hi ? hi : pr.hi};
-    }
+  } else {  // overflow: widen the last range (conservative)
+    const bool mine = (uint32_t)wv::lane() == (uint32_t)kMaxR - 1u;
+    rr.my_lo = (mine && lo < rr.my_lo) ? lo : rr.my_lo;
+    rr.my_hi = (mine && hi > rr.my_hi) ? hi : rr.my_hi;
     rr.nlong++;
   }
+}
+// range r of the list, as a scalar (r wave-uniform)
+PMA_DEV PlanRange range_at(const RangeRec &rr, uint32_t r) { return PlanRange{wv::bcast(rr.my_lo, (int)r), wv::bcast(rr.my_hi, (int)r)}; }
+PMA_DEV void store_ranges(const RangeRec &rr, Plan *plan) {
+  if ((uint32_t)wv::lane() < rr.nr) plan->r[wv::lane()] = PlanRange{rr.my_lo, rr.my_hi};
 }
 
 // Gap-aware lower bound of `dest` in slots [start,end) (PCSR.cpp:427-502), one wave; dest / start / end are wave-uniform and
@@ -951,8 +961,6 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, uint32_t idx) {
   const int lane = wv::lane();
   const Geometry &g = v.g;
   RangeRec rr;
-  rr.plan = plan;
-  rr.nr = 0;
   uint32_t kind = K_NOOP, index = 0, gap = 0, wstart = 0, wlen = 0, wl = 1, wh = 0, acalls = 0, aslots = 0;
   uint32_t sleaf_b = 0, sleaf_e = 0, mv_lo = 1, mv_hi = 0;
   // The node records around `src`, requested in ONE batch before anything depends on them: lanes 0 .. kW-1 hold the sentinel
@@ -963,14 +971,14 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, uint32_t idx) {
   uint32_t b0 = 0, e0 = 0;
   bool v0 = false;
   if (op.src < g.n) {
-    if ((uint32_t)lane < kW) {
-      v0 = (uint32_t)lane <= op.src;
-      if (v0) b0 = v.nodes[op.src - (uint32_t)lane].beginning;
-      if (lane == 0) e0 = v.nodes[op.src].end;
-    } else if ((uint32_t)lane < 2u * kW) {
-      const uint64_t u = (uint64_t)op.src + 1ull + ((uint64_t)lane - kW);
-      v0 = u < g.n;
-      if (v0) b0 = v.nodes[u].beginning;
+    // (one predicated load for all 2 kW lanes: {beginning, end} as an 8-byte access — only lane 0's `end` is used)
+    const bool dn = (uint32_t)lane < kW;
+    const uint64_t u = dn ? (uint64_t)op.src - (uint64_t)lane : (uint64_t)op.src + 1ull + ((uint64_t)lane - kW);
+    v0 = (uint32_t)lane < 2u * kW && (dn ? (uint32_t)lane <= op.src : u < g.n);
+    if (v0) {
+      const Node *nd = &v.nodes[u];
+      b0 = nd->beginning;
+      e0 = nd->end;
     }
   }
   if (op.src < g.n) {
@@ -995,9 +1003,9 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, uint32_t idx) {
     const uint32_t c_leaf = v.leafcnt[leaf];
     bool nul0 = false;
     constexpr uint32_t kGapPre = 16;  // slots of the gap search requested with this batch (a null within 16 slots in 99.7 % of the cases at density 0.7)
-    if (op.op != 0 && (uint32_t)lane < kGapPre) {
+    {
       const uint64_t g0 = (uint64_t)index + 1ull + (uint64_t)lane;
-      if (g0 < g.N) nul0 = (v.items[g0].value == 0);
+      if (op.op != 0 && (uint32_t)lane < kGapPre && g0 < g.N) nul0 = (v.items[g0].value == 0);
     }
     const bool occupied = !is_null(at);
     if (op.op != 0) {
@@ -1178,7 +1186,8 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, uint32_t idx) {
       if (b_lo == wstart && (kind == K_REMOVE || index > wstart)) mv_lo++;
     }
   }
-  const uint32_t nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
+  const uint32_t nr = rr.nr;
+  store_ranges(rr, plan);
   store_plan_header(plan, kind, index, gap, wstart, wlen, wl, wh, mv_lo, mv_hi, sleaf_b, sleaf_e, acalls, aslots, nr, rr.nlong, rr.sdep, idx, op);
   PlanRegs pr;
   pr.sdep = rr.sdep;

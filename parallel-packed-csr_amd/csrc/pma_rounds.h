@@ -179,7 +179,6 @@ constexpr uint32_t XF_RESEARCH = 8u;      // add_node retry after double_list: s
 // slot next to it), of the leaves its search and climb read, and of the sentinels it locates its range by.
 struct XValid {
   const uint32_t *wstamp, *rstamp, *vws;
-  Plan *scratch_plan;  // receives the read ranges of the search
   uint32_t me1;
 };
 // does a[lo..hi] hold a value above thr?  (this lane's share; the caller ballots.)  An exclusive update's window can be the
@@ -218,12 +217,10 @@ PMA_DEV bool xv_bad_writes(const View &v, const XValid &xv, uint64_t leaf_lo, ui
 }
 PMA_DEV bool xv_bad_reads(const View &v, const XValid &xv, const dev::RangeRec &rr, uint32_t src) {
   if (!xv.me1) return false;
-  wv::fence();  // the ranges were recorded by lane 0 (rec_range): its stores before every lane's loads of them
   bool bad = false;
-  const uint32_t nr = rr.nr < (uint32_t)kMaxR ? rr.nr : (uint32_t)kMaxR;
-  for (uint32_t r = 0; r < nr; r++) {
-    const uint32_t lo = xv.scratch_plan->r[r].lo, hi = xv.scratch_plan->r[r].hi;
-    bad |= xv_any_above(xv.wstamp, lo, hi, xv.me1);
+  for (uint32_t r = 0; r < rr.nr; r++) {  // (the ranges are in registers, lane r holding range r)
+    const PlanRange pr = dev::range_at(rr, r);
+    bad |= xv_any_above(xv.wstamp, pr.lo, pr.hi, xv.me1);
   }
   if (wv::lane() == 0 && (rr.sdep & 1u) && xv.vws[src] > xv.me1) bad = true;
   if (wv::lane() == 1 && (rr.sdep & 2u) && src + 1u < v.g.n && xv.vws[src + 1u] > xv.me1) bad = true;
@@ -241,8 +238,7 @@ PMA_KERNEL void k_exclusive(View v, Op op, const Op *ops, uint32_t op_index, uin
   uint32_t result = X_DONE, rws = 0, rwl = 0, found = 0;
   if (op_index != kMax) op = ops[op_index];
   dev::RangeRec rr;
-  rr.plan = xv.me1 ? xv.scratch_plan : (Plan *)nullptr;
-  rr.nr = 0;
+  rr.on = xv.me1 != 0;
 #define PMA_X_VIOLATION()            \
   do {                               \
     if (lane == 0) {                 \

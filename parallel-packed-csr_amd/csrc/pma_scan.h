@@ -8,8 +8,7 @@ namespace ppcsr {
 // ---- read-side kernels (get_neighbourhood PCSR.cpp:901-912, edge_exists :860-869) --------------------------
 PMA_KERNEL void k_edge_exists(View v, uint32_t src, uint32_t dst, ExclOut *out) {
   dev::RangeRec rr;
-  rr.plan = nullptr;
-  rr.nr = 0;
+  rr.on = false;
   uint32_t found = 0;
   if (src < v.g.n) {
     const Node nd = v.nodes[src];

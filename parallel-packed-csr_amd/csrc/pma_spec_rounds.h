@@ -282,7 +282,10 @@ PMA_DEV void o_plan_t(const OptArgs &a) {
     if (lane == 0) wv::atomic_min_u64(&a.v.dres[pr.wleaf_lo], key);
   } else if (kind_strong(kind)) {
     const uint32_t wl = pr.wleaf_lo, wh = pr.wleaf_hi;
-    for (uint32_t leaf = wl + (uint32_t)lane; leaf <= wh; leaf += 64) wv::atomic_min_u64(&a.v.wres[leaf], key);
+    for (uint32_t base = wl; base <= wh; base += 64) {  // (scalar trip count)
+      const uint32_t leaf = base + (uint32_t)lane;
+      if (leaf <= wh) wv::atomic_min_u64(&a.v.wres[leaf], key);
+    }
     // an update whose window is already within two levels of the exclusive threshold is likely to turn exclusive
     // once the earlier updates have landed: nothing later may overtake it (soft barrier)
     // ... and so is an update that has ALREADY been deferred at least once and whose window is big (a.defer_barrier
@@ -292,9 +295,13 @@ PMA_DEV void o_plan_t(const OptArgs &a) {
       wv::atomic_min_u64(&c->sbar[rt], key);
     }
     const uint32_t ml = pr.mv_lo, mh = pr.mv_hi;
-    for (uint64_t u = (uint64_t)ml + (uint64_t)lane; u <= (uint64_t)mh && ml <= mh; u += 64) wv::atomic_min_u64(&a.v.vw[u], key);
+    if (ml <= mh)
+      for (uint64_t base = ml; base <= (uint64_t)mh; base += 64) {
+        const uint64_t u = base + (uint64_t)lane;
+        if (u <= (uint64_t)mh) wv::atomic_min_u64(&a.v.vw[u], key);
+      }
   }
-  if (pr.nr <= 64u && pr.nlong == 0u) {  // lane r holds read range r
+  if (pr.nlong == 0u) {  // lane r holds read range r
     if ((uint32_t)lane < pr.nr)
       for (uint32_t leaf = pr.my_lo; leaf <= pr.my_hi; leaf++) wv::atomic_min_u64(&a.v.rres[leaf], key);
   } else {

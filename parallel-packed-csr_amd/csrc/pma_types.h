@@ -67,7 +67,7 @@ enum Kind : uint32_t {
   K_SKIP = 6,      // already executed by the exclusive executor inside this epoch: commits as nothing
 };
 
-constexpr int kMaxR = 70;  // read-leaf ranges recorded per op (search certificate + one or two per level of the density climb + a few)
+constexpr int kMaxR = 64;  // read-leaf ranges recorded per op (search certificate + one or two per level of the density climb + a few): one per lane of the planning wave
 
 // Layout: the 20-word header and the first 6 read ranges fill the record's first 128 bytes, which is all the round kernels touch
 // for almost every update (two or three ranges: the search certificate and the leaves of a short climb) — one wave-wide store
@@ -95,6 +95,7 @@ struct Plan {
   uint32_t src, dst, op;  // the update
   uint32_t pad;
   PlanRange r[kMaxR];  // leaf ranges read by the search / the density climb
+  uint32_t pad2[12];    // (records are five 128-byte lines)
 };
 // word index of a header field inside the record (lane <-> word in the wave-wide accesses)
 enum PlanWord : int { PW_KIND = 0, PW_INDEX, PW_GAP, PW_WSTART, PW_WLEN, PW_WLEAF_LO, PW_WLEAF_HI, PW_MV_LO, PW_MV_HI, PW_SLEAF_B, PW_SLEAF_E,

@@ -46,10 +46,18 @@ PMA_DEV void lanes(uint32_t v, uint32_t *out) {
   for (int i = 0; i < N; i++) out[i] = (uint32_t)__builtin_amdgcn_readlane((int)v, i);
 }
 PMA_DEV uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src)); }
+// sum over the wave (all 64 lanes active), as a scalar.  DPP adds: an inclusive scan inside each row of 16 lanes (row_shr 1, 2,
+// 4, 8), the row totals passed on (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3), the total read off lane 63 —
+// six VALU instructions and a v_readlane where six shuffles were six LDS round trips.
 PMA_DEV uint32_t reduce_add(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-  return v;
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 // orders this wave's LDS + global accesses among its own lanes (same CU: L1 is shared)
 PMA_DEV void fence() { __threadfence_block(); }
