@@ -143,7 +143,9 @@ struct Engine::Impl {
   uint32_t region_rare_cpr = 1536;
   double cpr_mean = -1.0;
   // Round width (upper bound when `adaptive` is on).  One update = one wave; `resident_waves` of them fit the chip at once
-  // (o_plan: 78 VGPRs = 6 waves per SIMD, 24 per CU, 6144 on 256 CUs).  A round's kernels are bound by latency, so a round
+  // (rounds 1-3: o_plan at 78 VGPRs = 6 waves per SIMD, 24 per CU, 6144 on 256 CUs; since round 4 o_plan runs 8 per SIMD and
+  // o_apply — one 6 KB LDS tile per wave — 6: the unit is 7 per SIMD, 7168 on 256 CUs, measured best of 6144 / 7168 / 8192:
+  // config #2 258 / 263 / 261 M/s).  A round's kernels are bound by latency, so a round
   // of 2 x resident takes ~1.4x the time of one of 1 x resident; widths in between leave the second pass partly empty
   // (config #2, updates/s: 6144 -> 139 M, 8192 -> 130 M, 12288 -> 162 M, 18432 -> 169 M, 24576 -> 153 M: the re-planned
   // share grows with the width — 3 %, 7 %, 12 %).  init() sets opt_horizon = 3 x resident, start_horizon = resident; the
@@ -347,7 +349,7 @@ int Engine::init(uint32_t init_n, uint32_t src_n, int lock_search, int device) {
     int cus = 0;
     GCHK(gpu::device_cus(device, &cus));
     if (cus > 0) {
-      p.resident_waves = (uint32_t)cus * 24u;
+      p.resident_waves = (uint32_t)cus * 28u;
       p.start_horizon = p.resident_waves;
       p.opt_horizon = 3u * p.resident_waves;
     }

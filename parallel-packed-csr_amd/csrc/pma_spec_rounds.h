@@ -233,39 +233,70 @@ PMA_KERNEL void o_settle(OptArgs a) {
   if (wv::thread_idx() == 0) round_record(a, c, s);
 }
 
+// words of the round's state that wave 0 of a workgroup hands to the others (LDS, lane i <-> word i)
+enum RoundWord : int { RW_STOP = 0, RW_HOR, RW_USED, RW_NF, RW_PRE0, RW_SKIP_IDX = RW_PRE0 + (int)kStripes + 1, RW_SKIP_ROUND, RW_WORDS };
+static_assert(RW_WORDS <= 16, "round words");
 template <bool EXTRAS>
 PMA_DEV void o_plan_t(const OptArgs &a) {
+  // The round's bookkeeping is ~250 scalar instructions and two dozen loads — the same for every wave.  Wave 0 of each workgroup
+  // evaluates it and leaves the handful of words the others need in LDS (evaluated by every wave it was 45 % of this kernel's
+  // scalar instructions, and the scalar unit is what bounds it).
+  PMA_SHARED uint32_t rsh[16];
   OptCtl *c = a.ctl;
   const uint32_t rt = a.round % 3u;
+  const int lane = wv::lane();
   // (one wave = one update: the wave's slot and everything that follows from it is the same in all lanes — see wv::uni)
-  const uint32_t wid = wv::uni(wv::block_idx() * 4u + (uint32_t)wv::wave_in_block());  // (256-thread workgroups)
-  const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error | c->need_big;
-  const uint32_t skip_idx = c->skip_idx, skip_round = c->skip_round;
-  if (f_done || f_viol || f_excl || f_err) return;
-  const RoundState rs = round_begin(a, c);
-  if (wid == 0u && wv::lane() == 0) round_record(a, c, rs);
-  if (rs.done || rs.excl || rs.error || rs.need_big) return;
-  const uint32_t hor = rs.hor, used = rs.used;
+  const uint32_t wib = wv::uni((uint32_t)wv::wave_in_block());
+  const uint32_t wid = wv::uni(wv::block_idx() * 4u) + wib;  // (256-thread workgroups)
+  if (wib == 0u) {
+    const uint32_t f_done = c->done, f_viol = c->violation, f_excl = c->excl, f_err = c->error | c->need_big;
+    const uint32_t skip_idx = c->skip_idx, skip_round = c->skip_round;
+    uint32_t stop = (f_done | f_viol | f_excl | f_err) ? 1u : 0u;
+    uint32_t w = 0;
+    if (!stop) {
+      const RoundState rs = round_begin(a, c);
+      if (wid == 0u && lane == 0) round_record(a, c, rs);
+      stop = (rs.done | rs.excl | rs.error | rs.need_big) ? 1u : 0u;
+      w = wv::setlane<RW_HOR>(w, rs.hor);
+      w = wv::setlane<RW_USED>(w, rs.used);
+      w = wv::setlane<RW_NF>(w, rs.nf);
+      w = wv::setlane<RW_PRE0 + 0>(w, rs.pre[0]);
+      w = wv::setlane<RW_PRE0 + 1>(w, rs.pre[1]);
+      w = wv::setlane<RW_PRE0 + 2>(w, rs.pre[2]);
+      w = wv::setlane<RW_PRE0 + 3>(w, rs.pre[3]);
+      w = wv::setlane<RW_PRE0 + 4>(w, rs.pre[4]);
+      w = wv::setlane<RW_PRE0 + 5>(w, rs.pre[5]);
+      w = wv::setlane<RW_PRE0 + 6>(w, rs.pre[6]);
+      w = wv::setlane<RW_PRE0 + 7>(w, rs.pre[7]);
+      w = wv::setlane<RW_PRE0 + 8>(w, rs.pre[8]);
+      w = wv::setlane<RW_SKIP_IDX>(w, skip_idx);
+      w = wv::setlane<RW_SKIP_ROUND>(w, skip_round);
+    }
+    w = wv::setlane<RW_STOP>(w, stop);
+    if (lane < 16) rsh[lane] = w;
+  }
+  wv::block_sync();
+  const uint32_t rw = rsh[lane & 15];
+  if (wv::bcast(rw, RW_STOP)) return;
+  const uint32_t hor = wv::bcast(rw, RW_HOR), used = wv::bcast(rw, RW_USED);
   if (wid >= hor) return;
   uint32_t idx;
   if (wid < used) {  // the wid-th deferred update of the previous round: stripe by stripe
     const uint32_t *carry = ((a.round - 1u) & 1u) ? a.carry1 : a.carry0;
-    uint32_t q = 0;
-#pragma unroll
-    for (uint32_t k = 1; k < kStripes; k++) q += (wid >= rs.pre[k]) ? 1u : 0u;
-    uint32_t base = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kStripes; k++) base = (q == k) ? rs.pre[k] : base;
+    // (lanes RW_PRE0 + k hold the exclusive prefix of the stripe counts: the stripe is the number of prefixes at or below wid)
+    const uint64_t mle = wv::ballot(lane >= RW_PRE0 + 1 && lane < RW_PRE0 + (int)kStripes && rw <= wid);
+    const uint32_t q = (uint32_t)wv::popc64(mle);
+    const uint32_t base = wv::bcast(rw, RW_PRE0 + (int)q);
     idx = wv::uni(carry[(uint64_t)q * a.carry_cap + (wid - base)]);
   } else {
-    idx = rs.nf + (wid - used);
+    idx = wv::bcast(rw, RW_NF) + (wid - used);
   }
+  const uint32_t skip_idx = wv::bcast(rw, RW_SKIP_IDX), skip_round = wv::bcast(rw, RW_SKIP_ROUND);
   Op op = a.ops[idx];
   op.src = wv::uni(op.src);
   op.dst = wv::uni(op.dst);
   op.op = wv::uni(op.op);
   Plan *pl = &a.plans[wid];
-  const int lane = wv::lane();
   if (a.round == skip_round && idx == skip_idx) {  // executed by the exclusive executor in the middle of this epoch: nothing left to do, commits at once
     dev::store_plan_header(pl, K_SKIP, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, idx, op);
     return;
@@ -313,7 +344,8 @@ PMA_DEV void o_plan_t(const OptArgs &a) {
     if (lane == 1 && (pr.sdep & 2u) && op.src + 1u < a.v.g.n) wv::atomic_min_u64(&a.v.vr[op.src + 1u], key);
   }
 }
-PMA_KERNEL void o_plan(OptArgs a) { o_plan_t<false>(a); }
+// (35 VGPRs; 8 waves per SIMD need <= 96 scalar registers: the planner is a chain of dependent loads, residency is throughput)
+PMA_KERNEL void PMA_LAUNCH_BOUNDS(256, 8) o_plan(OptArgs a) { o_plan_t<false>(a); }
 PMA_KERNEL void o_plan_x(OptArgs a) { o_plan_t<true>(a); }
 
 // One update checked by one wave: `wid` its horizon slot, `h` its plan header (scalars; h.my_lo / my_hi: lane r holds read range
