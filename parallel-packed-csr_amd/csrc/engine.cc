@@ -161,7 +161,7 @@ struct Engine::Impl {
   uint32_t excl_in_wave = 4096;
   // speculative rounds: windows up to big_window slots stay inside the round; those above big_min are rebalanced by a
   // workgroup each (o_big, big_grid workgroups, one scratch stretch of big_window slots per workgroup)
-  uint32_t big_window = 32768, big_min = 512, big_grid = 64;
+  uint32_t big_window = 32768, big_min = 256, big_grid = 64;
   dev::BigJob *d_jobs = nullptr;
   Edge *d_bigscratch = nullptr;
   uint64_t bigscratch_cap = 0;
@@ -198,6 +198,7 @@ struct Engine::Impl {
   // inserts; at / 2: 276 rounds and the same 2-3 rollbacks; without any: 234 rounds, but slower ones
   uint32_t soft_barrier = 0;
   uint32_t defer_barrier = 0;  // slots; a deferred update with a window at least this big lets nothing later overtake it (0: off)
+  uint32_t dbg_repeat = 0;  // measurement aid (diagnostics build of the round kernels only): o_plan executes parts of a plan twice — see OptArgs::dbg
   uint32_t diag = 0;     // count, per epoch, why planned updates did not commit (printed to stderr at the end of the epoch)
   uint32_t *d_dg = nullptr;  // diag >= 2: per-update trace of the batch (OptArgs::dg)
   uint64_t dg_cap = 0;
@@ -685,6 +686,10 @@ int Engine::set_option(const char *key, int64_t value) {
     p.defer_barrier = (uint32_t)std::max<int64_t>(0, value);
     return PPCSR_OK;
   }
+  if (k == "dbg_repeat") {
+    p.dbg_repeat = (uint32_t)value;
+    return PPCSR_OK;
+  }
   if (k == "diag") {  // 1: per-epoch counts of why updates did not commit; 2: + a per-update trace, dumped per epoch to $PPCSR_DIAG_DUMP
     p.diag = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 2));
     return PPCSR_OK;
@@ -997,7 +1002,8 @@ int Engine::run_speculative(const Op *d_ops, uint64_t n) {
       a.diag = p.diag;
       a.defer_barrier = p.defer_barrier;
       // the round kernels come in two instantiations: without / with the diagnostics compiled in
-      const bool extras = p.diag != 0;
+      const bool extras = p.diag != 0 || p.dbg_repeat != 0;
+      a.dbg = p.dbg_repeat;
       a.dg = p.diag >= 2 ? p.d_dg : (uint32_t *)nullptr;
       a.soft_barrier = p.soft_barrier ? p.soft_barrier : a.v.big_window / 2u;
       // while the rare-rollback rule keeps regions wide, overtakers are kept off a growing window by the region rule itself and

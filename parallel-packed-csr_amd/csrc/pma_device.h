@@ -41,7 +41,8 @@ struct View {
 constexpr uint32_t kBigWindow = 4096;  // default of View::big_window: the largest window ONE wave rebalances inside a round
 constexpr uint32_t kMaxSlide = 4096;   // slides longer than this too
 constexpr int kStatShards = 256;
-constexpr uint32_t kLdsWindow = 512;   // windows up to this many slots are rebalanced inside one wave's LDS tile (12 KB)
+constexpr uint32_t kLdsWindow = 256;   // windows up to this many slots are rebalanced inside one wave's LDS tile (3 KB; round 4: 512
+                                       // slots = 6 KB per wave held o_apply at 6 waves per SIMD — larger windows go to o_big's workgroups)
 
 struct StatShard {
   unsigned long long redistribute_calls, redistribute_slots, not_found, duplicates, noops, slide_slots, committed;
@@ -155,7 +156,43 @@ PMA_DEV void store_ranges(const RangeRec &rr, Plan *plan) {
 // value/dest of that slot, or known = 0.
 struct SearchHit {
   uint32_t known, value, dest;
+  // what the walk's register copy also knows: slots [cbase, cbase + cn) were loaded (cn = 0: no copy), bit l of cnull: slot
+  // cbase + l is null.  The copy reaches up to kGapAhead slots past the end of the searched interval: the gap search of an
+  // insert into an occupied slot starts there and almost always ends there.
+  uint32_t cbase, cn;
+  uint64_t cnull;
 };
+constexpr uint32_t kGapAhead = 16;
+// Leaf counts around the slot the search is about to return, requested WITH the walk's register copy (they were a dependent
+// round trip after it): lane l < kLeafCache holds leafcnt[base + l], base a multiple of 8 — the leaf itself, its sibling of the
+// "would become full" rule and the first three levels of the density climb (aligned windows of up to 8 leaves) are answered
+// from registers.
+constexpr uint32_t kLeafCache = 16;
+struct LeafCache {
+  uint32_t base = 0, n = 0;  // wave-uniform; n = 0: nothing cached
+  uint32_t lc = 0;           // lane l: leafcnt[base + l]
+};
+PMA_DEV void leaf_cache_load(const View &v, LeafCache &lc, uint32_t slot) {
+  const uint32_t nleaves = (uint32_t)(v.g.N >> v.g.sh);
+  lc.base = (slot >> v.g.sh) & ~7u;
+  lc.n = nleaves - lc.base < kLeafCache ? nleaves - lc.base : kLeafCache;
+  if ((uint32_t)wv::lane() < lc.n) lc.lc = v.leafcnt[lc.base + (uint32_t)wv::lane()];
+}
+// sum of leafcnt[leaf_lo .. leaf_lo + nleaves), from the cache when it covers the range
+template <bool WIDE>
+PMA_DEV uint32_t count_leaves_c(const View &v, const LeafCache *lc, uint32_t leaf_lo, uint32_t nleaves) {
+  if (lc != nullptr && leaf_lo >= lc->base && leaf_lo + nleaves <= lc->base + lc->n) {
+    const uint32_t o = leaf_lo - lc->base;
+    if (nleaves == 1) return wv::bcast(lc->lc, (int)o);
+    const uint32_t l = (uint32_t)wv::lane();
+    return wv::reduce_add((l >= o && l < o + nleaves) ? lc->lc : 0u);
+  }
+  return WIDE ? count_leaves_wide(v, leaf_lo, nleaves) : count_leaves(v, leaf_lo, nleaves);
+}
+template <bool WIDE>
+PMA_DEV uint32_t count_window_c(const View &v, const LeafCache *lc, uint64_t start, uint64_t len) {
+  return count_leaves_c<WIDE>(v, lc, (uint32_t)(start >> v.g.sh), (uint32_t)(len >> v.g.sh));
+}
 // What is recorded as READ is the search's CERTIFICATE, not its path.  In a sorted neighbourhood the slot the reference's
 // walk returns is a function of the final tight bracket alone (tests/test_search_model.py): a live slot a with dest < key
 // (or the first slot of the range), a live slot b with dest > key (or the end of the range), and nothing live in between —
@@ -164,10 +201,13 @@ struct SearchHit {
 // untouched, so only [a, b] is recorded; and the result depends on the POSITION of sentinel src / src + 1 only when the
 // bracket still starts / ends at the range's own boundary (rr.sdep).  Path reads used to order every update of a hub vertex
 // behind every write to the few leaves its coarse samples sit on.
-PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32_t end, RangeRec &rr, SearchHit *hit) {
+PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32_t end, RangeRec &rr, SearchHit *hit, LeafCache *lcache = nullptr) {
   hit->known = 0;
   hit->value = 0;
   hit->dest = 0;
+  hit->cbase = 0;
+  hit->cn = 0;
+  hit->cnull = 0;
   const int lane = wv::lane();
   const Edge *items = v.items;
   const uint32_t range_start = start, range_end = end;
@@ -228,11 +268,20 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
       cbase = start;
       cend = end;
       const uint32_t s = start + (uint32_t)lane;
-      if (s < end) {
+      // (the copy reaches kGapAhead slots past the interval — see SearchHit — and never past the array)
+      uint64_t lim64 = (uint64_t)end + kGapAhead;
+      if (lim64 > (uint64_t)start + 64ull) lim64 = (uint64_t)start + 64ull;
+      if (lim64 > v.g.N) lim64 = v.g.N;
+      const uint32_t lim = (uint32_t)lim64;
+      if (s < lim) {
         cval = items[s].value;
         cdst = items[s].dest;
       }
+      if (lcache != nullptr) leaf_cache_load(v, *lcache, start);
       clive = wv::ballot(s < end && cval != 0);
+      hit->cbase = cbase;
+      hit->cn = lim - cbase;
+      hit->cnull = wv::ballot(s < lim && cval == 0);
       cached = true;
       if (narrow) {
         // one more narrowing step, on the register copy: the bracket comes out tight (or the key is found), and the walk
@@ -352,7 +401,7 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
     hit->dest = ed;
     return start;
   }
-  if (cached && end >= cbase && end < cend) {
+  if (cached && end >= cbase && end < cbase + hit->cn) {
     hit->known = 1;
     hit->value = wv::bcast(cval, (int)(end - cbase));
     hit->dest = wv::bcast(cdst, (int)(end - cbase));
@@ -363,15 +412,20 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
 
 // first null slot in [from, N); returns N if none.  Stops (returns kMax) after `limit` slots.
 // pre / pre_nul / pre_w: the caller has already loaded the first pre_w slots (lane l < pre_w: slot from + l is null)
-PMA_DEV uint32_t find_gap_right(const View &v, uint32_t from, uint32_t limit, bool pre = false, bool pre_nul = false, uint32_t pre_w = 64) {
+// pre_mask / pre_w: the caller already knows the first pre_w slots (bit l of pre_mask: slot from + l is null) — a gap among
+// them costs no load at all
+PMA_DEV uint32_t find_gap_right(const View &v, uint32_t from, uint32_t limit, uint64_t pre_mask = 0, uint32_t pre_w = 0) {
   const int lane = wv::lane();
   const uint64_t N = v.g.N;
-  for (uint64_t base = from; base < N; base += 64) {
+  if (pre_w) {
+    const uint64_t m = pre_w >= 64u ? pre_mask : (pre_mask & ((1ull << pre_w) - 1ull));
+    if (m) return from + (uint32_t)wv::ctz64(m);
+  }
+  for (uint64_t base = (uint64_t)from + pre_w; base < N; base += 64) {
     if (base - from > limit) return kMax;
     const uint64_t s = base + (uint64_t)lane;
     bool nul = false;
-    if (pre && base == from && (uint32_t)lane < pre_w) nul = pre_nul;
-    else if (s < N) nul = (v.items[s].value == 0);
+    if (s < N) nul = (v.items[s].value == 0);
     const uint64_t m = wv::ballot(nul);
     if (m) return (uint32_t)(base + (uint64_t)wv::ctz64(m));
   }
@@ -396,7 +450,7 @@ struct InsertPlan {
 // while the rest of the launch waits.
 template <bool WIDE = false>
 PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, uint32_t c_leaf, uint32_t gap_right, RangeRec &rr,
-                               uint64_t cap = ~0ull) {
+                               uint64_t cap = ~0ull, const LeafCache *lcache = nullptr) {
   const Geometry &g = v.g;
   const int sh = g.sh;
   const uint64_t logN = (uint64_t)g.logN;
@@ -440,7 +494,7 @@ PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, uin
         continue;
       }
       node_index = new_idx;
-      c = v.leafcnt[node_index >> sh];
+      c = count_leaves_c<false>(v, lcache, (uint32_t)(node_index >> sh), 1u);
       rec_range(rr, v, (uint32_t)node_index, (uint32_t)node_index);
     }
     while ((uint64_t)c + 1 >= (uint64_t)g.t_up[level]) {  // PCSR.cpp:1028-1061
@@ -462,11 +516,11 @@ PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, uin
             break;
           }
           // window grew to the left: new count = old window + left half
-          c += count_window_t<WIDE>(v, new_idx, len / 2);
+          c += count_window_c<WIDE>(v, lcache, new_idx, len / 2);
           rec_range(rr, v, (uint32_t)new_idx, (uint32_t)(new_idx + len / 2 - 1));
           node_index = new_idx;
         } else {
-          c += count_window_t<WIDE>(v, new_idx + len / 2, len / 2);
+          c += count_window_c<WIDE>(v, lcache, new_idx + len / 2, len / 2);
           rec_range(rr, v, (uint32_t)(new_idx + len / 2), (uint32_t)(new_idx + len - 1));
         }
       } else {
@@ -504,7 +558,7 @@ struct RemovePlan {
   uint64_t wstart, wlen;
 };
 template <bool WIDE = false>
-PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index, RangeRec &rr, uint64_t cap = ~0ull) {
+PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index, RangeRec &rr, uint64_t cap = ~0ull, const LeafCache *lcache = nullptr) {
   const Geometry &g = v.g;
   const int sh = g.sh;
   RemovePlan out;
@@ -512,7 +566,7 @@ PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index, RangeRec &rr, uint
   uint64_t node_index = ((uint64_t)index >> sh) << sh;
   int level = g.H;
   uint64_t len = (uint64_t)g.logN;
-  uint32_t c = v.leafcnt[node_index >> sh];  // pre-removal count; compare c-1
+  uint32_t c = count_leaves_c<false>(v, lcache, (uint32_t)(node_index >> sh), 1u);  // pre-removal count; compare c-1
   rec_range(rr, v, (uint32_t)node_index, (uint32_t)node_index);
   while ((uint64_t)c < (uint64_t)g.t_lo[level] + 1) {  // (c - 1) < t_lo
     len *= 2;
@@ -521,11 +575,11 @@ PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index, RangeRec &rr, uint
       level--;
       const uint64_t new_idx = node_index & ~(len - 1);
       if (new_idx < node_index) {
-        c += count_window_t<WIDE>(v, new_idx, len / 2);
+        c += count_window_c<WIDE>(v, lcache, new_idx, len / 2);
         rec_range(rr, v, (uint32_t)new_idx, (uint32_t)(new_idx + len / 2 - 1));
         node_index = new_idx;
       } else {
-        c += count_window_t<WIDE>(v, new_idx + len / 2, len / 2);
+        c += count_window_c<WIDE>(v, lcache, new_idx + len / 2, len / 2);
         rec_range(rr, v, (uint32_t)(new_idx + len / 2), (uint32_t)(new_idx + len - 1));
       }
     } else {
@@ -988,10 +1042,12 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, uint32_t idx) {
     sleaf_b = nd_beginning >> g.sh;
     sleaf_e = nd_end >> g.sh;
     SearchHit hit;
-    index = pma_search(v, op.dst, nd_beginning + 1, nd_end, rr, &hit);
+    LeafCache lcache;
+    index = pma_search(v, op.dst, nd_beginning + 1, nd_end, rr, &hit, &lcache);
     const uint32_t leaf = index >> g.sh;
-    // one batch of independent loads: the slot the search returned (unless the search already knows it), its leaf's
-    // count, and — for an occupied slot — the first slots of the gap search to the right
+    // What is still missing, in one batch of independent loads: the slot the search returned (unless the search already
+    // knows it), the leaf counts around it (unless they came with the walk's register copy) and — for an insert the copy
+    // does not reach behind — the first slots of the gap search to the right
     Edge at;
     at.src = 0;
     at.value = hit.value;
@@ -1000,13 +1056,25 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, uint32_t idx) {
       at.value = v.items[index].value;
       at.dest = v.items[index].dest;
     }
-    const uint32_t c_leaf = v.leafcnt[leaf];
-    bool nul0 = false;
-    constexpr uint32_t kGapPre = 16;  // slots of the gap search requested with this batch (a null within 16 slots in 99.7 % of the cases at density 0.7)
-    {
-      const uint64_t g0 = (uint64_t)index + 1ull + (uint64_t)lane;
-      if (op.op != 0 && (uint32_t)lane < kGapPre && g0 < g.N) nul0 = (v.items[g0].value == 0);
+    if (!(lcache.n && leaf >= lcache.base && leaf < lcache.base + lcache.n)) leaf_cache_load(v, lcache, index);
+    // slots right of `index` the register copy holds: bit l of gmask = slot index + 1 + l is null, for l < gw
+    uint64_t gmask = 0;
+    uint32_t gw = 0;
+    if (hit.cn && index >= hit.cbase && index + 1u < hit.cbase + hit.cn) {
+      const uint32_t sft = index + 1u - hit.cbase;  // 1 .. 63
+      gmask = hit.cnull >> sft;
+      gw = hit.cn - sft;
     }
+    constexpr uint32_t kGapPre = 16;  // slots of the gap search requested with this batch (a null within 16 slots in 99.7 % of the cases at density 0.7)
+    if (op.op != 0 && gw == 0u) {
+      const uint64_t g0 = (uint64_t)index + 1ull + (uint64_t)lane;
+      bool nul0 = false;
+      if ((uint32_t)lane < kGapPre && g0 < g.N) nul0 = (v.items[g0].value == 0);
+      gmask = wv::ballot(nul0);
+      const uint64_t room = g.N - 1ull - (uint64_t)index;  // slots right of index
+      gw = room < kGapPre ? (uint32_t)room : kGapPre;
+    }
+    const uint32_t c_leaf = wv::bcast(lcache.lc, (int)(leaf - lcache.base));
     const bool occupied = !is_null(at);
     if (op.op != 0) {
       const Edge elem{op.src, op.dst, op.op};
@@ -1014,8 +1082,8 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, uint32_t idx) {
         kind = K_DUP;
         wl = wh = leaf;
       } else {
-        const uint32_t gap_right = occupied ? find_gap_right(v, index + 1, kMaxSlide, true, nul0, kGapPre) : index;
-        InsertPlan ip = plan_insert(v, index, occupied, c_leaf, gap_right, rr, v.big_window);
+        const uint32_t gap_right = occupied ? find_gap_right(v, index + 1, kMaxSlide, gmask, gw) : index;
+        InsertPlan ip = plan_insert(v, index, occupied, c_leaf, gap_right, rr, v.big_window, &lcache);
         // tries > 3 (PCSR.cpp:952-955): the reference gives up on leaf locks, takes the global write lock and runs
         // insert(..., nullptr) — same slide, same write, but the window comes from POST-insert densities (PCSR.cpp:578-590).
         // That climb is a function of the leaf counts and of where the slide's gap is, so it is planned here like any
@@ -1054,7 +1122,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, uint32_t idx) {
             uint32_t c = cpost, j2 = 0;
             if (wn != (uint64_t)g.logN) {
               const uint32_t l0 = (uint32_t)(ws >> g.sh);
-              j2 = v.leafcnt[l0] + v.leafcnt[l0 + 1u] + ((gleaf == l0 || gleaf == l0 + 1u) ? 1u : 0u);
+              j2 = count_leaves_c<false>(v, &lcache, l0, 2u) + ((gleaf == l0 || gleaf == l0 + 1u) ? 1u : 0u);
               // elements of the evened window that land in its left leaf: the literal position chain (PCSR.cpp:237-247),
               // at most 63 dependent subtractions, every lane the same (cheap in registers: this path is rare and must
               // not cost the planning kernel its occupancy)
@@ -1084,7 +1152,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, uint32_t idx) {
                 c = j2;  // the 2-leaf window itself (its right leaf was evened by the same pass)
               } else {
                 const uint64_t half = (new_idx < node_index) ? new_idx : new_idx + len / 2;
-                c += count_window(v, half, len / 2) + (((uint64_t)gleaf >= (half >> g.sh) && (uint64_t)gleaf < ((half + len / 2) >> g.sh)) ? 1u : 0u);
+                c += count_window_c<false>(v, &lcache, half, len / 2) + (((uint64_t)gleaf >= (half >> g.sh) && (uint64_t)gleaf < ((half + len / 2) >> g.sh)) ? 1u : 0u);
                 rec_range(rr, v, (uint32_t)half, (uint32_t)(half + len / 2 - 1));
               }
               node_index = new_idx;
@@ -1121,7 +1189,7 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, uint32_t idx) {
       if (!occupied || is_sentinel(elem) || at.dest != op.dst) {
         kind = K_NOTFOUND;
       } else {
-        const RemovePlan rp = plan_remove(v, index, rr, v.big_window);
+        const RemovePlan rp = plan_remove(v, index, rr, v.big_window, &lcache);
         if (rp.half || rp.wlen > v.big_window) {
           kind = K_EXCL;
         } else {

@@ -86,6 +86,8 @@ struct OptArgs {
   uint32_t round;
   int regshift;
   uint32_t diag;
+  uint32_t dbg;  // diagnostics build only: bit 0 = o_plan plans every update twice, bit 1 = searches twice, bit 2 = evaluates the round's
+                 // bookkeeping twice (the SQ counters of two runs then give the cost of that part: tools/sq_run.sh)
   uint32_t defer_barrier;  // 0: off
   uint32_t soft_barrier;   // slots: see o_plan
   // windows above big_min slots are rebalanced by a workgroup of o_big (job queue + one scratch stretch per workgroup)
@@ -300,6 +302,18 @@ PMA_DEV void o_plan_t(const OptArgs &a) {
   if (a.round == skip_round && idx == skip_idx) {  // executed by the exclusive executor in the middle of this epoch: nothing left to do, commits at once
     dev::store_plan_header(pl, K_SKIP, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, idx, op);
     return;
+  }
+  if (EXTRAS && (a.dbg & 1u)) (void)dev::plan_op(a.v, op, pl, idx);
+  if (EXTRAS && (a.dbg & 2u) && op.src < a.v.g.n) {
+    dev::RangeRec rr2;
+    dev::SearchHit h2;
+    const Node nd = a.v.nodes[op.src];
+    const uint32_t r = dev::pma_search(a.v, op.dst, nd.beginning + 1u, nd.end, rr2, &h2);
+    if (r == 0xFFFFFFF0u) a.status[wid] = rr2.nr + h2.known;  // (never: keeps the call alive)
+  }
+  if (EXTRAS && (a.dbg & 4u)) {
+    const RoundState r2 = round_begin(a, c);
+    if (r2.hor == 0xFFFFFFF0u) a.status[wid] = r2.nf;
   }
   // the plan record goes to memory for o_check / o_apply; this kernel reserves straight from the registers
   const dev::PlanRegs pr = dev::plan_op(a.v, op, pl, idx);
@@ -914,9 +928,9 @@ PMA_DEV void carry_append(const OptArgs &a, uint32_t keep, uint32_t *s_keep /* [
   if (m < c->minkept[rt]) wv::atomic_min_u32(&c->minkept[rt], m);  // (the word only ever goes down: a stale read costs one atomic)
 }
 
-// (Forcing 8 waves per SIMD — __launch_bounds__(256, 8) on o_plan / o_apply, a 256-slot LDS tile — for 8192-wide rounds was
-// measured again in round 2: 56 / 44 B of scratch per lane and 113-123 M updates/s against 141 at 6 waves per SIMD.)
-PMA_KERNEL void o_apply(OptArgs a) {
+// (8 waves per SIMD: 53 VGPRs, <= 96 scalar registers, a 3 KB LDS tile per wave.  In round 2 — 78 VGPRs — forcing it meant 56 /
+// 44 B of scratch per lane and 113-123 M updates/s against 141 at 6 waves per SIMD.)
+PMA_KERNEL void PMA_LAUNCH_BOUNDS(256, 8) o_apply(OptArgs a) {
   PMA_SHARED uint32_t lds[4][3 * kLdsWindow];
   PMA_SHARED uint32_t s_keep[4];
   const uint32_t keep = o_apply_wave<false>(a, lds[wv::wave_in_block()]);
