@@ -201,16 +201,6 @@ PMA_DEV uint32_t count_window_c(const View &v, const LeafCache *lc, uint64_t sta
 // untouched, so only [a, b] is recorded; and the result depends on the POSITION of sentinel src / src + 1 only when the
 // bracket still starts / ends at the range's own boundary (rr.sdep).  Path reads used to order every update of a hub vertex
 // behind every write to the few leaves its coarse samples sit on.
-PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32_t end, RangeRec &rr, SearchHit *hit, LeafCache *lcache = nullptr) {
-  hit->known = 0;
-  hit->value = 0;
-  hit->dest = 0;
-  hit->cbase = 0;
-  hit->cn = 0;
-  hit->cnull = 0;
-  const int lane = wv::lane();
-  const Edge *items = v.items;
-  const uint32_t range_start = start, range_end = end;
 #define PMA_CERT_BRACKET()                                                                  \
   do {                                                                                      \
     if (start == range_start) rr.sdep |= 1u;                                                \
@@ -218,48 +208,13 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
     const uint32_t _hi = (end == range_end && end > start) ? end - 1u : end;                \
     rec_range(rr, v, start < _hi ? start : _hi, start < _hi ? _hi : start);                 \
   } while (0)
-  const bool narrow = v.g.narrow != 0;
-  if (!narrow || end <= start) rr.sdep |= 3u;  // unsorted / inverted ranges (add_node after a doubling): no theorem
-  // 64-ary narrowing.  The value the reference's walk returns does not depend on the walk: any bracket (start, end)
-  // with "start is the range's first slot or a live slot whose dest < key" and "end is the range's end or a live slot
-  // whose dest > key" leads to the same answer (the walk only ever tightens such a bracket, and every exit fires on
-  // the tight one; tests/test_search_model.py checks this against the scalar walk).  So the bracket is first tightened
-  // 64 samples at a time — one round trip per factor of ~64 instead of one per factor of 2 — and the reference's walk
-  // then finishes it from registers.
-  while (narrow && end > start && end - start > 64) {  // (end < start happens: add_node after a doubling can leave a vertex whose
-                                             // recorded range is inverted, PCSR.cpp:533-540 + 681-703; the walk below copes)
-    const uint32_t len = end - start;
-    // samples sit on an ABSOLUTE power-of-two grid (multiples of 2^sshift), not at offsets from `start`
-    const uint32_t sshift = 26u - (uint32_t)__builtin_clz(len);  // smallest shift with (len >> shift) < 64  (len > 64)
-    const uint32_t first = ((start + (1u << sshift) - 1u) >> sshift) << sshift;
-    const uint32_t sl = first + ((uint32_t)lane << sshift);
-    uint32_t sv = 0, sd = 0;
-    if (sl < end) {
-      sv = items[sl].value;
-      sd = items[sl].dest;
-    }
-    const bool live = sl < end && sv != 0;
-    const uint64_t mlt = wv::ballot(live && sd < dest);
-    const uint64_t mge = wv::ballot(live && sd >= dest);
-    uint32_t nstart = start, nend = end;
-    if (mge) {
-      const int lb = wv::ctz64(mge);
-      const uint32_t bslot = first + ((uint32_t)lb << sshift), bdst = wv::bcast(sd, lb);
-      if (bdst == dest) {  // the key itself: the walk returns its slot whenever it meets it
-        rec_range(rr, v, bslot, bslot);
-        hit->known = 1;
-        hit->value = wv::bcast(sv, lb);
-        hit->dest = bdst;
-        return bslot;
-      }
-      nend = bslot;
-    }
-    if (mlt) nstart = first + ((uint32_t)(63 - wv::clz64(mlt)) << sshift);
-    const bool progress = (nend - nstart) <= len / 2u;
-    start = nstart;
-    end = nend;
-    if (!progress) break;  // sparse samples: let the reference's walk take over from here
-  }
+// The reference's walk itself (mid, mid+1, mid-1, ... until a live slot; PCSR.cpp:427-502) on the bracket [start, end) of the
+// range [range_start, range_end): the general form — unsorted / inverted ranges, brackets the 64-ary narrowing could not
+// tighten (sparse samples), brackets of a single slot.  pma_search below handles the common case without a loop.
+PMA_DEV uint32_t pma_search_walk(const View &v, uint32_t dest, uint32_t start, uint32_t end, uint32_t range_start, uint32_t range_end, bool narrow,
+                                 RangeRec &rr, SearchHit *hit, LeafCache *lcache) {
+  const int lane = wv::lane();
+  const Edge *items = v.items;
   bool cached = false;
   uint32_t cbase = 0, cend = 0, cval = 0, cdst = 0;
   uint64_t clive = 0;  // bit l: slot cbase + l is live
@@ -407,6 +362,167 @@ PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32
     hit->dest = wv::bcast(cdst, (int)(end - cbase));
   }
   return end;
+}
+
+// The common case of pma_search: a bracket of 2 .. 64 slots in a sorted range.  true: *res is the slot the walk returns; false:
+// the general walk must finish (start / end hold the bracket reached so far).
+PMA_DEV bool pma_search_fast(const View &v, uint32_t dest, uint32_t &start, uint32_t &end, uint32_t range_start, uint32_t range_end, RangeRec &rr,
+                             SearchHit *hit, LeafCache *lcache, uint32_t *res) {
+  const int lane = wv::lane();
+  const Edge *items = v.items;
+  // ---- the common case: a bracket of 2 .. 64 slots in a sorted range.  It is loaded ONCE, lane l holding slot cbase + l (with
+  // the leaf counts around it and kGapAhead slots behind it for the caller); one more narrowing step on that copy makes the
+  // bracket tight or finds the key; the walk's first iteration on a tight bracket always ends it.  No loop.
+  const uint32_t cbase = start;
+  uint32_t cval = 0, cdst = 0;
+  const uint32_t s = start + (uint32_t)lane;
+  uint64_t lim64 = (uint64_t)end + kGapAhead;
+  if (lim64 > (uint64_t)start + 64ull) lim64 = (uint64_t)start + 64ull;
+  if (lim64 > v.g.N) lim64 = v.g.N;
+  const uint32_t lim = (uint32_t)lim64;
+  if (s < lim) {
+    cval = items[s].value;
+    cdst = items[s].dest;
+  }
+  if (lcache != nullptr) leaf_cache_load(v, *lcache, start);
+  const uint64_t clive = wv::ballot(s < end && cval != 0);  // bit l: slot cbase + l is live
+  hit->cbase = cbase;
+  hit->cn = lim - cbase;
+  hit->cnull = wv::ballot(s < lim && cval == 0);
+  {
+    const uint64_t mge = wv::ballot(s < end && cval != 0 && cdst >= dest);
+    const uint64_t mlt = clive & ~mge;
+    if (mge) {
+      const int lb = wv::ctz64(mge);
+      const uint32_t bdst = wv::bcast(cdst, lb);
+      if (bdst == dest) {
+        rec_range(rr, v, cbase + (uint32_t)lb, cbase + (uint32_t)lb);
+        hit->known = 1;
+        hit->value = wv::bcast(cval, lb);
+        hit->dest = bdst;
+        { *res = cbase + (uint32_t)lb; return true; }
+      }
+      end = cbase + (uint32_t)lb;
+    }
+    if (mlt) start = cbase + (uint32_t)(63 - wv::clz64(mlt));
+  }
+  if (start + 1u < end) {
+    // the walk's iteration on [start, end): the first live slot in the order mid, mid+1, mid-1, ... is the nearest set bit right
+    // of mid against the nearest at or left of it (at equal distance the right one is probed first)
+    const uint32_t mid = (start + end) / 2;
+    const uint32_t s0 = start - cbase, m0 = mid - cbase, e0 = end - cbase;  // s0 <= m0 < e0 <= 64
+    const uint64_t upto_m = (m0 >= 63u) ? ~0ull : ((2ull << m0) - 1ull);           // bits 0 .. m0
+    const uint64_t below_s = (1ull << s0) - 1ull;                                    // bits 0 .. s0 - 1   (s0 <= 62)
+    const uint64_t below_e = (e0 >= 64u) ? ~0ull : ((1ull << e0) - 1ull);          // bits 0 .. e0 - 1
+    const uint64_t left = clive & upto_m & ~below_s, right = clive & ~upto_m & below_e;
+    const bool found = (left | right) != 0;
+    const uint32_t lpos = left ? (uint32_t)(63 - wv::clz64(left)) : 0u, rpos = right ? (uint32_t)wv::ctz64(right) : 0u;
+    const bool take_left = left && (!right || (m0 - lpos) < (rpos - m0));
+    const uint32_t at = take_left ? lpos : rpos;
+    const uint32_t check = found ? cbase + at : mid;
+    const uint32_t idest = found ? wv::bcast(cdst, (int)at) : 0u, ival = found ? wv::bcast(cval, (int)at) : 0u;
+    if (found && check != start) return false;  // (cannot happen on a tight bracket; the general walk copes if it ever does)
+    if (found && dest <= idest) {
+      if (dest == idest) rec_range(rr, v, check, check); else PMA_CERT_BRACKET();
+      hit->known = 1;
+      hit->value = ival;
+      hit->dest = idest;
+      { *res = check; return true; }
+    }
+    // nothing live in (start, end): mid is null (mid > start, and start is the only slot that can be live)
+    PMA_CERT_BRACKET();
+    hit->known = 1;
+    { *res = mid; return true; }
+  }
+  // start + 1 >= end after the tightening: the walk's closing test of `start`, then `end`
+  {
+    if (end < start) start = end;
+    const uint32_t ev = wv::bcast(cval, (int)(start - cbase)), ed = wv::bcast(cdst, (int)(start - cbase));
+    if (ev != 0 && dest == ed) {
+      rec_range(rr, v, start, start);
+    } else {
+      PMA_CERT_BRACKET();
+    }
+    if (ev != 0 && dest <= ed) {
+      hit->known = 1;
+      hit->value = ev;
+      hit->dest = ed;
+      { *res = start; return true; }
+    }
+    if (end < cbase + hit->cn) {
+      hit->known = 1;
+      hit->value = wv::bcast(cval, (int)(end - cbase));
+      hit->dest = wv::bcast(cdst, (int)(end - cbase));
+    }
+    { *res = end; return true; }
+  }
+}
+
+PMA_DEV uint32_t pma_search(const View &v, uint32_t dest, uint32_t start, uint32_t end, RangeRec &rr, SearchHit *hit, LeafCache *lcache = nullptr) {
+  hit->known = 0;
+  hit->value = 0;
+  hit->dest = 0;
+  hit->cbase = 0;
+  hit->cn = 0;
+  hit->cnull = 0;
+  const int lane = wv::lane();
+  const Edge *items = v.items;
+  const uint32_t range_start = start, range_end = end;
+  const bool narrow = v.g.narrow != 0;
+  bool walk = false;  // the general walk finishes the search (one call site: it is a long piece of code)
+  if (!narrow || end <= start) {  // unsorted / inverted ranges (add_node after a doubling can leave a vertex whose recorded range is
+                                  // inverted, PCSR.cpp:533-540 + 681-703): no theorem, the literal walk
+    rr.sdep |= 3u;
+    walk = true;
+  }
+  // 64-ary narrowing.  The value the reference's walk returns does not depend on the walk: any bracket (start, end)
+  // with "start is the range's first slot or a live slot whose dest < key" and "end is the range's end or a live slot
+  // whose dest > key" leads to the same answer (the walk only ever tightens such a bracket, and every exit fires on
+  // the tight one; tests/test_search_model.py checks this against the scalar walk).  So the bracket is first tightened
+  // 64 samples at a time — one round trip per factor of ~64 instead of one per factor of 2 — and the walk then finishes
+  // it from registers.  (One exit condition, the outcome in `state`: loops with returns inside cost the scalar unit dearly.)
+  uint32_t state = 0;  // 1: a sample holds the key (fslot / fval), 2: sparse samples — no progress, the literal walk takes over
+  uint32_t fslot = 0, fval = 0;
+  while (!walk && state == 0u && end - start > 64u) {
+    const uint32_t len = end - start;
+    // samples sit on an ABSOLUTE power-of-two grid (multiples of 2^sshift), not at offsets from `start`
+    const uint32_t sshift = 26u - (uint32_t)__builtin_clz(len);  // smallest shift with (len >> shift) < 64  (len > 64)
+    const uint32_t first = ((start + (1u << sshift) - 1u) >> sshift) << sshift;
+    const uint32_t sl = first + ((uint32_t)lane << sshift);
+    uint32_t sv = 0, sd = 0;
+    if (sl < end) {
+      sv = items[sl].value;
+      sd = items[sl].dest;
+    }
+    const bool live = sl < end && sv != 0;
+    const uint64_t mlt = wv::ballot(live && sd < dest);
+    const uint64_t mge = wv::ballot(live && sd >= dest);
+    const int lb = mge ? wv::ctz64(mge) : 0;
+    const uint32_t bslot = first + ((uint32_t)lb << sshift), bdst = wv::bcast(sd, lb);
+    const bool key = mge != 0 && bdst == dest;  // the key itself: the walk returns its slot whenever it meets it
+    fslot = bslot;
+    fval = wv::bcast(sv, lb);
+    const uint32_t nend = mge ? bslot : end;
+    const uint32_t nstart = mlt ? first + ((uint32_t)(63 - wv::clz64(mlt)) << sshift) : start;
+    const bool progress = (nend - nstart) <= len / 2u;
+    if (!key) {
+      start = nstart;
+      end = nend;
+    }
+    state = key ? 1u : (progress ? 0u : 2u);  // sparse samples: let the reference's walk take over from here
+  }
+  if (state == 1u) {
+    rec_range(rr, v, fslot, fslot);
+    hit->known = 1;
+    hit->value = fval;
+    hit->dest = dest;
+    return fslot;
+  }
+  if (!walk && state == 0u && start + 1u < end) {
+    uint32_t res = 0;
+    if (pma_search_fast(v, dest, start, end, range_start, range_end, rr, hit, lcache, &res)) return res;
+  }
+  return pma_search_walk(v, dest, start, end, range_start, range_end, narrow, rr, hit, lcache);
 #undef PMA_CERT_BRACKET
 }
 
