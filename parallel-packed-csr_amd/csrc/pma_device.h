@@ -664,6 +664,81 @@ PMA_DEV InsertPlan plan_insert(const View &v, uint32_t index, bool occupied, uin
   }
 }
 
+// The first attempt of plan_insert (tries = 0, no left bound yet), for the round planner: 32-bit arithmetic (its windows stop at
+// `cap` <= 2^16 slots), straight-line but for the climb, whose one exit carries the outcome in `st`.  false: the attempt ended
+// in the reference's retry path (the window wants to grow to the left of the leaves it "holds", PCSR.cpp:1016-1022 /
+// 1043-1049) — the caller restores its read set and runs the general plan_insert.  Everything else: *out as plan_insert
+// would leave it.
+PMA_DEV bool plan_insert_first(const View &v, uint32_t index, bool occupied, uint32_t c_leaf, uint32_t gap_right, RangeRec &rr, uint32_t cap,
+                               const LeafCache *lcache, InsertPlan *out) {
+  const Geometry &g = v.g;
+  const int sh = g.sh;
+  const uint32_t logN = (uint32_t)g.logN;
+  const uint32_t N32 = g.N > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g.N;  // (window lengths here stay <= 2 * cap)
+  out->status = PS_OK;
+  out->node_index_final = 0;
+  out->max_len = logN;
+  out->gap = index;
+  if ((uint64_t)index == g.N - 1 && occupied) {  // PCSR.cpp:992-997
+    out->status = PS_GLOBAL_NOINFO;
+    return true;
+  }
+  uint32_t node_index = (index >> sh) << sh;
+  const uint32_t node_id = index >> sh;
+  const uint32_t min_node = (node_id > 0u && !g.lock_search) ? node_id - 1u : node_id;
+  uint32_t len = logN;
+  int level = g.H;
+  uint32_t c = c_leaf;
+  rec_range(rr, v, node_index, node_index);
+  if (c + 1u == len) {  // leaf would become full (PCSR.cpp:1012-1023)
+    const uint32_t new_idx = node_index & ~(2u * len - 1u);
+    if (new_idx != node_index && (new_idx >> sh) < min_node) return false;
+    node_index = new_idx;
+    c = count_leaves_c<false>(v, lcache, node_index >> sh, 1u);
+    rec_range(rr, v, node_index, node_index);
+  }
+  uint32_t st = 0;  // 1: window beyond cap, 2: retry path, 3: root overflow
+  while (st == 0u && c + 1u >= g.t_up[level]) {  // PCSR.cpp:1028-1061
+    len *= 2u;
+    if (len > N32) {
+      st = 3u;
+    } else if (len > cap) {
+      st = 1u;
+    } else {
+      level--;
+      const uint32_t new_idx = node_index & ~(len - 1u);
+      const bool left = new_idx < node_index;
+      if (left && (new_idx >> sh) < min_node) {
+        st = 2u;
+      } else {
+        // the window grew to the left (new count = old window + left half) or to the right
+        const uint32_t half = left ? new_idx : new_idx + len / 2u;
+        c += count_window_c<false>(v, lcache, half, len / 2u);
+        rec_range(rr, v, half, half + len / 2u - 1u);
+        node_index = new_idx;
+      }
+    }
+  }
+  if (st == 2u) return false;
+  if (st == 3u) {
+    out->status = PS_GLOBAL_DOUBLE;
+    return true;
+  }
+  out->max_len = len;
+  if (st == 1u) {
+    out->node_index_final = node_index & ~(len - 1u);
+    return true;
+  }
+  out->node_index_final = node_index;
+  // leaves the slide will cross (PCSR.cpp:1085-1132)
+  if (occupied) {
+    if (gap_right == kMax) out->status = PS_SLIDE_LONG;
+    else if ((uint64_t)gap_right == g.N) out->status = PS_SLIDE_OFF_END;
+    else out->gap = gap_right;
+  }
+  return true;
+}
+
 // NOTE on the count update inside the climb above: the reference recomputes get_density over the whole
 // new window at every level; the window at level L-1 is the union of the level-L window and its sibling,
 // so adding the sibling's count gives the identical integer.  In the "would become full" quirk case the
@@ -1199,7 +1274,14 @@ PMA_DEV PlanRegs plan_op(const View &v, const Op op, Plan *plan, uint32_t idx) {
         wl = wh = leaf;
       } else {
         const uint32_t gap_right = occupied ? find_gap_right(v, index + 1, kMaxSlide, gmask, gw) : index;
-        InsertPlan ip = plan_insert(v, index, occupied, c_leaf, gap_right, rr, v.big_window, &lcache);
+        InsertPlan ip;
+        {
+          const RangeRec rr0 = rr;
+          if (!plan_insert_first(v, index, occupied, c_leaf, gap_right, rr, v.big_window, &lcache, &ip)) {
+            rr = rr0;  // (the general form starts over, retries included)
+            ip = plan_insert(v, index, occupied, c_leaf, gap_right, rr, v.big_window, &lcache);
+          }
+        }
         // tries > 3 (PCSR.cpp:952-955): the reference gives up on leaf locks, takes the global write lock and runs
         // insert(..., nullptr) — same slide, same write, but the window comes from POST-insert densities (PCSR.cpp:578-590).
         // That climb is a function of the leaf counts and of where the slide's gap is, so it is planned here like any
