@@ -788,58 +788,67 @@ PMA_DEV RemovePlan plan_remove(const View &v, uint32_t index, RangeRec &rr, uint
 // scatter staged through this wave's LDS tile, one coalesced store.  Larger windows (rare) are
 // streamed through the same wave in 64-slot chunks: stable in-place compaction to the left, null fill,
 // then spread right-to-left — the reference's own three phases, 64 slots at a time.
+// Window of <= 64 slots whose slots are in registers (lane l: slot wstart + l; lanes >= wlen hold nulls): ranks, exact
+// positions, scatter through the wave's LDS tile, one coalesced store, leaf counts.
+PMA_DEV void redistribute_regs(const View &v, uint64_t wstart, uint64_t wlen, const Edge &e, uint32_t *lds) {
+  const int lane = wv::lane();
+  Edge *items = v.items;
+  const int sh = v.g.sh;
+  const uint32_t logN = (uint32_t)v.g.logN;
+  const bool valid = (uint64_t)lane < wlen;
+  const bool nn = valid && e.value != 0;
+  const uint64_t m = wv::ballot(nn);
+  const uint32_t j = (uint32_t)wv::popc64(m);
+  const uint32_t k = lanemask_lt_count(m, lane);
+  uint64_t mypos = wstart;
+  if (j >= 2) {
+    ChainSeg sg;
+    if (chain_single(wstart, wlen, j, &sg)) {  // closed form (every window that does not start at slot 0)
+      if (nn) mypos = chain_single_pos(sg, wstart, j, k);
+    } else {
+      const double step = chain_step(wlen, j);
+      double x = chain_top(wstart, j, step);
+      for (uint32_t t = 0; t + 1 < j; t++) {
+        if (nn && k == j - 1 - t) mypos = (uint64_t)x;
+        x = chain_sub(x, step);
+      }
+    }
+  }
+  // LDS tile (SoA, stride-1): clear, scatter, gather
+  lds[lane] = kMax;
+  lds[64 + lane] = 0;
+  lds[128 + lane] = 0;
+  wv::lds_fence();
+  if (nn) {
+    const uint32_t o = (uint32_t)(mypos - wstart);
+    lds[o] = e.src;
+    lds[64 + o] = e.dest;
+    lds[128 + o] = e.value;
+    fix_sentinel(v, e, (uint32_t)mypos);
+  }
+  wv::lds_fence();
+  Edge out;
+  out.src = lds[lane];
+  out.dest = lds[64 + lane];
+  out.value = lds[128 + lane];
+  if (valid) items[wstart + lane] = out;
+  const uint64_t occ = wv::ballot(valid && out.value != 0);
+  const uint32_t nleaf = (uint32_t)(wlen >> sh);
+  if ((uint32_t)lane < nleaf) {
+    const uint64_t sub = (logN >= 64) ? occ : ((occ >> ((uint32_t)lane * logN)) & ((1ull << logN) - 1ull));
+    v.leafcnt[(wstart >> sh) + lane] = (uint32_t)wv::popc64(sub);
+  }
+  wv::fence();
+}
 PMA_DEV void redistribute_wave(const View &v, uint64_t wstart, uint64_t wlen, uint32_t *lds /* 3*kLdsWindow u32 per wave */) {
   const int lane = wv::lane();
   Edge *items = v.items;
   const int sh = v.g.sh;
   const uint32_t logN = (uint32_t)v.g.logN;
   if (wlen <= 64) {
-    const bool valid = (uint64_t)lane < wlen;
     Edge e = null_edge();
-    if (valid) e = items[wstart + lane];
-    const bool nn = valid && e.value != 0;
-    const uint64_t m = wv::ballot(nn);
-    const uint32_t j = (uint32_t)wv::popc64(m);
-    const uint32_t k = lanemask_lt_count(m, lane);
-    uint64_t mypos = wstart;
-    if (j >= 2) {
-      ChainSeg sg;
-      if (chain_single(wstart, wlen, j, &sg)) {  // closed form (every window that does not start at slot 0)
-        if (nn) mypos = chain_single_pos(sg, wstart, j, k);
-      } else {
-        const double step = chain_step(wlen, j);
-        double x = chain_top(wstart, j, step);
-        for (uint32_t t = 0; t + 1 < j; t++) {
-          if (nn && k == j - 1 - t) mypos = (uint64_t)x;
-          x = chain_sub(x, step);
-        }
-      }
-    }
-    // LDS tile (SoA, stride-1): clear, scatter, gather
-    lds[lane] = kMax;
-    lds[64 + lane] = 0;
-    lds[128 + lane] = 0;
-    wv::lds_fence();
-    if (nn) {
-      const uint32_t o = (uint32_t)(mypos - wstart);
-      lds[o] = e.src;
-      lds[64 + o] = e.dest;
-      lds[128 + o] = e.value;
-      fix_sentinel(v, e, (uint32_t)mypos);
-    }
-    wv::lds_fence();
-    Edge out;
-    out.src = lds[lane];
-    out.dest = lds[64 + lane];
-    out.value = lds[128 + lane];
-    if (valid) items[wstart + lane] = out;
-    const uint64_t occ = wv::ballot(valid && out.value != 0);
-    const uint32_t nleaf = (uint32_t)(wlen >> sh);
-    if ((uint32_t)lane < nleaf) {
-      const uint64_t sub = (logN >= 64) ? occ : ((occ >> ((uint32_t)lane * logN)) & ((1ull << logN) - 1ull));
-      v.leafcnt[(wstart >> sh) + lane] = (uint32_t)wv::popc64(sub);
-    }
-    wv::fence();
+    if ((uint64_t)lane < wlen) e = items[wstart + lane];
+    redistribute_regs(v, wstart, wlen, e, lds);
     return;
   }
   if (wlen <= kLdsWindow) {
@@ -1553,6 +1562,45 @@ PMA_DEV void apply_op(const View &v, const Op op, const PlanHead &h, uint32_t *l
   if (kind == K_INSERT || kind == K_REMOVE) {  // everything this update writes lies in [wleaf_lo, wleaf_hi] (slide + window)
     mark_leaves(v, plan->wleaf_lo, plan->wleaf_hi);
     if (lane == 0) v.vdirty[op.src] = v.serial;
+  }
+  // A window of <= 64 slots that contains everything the update touches (slot, slide) is loaded ONCE: the slide and the write
+  // happen in registers, then ranks / positions / one store.  (Slide, write and rebalance one after the other were three
+  // load -> store -> acknowledgement round trips on the same 64 slots; sentinels the slide moves are inside the window, whose
+  // rebalance sets every back-pointer from the final positions.)
+  if ((kind == K_INSERT || kind == K_REMOVE) && !defer && plan->wlen <= 64u && index >= plan->wstart &&
+      (kind == K_REMOVE || plan->gap < plan->wstart + plan->wlen)) {
+    const uint32_t ws = plan->wstart, wn = plan->wlen;
+    Edge e = null_edge();
+    if ((uint32_t)lane < wn) e = v.items[ws + (uint32_t)lane];
+    const uint32_t li = index - ws;
+    if (kind == K_INSERT) {
+      const uint32_t lg = plan->gap - ws;  // li <= lg < wn
+      if (lane == 0) {
+        wv::atomic_add_nn(&v.nodes[op.src].num_neighbors, 1u);
+        wv::atomic_add_u64(&st->redistribute_calls, (unsigned long long)plan->alg_calls);
+        wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)plan->alg_slots);
+        wv::atomic_add_u64(&st->slide_slots, (unsigned long long)(lg - li));
+      }
+      const int from = lane > 0 ? lane - 1 : 0;
+      Edge up;
+      up.src = wv::shfl(e.src, from);
+      up.dest = wv::shfl(e.dest, from);
+      up.value = wv::shfl(e.value, from);
+      if ((uint32_t)lane > li && (uint32_t)lane <= lg) e = up;  // slide_right: slots index .. gap-1 move one to the right
+      if ((uint32_t)lane == li) e = Edge{op.src, op.dst, op.op};
+    } else {
+      if (lane == 0) {
+        wv::atomic_add_nn(&v.nodes[op.src].num_neighbors, 0xFFFFFFFFu);
+        wv::atomic_add_u64(&st->redistribute_calls, (unsigned long long)plan->alg_calls);
+        wv::atomic_add_u64(&st->redistribute_slots, (unsigned long long)plan->alg_slots);
+      }
+      if ((uint32_t)lane == li) {
+        e.value = 0;
+        e.dest = 0;
+      }
+    }
+    redistribute_regs(v, ws, wn, e, lds);
+    return;
   }
   if (kind == K_INSERT) {
     const uint32_t gap = plan->gap;

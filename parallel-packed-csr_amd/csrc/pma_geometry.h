@@ -235,7 +235,9 @@ PMA_HD inline void build_chain_table(uint64_t index, uint64_t len, uint64_t j, C
 // Whole chain in ONE segment?  True for every window that does not straddle a power of two — i.e. all aligned PMA
 // windows except those starting at slot 0 — because every chain value then lies in [index, index+len) inside one
 // binade.  On success pos_k = chain_single_pos(sg, index, j, k) for 0 <= k < j, with no serial dependency.
-PMA_HD inline bool chain_single(uint64_t index, uint64_t len, uint64_t j, ChainSeg *sg) {
+// (chain_single_div: the same through chain_segment's step count — one division; kept as the statement the tests hold the
+//  division-free form below against)
+PMA_HD inline bool chain_single_div(uint64_t index, uint64_t len, uint64_t j, ChainSeg *sg) {
   if (j < 2) return false;
   const double step = chain_step(len, j);
   const double x = chain_top(index, j, step);
@@ -246,6 +248,70 @@ PMA_HD inline bool chain_single(uint64_t index, uint64_t len, uint64_t j, ChainS
   const uint64_t c = chain_segment(x, S, es, sg);
   sg->count = c;
   return c >= j - 2;
+}
+// The segment's step count c = 1 + floor((M1 - Th) / Drest) + 1 is only ever compared with j - 2 here, and
+// floor(a / d) >= n  <=>  a >= n * d: a multiplication instead of the division (this runs once per in-wave rebalance, on the
+// scalar unit, with the update's wave waiting).  sg->count is the number of steps the caller needs (j - 2) on success.
+PMA_HD inline bool chain_single(uint64_t index, uint64_t len, uint64_t j, ChainSeg *sg) {
+  if (j < 2) return false;
+  const double step = chain_step(len, j);
+  const double x = chain_top(index, j, step);
+  const uint64_t sb = dbl_bits(step);
+  const int es = (int)((sb >> 52) & 0x7FF) - 1023;
+  const uint64_t S = (sb & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+  const uint64_t xb = dbl_bits(x);
+  const int e = (int)((xb >> 52) & 0x7FF) - 1023;
+  const uint64_t M0 = (xb & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+  sg->t0 = 0;
+  sg->M0 = M0;
+  sg->shift = 52 - e;
+  sg->pad = 0;
+  sg->Dfirst = sg->Drest = 0;
+  sg->count = 0;
+  const uint64_t need = j - 2;  // chain steps beyond the first value
+  const int r = e - es;
+  if (!(sg->shift >= 0 && r >= 0 && r <= 52)) return need == 0;
+  uint64_t q, rem, half;
+  if (r == 0) {
+    q = S;
+    rem = 0;
+    half = 1;
+  } else {
+    q = S >> r;
+    rem = S & ((1ull << r) - 1);
+    half = 1ull << (r - 1);
+  }
+  uint64_t Df, Dr;
+  if (rem < half) {
+    Df = Dr = q;
+  } else if (rem > half) {
+    Df = Dr = q + 1;
+  } else {  // exact tie: round to even mantissa
+    Df = (((M0 - q) & 1ull) == 0) ? q : q + 1;
+    Dr = ((q & 1ull) == 0) ? q : q + 1;
+  }
+  sg->Dfirst = Df;
+  sg->Drest = Dr;
+  if (need == 0) return true;
+  const uint64_t Th = (1ull << 52) + q + (rem ? 1 : 0);
+  if (!(M0 >= Th && Dr > 0)) return false;  // c = 0
+  if (need == 1) {
+    sg->count = 1;
+    return true;
+  }
+  const uint64_t M1 = M0 - Df;
+  if (M1 < Th) return false;  // c = 1
+  // c = floor((M1 - Th) / Dr) + 2 >= need  <=>  (need - 2) * Dr <= M1 - Th.  need < 2^32 (element counts), Dr < 2^54: the
+  // product is formed from two partial products that cannot wrap, and compared with M1 - Th < 2^53
+  const uint64_t a = M1 - Th, n = need - 2;
+  if (n >> 32) return false;
+  const uint64_t Dh = Dr >> 27, Dl = Dr & ((1ull << 27) - 1);
+  const uint64_t ph = n * Dh;  // < 2^32 * 2^27
+  const uint64_t pl = n * Dl;  // < 2^59
+  if (ph >= (1ull << 27)) return false;  // (n * Dr >= 2^54 > a)
+  if ((ph << 27) + pl > a) return false;
+  sg->count = need;
+  return true;
 }
 PMA_HD inline uint64_t chain_single_pos(const ChainSeg &sg, uint64_t index, uint64_t j, uint64_t k) {
   if (k == 0) return index;

@@ -30,6 +30,12 @@ extern "C" int ppcsr_sim_chain_positions(uint64_t index, uint64_t len, uint64_t 
   }
   // closed form used by the in-wave rebalance: when the chain is a single segment it must give the same positions
   ppcsr::ChainSeg sg;
+  {  // the division-free closed-form test against its statement with the division: same verdict, same segment
+    ppcsr::ChainSeg sd;
+    const bool a = j >= 2 && ppcsr::chain_single(index, len, j, &sg), b = j >= 2 && ppcsr::chain_single_div(index, len, j, &sd);
+    if (a != b) ok = 0;
+    if (a && (sg.M0 != sd.M0 || sg.Dfirst != sd.Dfirst || sg.Drest != sd.Drest || sg.shift != sd.shift)) ok = 0;
+  }
   if (j >= 2 && ppcsr::chain_single(index, len, j, &sg)) {
     for (uint64_t k = 0; k < j; k++)
       if (ppcsr::chain_single_pos(sg, index, j, k) != out[k]) ok = 0;

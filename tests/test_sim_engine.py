@@ -449,6 +449,15 @@ def test_chain_table_matches_serial_fp64_chain():
         idx = int(rng.integers(0, 1 << (30 - lg))) * ln
         j = int(rng.integers(1, ln + 1))
         cases.append((idx, ln, j))
+    # the windows ONE wave / one workgroup rebalances (closed form without the division): small windows at every kind of
+    # start — slot 0, powers of two (the window fills its binade from the bottom), other multiples — and every fill
+    for _ in range(2500):
+        lg = int(rng.integers(3, 11))
+        ln = 1 << lg
+        kind = int(rng.integers(0, 4))
+        idx = 0 if kind == 0 else ((1 << int(rng.integers(lg, 31))) if kind == 1 else int(rng.integers(1, 1 << (31 - lg))) * ln)
+        j = int(rng.integers(1, ln + 1)) if rng.integers(0, 4) else int(rng.choice([1, 2, 3, 4, ln - 1, ln]))
+        cases.append((idx, ln, max(j, 1)))
     for idx, ln, j in cases:
         ref = np.zeros(j, np.uint64)
         got = np.zeros(j, np.uint64)
