@@ -106,6 +106,7 @@ uint64_t shfl64(uint64_t v, int src) {
   src &= 63;
   return w.present[par][src] ? w.in[par][src] : 0;  // inactive source lane: undefined on HW, 0 here
 }
+bool check_uniform = false;
 uint64_t first64(uint64_t v) {
   int par = arrive(OP_SHFL, v, false);
   Wave &w = waves[cur->tid >> 6];
@@ -114,6 +115,7 @@ uint64_t first64(uint64_t v) {
   return v;
 }
 uint64_t uniform64(uint64_t v) {
+  if (!check_uniform) return v;  // (the claim is trusted: no rendezvous — the checked runs are the tests that switch it on)
   int par = arrive(OP_SHFL, v, false);
   Wave &w = waves[cur->tid >> 6];
   for (int l = 0; l < 64; l++)
@@ -129,7 +131,6 @@ void gather64(uint64_t v, uint64_t *all64) {
   Wave &w = waves[cur->tid >> 6];
   for (int l = 0; l < 64; l++) all64[l] = w.present[par][l] ? w.in[par][l] : 0;
 }
-bool check_uniform = false;
 uint64_t reduce_add64(uint64_t v) {
   int par = arrive(OP_SUM, v, false);
   return waves[cur->tid >> 6].result[par];

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from helpers import load_pkg, load_streams  # noqa: E402
 
 pkg, st = load_pkg(), load_streams()
-N4, P4, part = 10_000_000, 8, 3
+N4, P4, part = 10_000_000, 8, int(os.environ.get("PART", "3"))
 ps = N4 // P4
 
 
