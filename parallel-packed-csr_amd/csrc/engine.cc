@@ -154,6 +154,8 @@ struct Engine::Impl {
   uint32_t opt_horizon = 6144;    // (the CPU emulator, which reports no CUs, keeps these)
   uint32_t start_horizon = 6144;
   uint32_t adaptive = 1;
+  uint32_t rb_defer_table = 1u << 22;  // windows from slot 0 of at least this many slots build their position table inside the
+                                       // scatter launch (0: never — the table is built in front of it)
   uint32_t scatter_blocks = 8192;
   uint32_t small_batch = 256;    // batches up to this size take the strict rounds even in speculative mode
   // windows up to this size are rebalanced by the exclusive executor's own wave (64 slots at a time: ~2 us per dependent
@@ -684,6 +686,10 @@ int Engine::set_option(const char *key, int64_t value) {
   }
   if (k == "defer_barrier") {
     p.defer_barrier = (uint32_t)std::max<int64_t>(0, value);
+    return PPCSR_OK;
+  }
+  if (k == "rb_defer_table") {
+    p.rb_defer_table = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(value, 1ll << 31));
     return PPCSR_OK;
   }
   if (k == "dbg_repeat") {
@@ -1392,7 +1398,7 @@ int Engine::rank_scan(const uint32_t *d_cnt, uint64_t nleaves, bool table, uint6
   if (rc != PPCSR_OK) return rc;
   const uint64_t ntiles = (nleaves + kScanTile - 1) / kScanTile;
   GPU_LAUNCH(p.stream, k_scan_tiles, ntiles, 256, d_cnt, nleaves, p.d_tiles);
-  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, table ? p.d_table : (ChainTable *)nullptr, tb_index, tb_len, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, table ? p.d_table : (ChainTable *)nullptr, tb_index, tb_len, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, 0u);
   GPU_LAUNCH(p.stream, k_scan_apply, ntiles, 256, d_cnt, nleaves, (const uint32_t *)p.d_tiles, p.d_rank);
   return PPCSR_OK;
 }
@@ -1423,10 +1429,13 @@ int Engine::rebalance_fused(const View &nv, const Edge *src_items, uint64_t src_
   GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, src_cnt, nleaves, tile, p.d_tiles, inplace ? p.d_rank : (uint32_t *)nullptr,
              inplace ? (uint32_t *)nullptr : dst_cnt, inplace ? (uint64_t)0 : dst_nleaves,
              inplace ? p.v.ldirty + (src_cnt - p.v.leafcnt) : (uint32_t *)nullptr, p.serial);
-  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, tb_index, tb_len, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+  // a window that starts at slot 0 crosses a binade per level of the tree: its position table is a serial chain of ~10 us, built
+  // INSIDE the scatter launch behind the first tiles when the window is big enough for that to pay (pma_rebalance.h)
+  const uint32_t defer = (p.rb_defer_table && tb_index == 0 && tb_len >= (uint64_t)p.rb_defer_table) ? 1u : 0u;
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, tb_index, tb_len, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, defer);
   GPU_LAUNCH(p.stream, k_rb_scatter, ntiles, 256, nv, src_items, src_lo, src_len, src_sh,
                inplace ? (const uint32_t *)p.d_rank : (const uint32_t *)src_cnt, tile, p.rb_prefetch ? 4u : 1u, (const uint32_t *)p.d_tiles,
-               (const ChainTable *)p.d_table, dst, dst_bias, dst_cnt, nv.g.sh, (uint64_t)0);
+               p.d_table, dst, dst_bias, dst_cnt, nv.g.sh, (uint64_t)0, defer);
   return PPCSR_OK;
 }
 
@@ -1530,7 +1539,7 @@ int Engine::big_redistribute(uint64_t wstart, uint64_t wlen, bool sync) {
       uint32_t *order = p.d_ip + kIpHdrWords, *flags = p.d_ip + kIpHdrWords + kIpMaxTiles;
       GPU_LAUNCH(p.stream, k_rb_tilesums, ntiles, 256, v.leafcnt + leaf_lo, nleaves, tile_leaves, p.d_tiles, p.d_rank, (uint32_t *)nullptr, (uint64_t)0,
                  v.ldirty + leaf_lo, p.serial);
-      GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, wstart, wlen, order, p.d_ip, tile_slots);
+      GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, p.d_table, wstart, wlen, order, p.d_ip, tile_slots, 0u);
       if (cpw == 8)
         GPU_LAUNCH(p.stream, k_rb_inplace8, ntiles, 256, v, wstart, wlen, v.g.sh, (const uint32_t *)p.d_rank, (const uint32_t *)p.d_tiles,
                    (const ChainTable *)p.d_table, (const uint32_t *)order, p.d_ip, flags, p.ip_epoch, p.ip_lists);
@@ -1713,7 +1722,7 @@ int Engine::scan_launch(unsigned long long *d_rows, int *d_dst, uint64_t cap, co
   if (fresh_state) GCHK(gpu::dset(d_cs, 0, nchunks * sizeof(uint32_t), p.stream));  // later scans find it zeroed (k_chunk_counts)
   GPU_LAUNCH(p.stream, k_chunk_sentinels, grid_for(n(), 256), 256, p.v, d_cs);
   GPU_LAUNCH(p.stream, k_chunk_counts, ntiles, 256, p.v, d_cs, d_cc, tile, p.d_tiles);
-  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, (ChainTable *)nullptr, (uint64_t)0, (uint64_t)0, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+  GPU_LAUNCH(p.stream, k_scan_tilesums, 1, kTileSumThreads, p.d_tiles, ntiles, p.d_total, (ChainTable *)nullptr, (uint64_t)0, (uint64_t)0, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u, 0u);
   GPU_LAUNCH(p.stream, k_scan_write, ntiles, 256, p.v, (const uint32_t *)d_cc, tile, (const uint32_t *)p.d_tiles, d_rows, d_dst, cap,
              d_values, d_contrib, d_triples, src_base);
   return PPCSR_OK;

@@ -86,8 +86,12 @@ struct ChainTable {
   uint64_t index, len, j;
   int nseg;
   int overflow;
+  // a table built INSIDE the kernel that uses it (k_rb_scatter, see there): segments published so far (bit 31: the table is
+  // complete) and the first chain step they do not cover yet
+  uint32_t pub_nseg, pub_t;
   ChainSeg seg[kMaxSeg];
 };
+constexpr uint32_t kTbDone = 0x80000000u;
 
 PMA_HD inline uint64_t dbl_bits(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -235,7 +235,7 @@ PMA_DEV void rb_order_body(const uint32_t *tile_excl, const ChainTable *tb, uint
 
 constexpr uint32_t kTileSumThreads = 1024;
 PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned long long *total, ChainTable *tb,
-                                uint64_t tb_index, uint64_t tb_len, uint32_t *order, uint32_t *ctl, uint32_t tile_slots) {
+                                uint64_t tb_index, uint64_t tb_len, uint32_t *order, uint32_t *ctl, uint32_t tile_slots, uint32_t defer_table) {
   // ONE workgroup of kTileSumThreads.  Each thread owns a contiguous run of tile sums (independent loads, all in
   // flight together); waves combine through LDS; the prefix is written back while one lane builds the rebalance's exact
   // position table from the grand total (saves a launch).
@@ -264,7 +264,17 @@ PMA_KERNEL void k_scan_tilesums(uint32_t *tilesum, uint64_t ntiles, unsigned lon
     // (one serial chain — a division and a true fp64 subtraction per binade the window crosses, 23 for a window that starts
     //  at slot 0: ~9 us of this launch; run by the whole wave on wave-uniform inputs it measured the same)
     *total = grand;
-    if (tb) build_chain_table(tb_index, tb_len, (uint64_t)grand, tb);
+    if (tb && defer_table) {  // the consumer (k_rb_scatter) builds the table itself, behind its first tiles: only the header here
+      tb->index = tb_index;
+      tb->len = tb_len;
+      tb->j = (uint64_t)grand;
+      tb->nseg = 0;
+      tb->overflow = 0;
+      tb->pub_nseg = grand < 2u ? kTbDone : 0u;  // (j < 2: an empty table is complete)
+      tb->pub_t = 0;
+    } else if (tb) {
+      build_chain_table(tb_index, tb_len, (uint64_t)grand, tb);
+    }
   }
   uint32_t run = woff + incl - mine;
   for (uint64_t i = lo; i < hi; i++) {
@@ -491,6 +501,88 @@ PMA_KERNEL void k_rb_tilesums(uint32_t *cnt, uint64_t nleaves, uint32_t tile_lea
 }
 // One chunk (64 source slots, already in registers) of the rebalance scatter: rank the live slots, look their exact
 // positions up, store element + trailing nulls, fix sentinels, add the destination leaf counts.
+// The exact position table of a window that starts at slot 0 is a SERIAL chain — a division and a true fp64 subtraction per binade
+// the window crosses, 23 for 2^24 slots: ~10 us on one lane, which the whole-array rebalance used to spend in front of its
+// scatter launch.  Its first segment covers the top HALF of the positions, the second the next quarter ...: with the tiles taken
+// from the top of the window down, a builder thread inside the scatter launch (workgroup 0) stays ahead of them.  Every
+// finished segment is published — its six words and then the count, at agent scope, word by word: plain stores may sit in the
+// builder's XCD L2 — and a workgroup copies the table to its LDS once the published part covers the chain steps its tile needs.
+// A workgroup that waits too long (it never does: workgroup 0 is dispatched first) builds the table itself: no hang, no error path.
+PMA_DEV void build_chain_table_publish(ChainTable *tb) {  // one thread; index / len / j are in the header already
+  const uint64_t index = tb->index, len = tb->len, j = tb->j;
+  if (j < 2) return;
+  int nseg = 0;
+  const double step = chain_step(len, j);
+  double x = chain_top(index, j, step);
+  const uint64_t sb = dbl_bits(step);
+  const int es = (int)((sb >> 52) & 0x7FF) - 1023;
+  const uint64_t S = (sb & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+  const uint64_t T = j - 2;
+  uint64_t t = 0;
+  for (;;) {
+    ChainSeg sg;
+    sg.t0 = t;
+    uint64_t c = chain_segment(x, S, es, &sg);
+    if (c > T - t) c = T - t;
+    sg.count = c;
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(&tb->seg[nseg]);
+    const unsigned long long *in = reinterpret_cast<const unsigned long long *>(&sg);
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(ChainSeg) / 8); q++) wv::store_agent_u64(out + q, in[q]);
+    nseg++;
+    t += c;
+    const bool done = t >= T || nseg >= kMaxSeg;
+    wv::store_agent_u64(reinterpret_cast<unsigned long long *>(&tb->pub_nseg),
+                        (unsigned long long)((uint32_t)nseg | (done ? kTbDone : 0u)) | ((unsigned long long)(uint32_t)(t + 1) << 32));
+    if (done) return;
+    // one true fp64 subtraction across the binade boundary
+    const uint64_t Mc = (c == 0) ? sg.M0 : (sg.M0 - sg.Dfirst - (c - 1) * sg.Drest);
+    const int e = 52 - sg.shift;
+    const double xc = bits_dbl(((uint64_t)(e + 1023) << 52) | (Mc & 0xFFFFFFFFFFFFFull));
+    x = chain_sub(xc, step);
+    t += 1;
+  }
+}
+static_assert(sizeof(ChainSeg) % 8 == 0 && offsetof(ChainTable, pub_t) == offsetof(ChainTable, pub_nseg) + 4 && offsetof(ChainTable, pub_nseg) % 8 == 0,
+              "the publication word is one aligned 64-bit store: count in the low half, covered steps in the high half");
+// the table in LDS (stb) for a workgroup whose tile needs the chain steps up to t_need; all threads of the workgroup call
+PMA_DEV void rb_table_to_lds(ChainTable *tb, ChainTable *stb, uint64_t t_need, bool builder, uint32_t *s_flag) {
+  if (builder && wv::thread_idx() == 0) build_chain_table_publish(tb);
+  if (wv::thread_idx() == 0) {
+    uint32_t n = 0;
+    bool ok = false;
+    for (uint32_t spin = 0; spin < 200000u; spin++) {
+      const unsigned long long w = wv::load_agent_u64(reinterpret_cast<const unsigned long long *>(&tb->pub_nseg));
+      n = (uint32_t)w;
+      if ((n & kTbDone) || (uint64_t)(uint32_t)(w >> 32) > t_need) {
+        ok = true;
+        break;
+      }
+      wv::spin_pause();
+    }
+    *s_flag = ok ? (n & ~kTbDone) : 0xFFFFFFFFu;
+  }
+  wv::block_sync();
+  const uint32_t n = *s_flag;
+  if (n == 0xFFFFFFFFu) {  // (never, see above) build it here
+    if (wv::thread_idx() == 0) build_chain_table(tb->index, tb->len, tb->j, stb);
+    wv::block_sync();
+    return;
+  }
+  if (wv::thread_idx() == 0) {
+    stb->index = tb->index;
+    stb->len = tb->len;
+    stb->j = tb->j;
+    stb->nseg = (int)n;
+    stb->overflow = 0;
+  }
+  const uint32_t words = n * (uint32_t)(sizeof(ChainSeg) / 8);
+  const unsigned long long *g = reinterpret_cast<const unsigned long long *>(&tb->seg[0]);
+  unsigned long long *sp = reinterpret_cast<unsigned long long *>(&stb->seg[0]);
+  for (uint32_t i = wv::thread_idx(); i < words; i += wv::block_dim()) sp[i] = wv::load_agent_u64(g + i);
+  wv::block_sync();
+}
+
 PMA_DEV void rb_scatter_chunk(const View &v, const Edge &e, uint64_t k0 /* wave-uniform */, const ChainTable *stb, uint64_t j, uint64_t wend,
                               Edge *__restrict__ dst, uint64_t dst_bias, uint32_t *dst_leafcnt, int dst_sh, uint64_t dst_leaf_bias,
                               int lane, uint64_t lt_mask, int *hint, int *hint2, int *hint3) {
@@ -535,19 +627,25 @@ PMA_DEV void rb_scatter_chunk(const View &v, const Edge &e, uint64_t k0 /* wave-
 constexpr int kRbBatch = 4;
 PMA_KERNEL void k_rb_scatter(View v, const Edge *__restrict__ src, uint64_t src_lo, uint64_t src_len, int src_sh,
                              const uint32_t *__restrict__ cnt, uint32_t tile_leaves, uint32_t batch,
-                             const uint32_t *__restrict__ tile_excl, const ChainTable *tb, Edge *__restrict__ dst, uint64_t dst_bias,
-                             uint32_t *dst_leafcnt, int dst_sh, uint64_t dst_leaf_bias) {
+                             const uint32_t *__restrict__ tile_excl, ChainTable *tb, Edge *__restrict__ dst, uint64_t dst_bias,
+                             uint32_t *dst_leafcnt, int dst_sh, uint64_t dst_leaf_bias, uint32_t defer_table) {
   PMA_SHARED ChainTable stb;
   PMA_SHARED uint32_t pre[kRbTile];
   PMA_SHARED uint32_t wsum[4];
-  {
+  PMA_SHARED uint32_t s_flag;
+  // defer_table: the table is built inside this launch by workgroup 0 (build_chain_table_publish) and the tiles are taken from
+  // the top of the window down — the high tiles need only the first segments
+  const uint64_t tile = defer_table ? (uint64_t)wv::grid_dim() - 1ull - wv::block_idx() : (uint64_t)wv::block_idx();
+  if (defer_table) {
+    const uint64_t jj = tb->j, r0 = tile_excl[tile];
+    rb_table_to_lds(tb, &stb, jj > r0 ? jj - 1ull - r0 : 0ull, wv::block_idx() == 0, &s_flag);
+  } else {
     const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);
     uint32_t *sp = reinterpret_cast<uint32_t *>(&stb);
     const uint32_t words = (uint32_t)((sizeof(ChainTable) - sizeof(ChainSeg) * (size_t)(kMaxSeg - tb->nseg)) / 4);
     for (uint32_t i = wv::thread_idx(); i < words; i += wv::block_dim()) sp[i] = g[i];
   }
   const int lane = wv::lane(), w = wv::wave_in_block();
-  const uint64_t tile = wv::block_idx();
   const uint64_t nleaves = src_len >> src_sh;
   {  // exclusive prefix of this tile's leaf counts (one leaf per thread)
     const uint64_t l = tile * tile_leaves + wv::thread_idx();

@@ -87,6 +87,11 @@ PMA_DEV void flag_publish(uint32_t *p, uint32_t v) {
 }
 PMA_DEV uint32_t flag_read(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PMA_DEV void flag_acquire() { asm volatile("" ::: "memory"); }
+// data that travels between workgroups INSIDE a launch (the position table of k_rb_scatter): written and read at agent scope,
+// word by word — a plain store may sit in the writer's XCD L2 and a plain load may be served from a stale line of the
+// reader's, and a release / acquire pair at agent scope is an L2 write-back / invalidate per use
+PMA_DEV void store_agent_u64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PMA_DEV unsigned long long load_agent_u64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // which of the 8 XCDs this wave runs on (HW_REG_XCC_ID bits 3:0) — used for affinity only, never for correctness
 PMA_DEV uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }
 PMA_DEV void spin_pause() { __builtin_amdgcn_s_sleep(2); }

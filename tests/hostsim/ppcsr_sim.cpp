@@ -28,6 +28,29 @@ extern "C" int ppcsr_sim_chain_positions(uint64_t index, uint64_t len, uint64_t 
       for (uint64_t i = 0; i <= cnt; i++)
         if (((A + i * D) >> shift) != out[k0 + i]) ok = 0;
   }
+  // a table published segment by segment (k_rb_scatter's builder): with only the first n segments, every element whose chain step
+  // the published part covers (t = j-1-k <= t0 + count of segment n-1) must already get its final position — look-ups and
+  // linear runs alike
+  if (j >= 2 && tb.nseg > 1) {
+    static ppcsr::ChainTable part;
+    for (int n = 1; n < tb.nseg; n++) {
+      part = tb;
+      part.nseg = n;
+      const uint64_t covered = tb.seg[n - 1].t0 + tb.seg[n - 1].count;  // inclusive
+      const uint64_t k_lo = (j - 1 > covered) ? j - 1 - covered : 1;     // elements k_lo .. j-1 are covered (k = 0 has no chain step)
+      int h = -1, h3 = -1;
+      const uint64_t stride = (j - k_lo) / 97 + 1;
+      for (uint64_t k = k_lo; k < j; k += stride)
+        if (ppcsr::chain_pos(&part, k, &h) != out[k]) ok = 0;
+      if (ppcsr::chain_pos(&part, k_lo, &h) != out[k_lo]) ok = 0;
+      const uint64_t cnt = (k_lo + 64 <= j - 1) ? 64 : (j - 1 - k_lo);
+      uint64_t A, D;
+      int shift;
+      if (cnt && ppcsr::chain_linear_run(&part, k_lo, cnt, &h3, &A, &D, &shift))
+        for (uint64_t i = 0; i <= cnt; i++)
+          if (((A + i * D) >> shift) != out[k_lo + i]) ok = 0;
+    }
+  }
   // closed form used by the in-wave rebalance: when the chain is a single segment it must give the same positions
   ppcsr::ChainSeg sg;
   {  // the division-free closed-form test against its statement with the division: same verdict, same segment

@@ -82,6 +82,8 @@ inline void wait_loads() {}
 inline void flag_publish(uint32_t *p, uint32_t v) { *p = v; }
 inline uint32_t flag_read(const uint32_t *p) { return *(const volatile uint32_t *)p; }
 inline void flag_acquire() {}
+inline void store_agent_u64(unsigned long long *p, unsigned long long v) { *p = v; }
+inline unsigned long long load_agent_u64(const unsigned long long *p) { return *(const volatile unsigned long long *)p; }
 inline uint32_t xcc_id() { return (uint32_t)sim::cur_block() & 7u; }
 inline void spin_pause() {}
 inline int clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }

@@ -26,6 +26,9 @@ MODES = {
     "default": dict(),  # engine defaults: speculative rounds, batches of <= 256 updates through the strict rounds
     # round 4: the wave-per-update o_check forced (by default the engine picks it for streams with long footprints)
     "wave-check": dict(mode=1, small_batch=0, check_lanes=0, opt_horizon=2048),
+    # the diagnostics build of the round kernels with every measurement aid on: o_plan executes the plan, the search and the
+    # round's bookkeeping twice (tools/sq_delta.sh) — it must still plan the same thing
+    "diag-repeat": dict(mode=1, small_batch=0, dbg_repeat=7, opt_horizon=4096),
 }
 
 

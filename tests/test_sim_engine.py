@@ -46,6 +46,8 @@ def sim():
         e.set_option("big_grid", opts.get("big_grid", 2))        # (every emulated workgroup of o_big is 1024 fibers)
         e.set_option("big_min", opts.get("big_min", 512))
         e.set_option("big_window", opts.get("big_window", 131072))
+        if "rb_defer_table" in opts:
+            e.set_option("rb_defer_table", opts["rb_defer_table"])
         return e
     return make
 
@@ -67,12 +69,14 @@ def test_sim_small_inserts(sim, streams):
     _same(e, o)
 
 
-def test_sim_mixed_with_resizes(sim, streams):
+@pytest.mark.parametrize("defer_min", [1 << 22, 64])
+def test_sim_mixed_with_resizes(sim, streams, defer_min):
+    """(defer_min = 64: double_list / half_list build their position table inside the scatter launch, tiles from the top down)"""
     a = streams.random_stream(40, 6000, seed=2)
     d = a.copy()
     d[:, 2] = 0
     ops = np.concatenate([a, d[::-1]])
-    e, o = sim(40), Oracle(40)
+    e, o = sim(40, rb_defer_table=defer_min), Oracle(40)
     for lo in range(0, len(ops), 1500):
         e.apply(ops[lo:lo + 1500])
         o.apply(ops[lo:lo + 1500])
@@ -238,11 +242,13 @@ def test_sim_leaves_the_sequential_regime_when_ranges_are_sane(sim, streams):
     assert e.stats()["rounds"] - r0 < 1000  # (2000 updates one per round would be 2000 rounds)
 
 
-def test_sim_big_window_rebalance(sim, streams):
+@pytest.mark.parametrize("defer_min", [1 << 22, 64])
+def test_sim_big_window_rebalance(sim, streams, defer_min):
     """the multi-workgroup rebalance (rank scan + exact position table + fused scatter/fill) on whole-array and
-    partial windows, against the reference's redistribute() run by the oracle on the same window"""
+    partial windows, against the reference's redistribute() run by the oracle on the same window; defer_min = 64: the position
+    table is built inside the scatter launch (published segment by segment, tiles taken from the top of the window down)"""
     ops = streams.random_stream(300, 6000, seed=9)
-    e, o = sim(300), Oracle(300)
+    e, o = sim(300, rb_defer_table=defer_min), Oracle(300)
     e.apply(ops)
     o.apply(ops)
     N = e.geometry()[0]
