@@ -60,7 +60,8 @@ for c in range(cases):
                     region_rare_dist=int(rng.choice([1, 4096, 65536])), region_rare_cpr=int(rng.choice([0, 64, 1536])),
                     region_rare_calm=int(rng.choice([1, 8])))
     if rng.integers(0, 2):  # round-4: which o_check, when windows are queued for workgroups, how often the host looks
-        opts.update(check_lanes=int(rng.choice([-1, 0, 1])), big_min=int(rng.choice([64, 512, 512])), rounds_per_sync=int(rng.choice([2, 8, 32])))
+        opts.update(check_lanes=int(rng.choice([-1, 0, 1])), big_min=int(rng.choice([64, 512, 512])), rounds_per_sync=int(rng.choice([2, 8, 32])),
+                    rb_defer_table=int(rng.choice([64, 4096, 1 << 22])))  # (64: every resize builds its position table inside the scatter launch)
     if rng.integers(0, 5) == 0:
         opts["mode"] = 0
     eng, o = pkg.PCSR(n, lock_search=lock), Oracle(n, lock_search=lock)
