@@ -1,4 +1,4 @@
-// Speculative rounds of the update scheduler (o_plan / o_check / o_apply / o_compact).
+// Speculative rounds of the update scheduler (o_plan / o_check / o_apply, o_big for the queued windows, o_settle at the end of a chunk).
 #pragma once
 #include "pma_rounds.h"
 
@@ -24,11 +24,11 @@ namespace ppcsr {
 // =====================================================================================================================
 // Round r's bookkeeping — how many of round r-1's updates are still pending, the next horizon, the adapted width, is the epoch
 // done, does the lowest pending update need the exclusive executor — is a pure function of words that round r-1's launches left
-// behind, so EVERY wave of o_plan(r) evaluates it for itself (round_begin: two dozen scalar instructions on words it loads with
-// its other control words) and wave 0 alone records the outcome for the later launches and the host.  That replaced a launch of
-// its own per round (o_compact: one workgroup compacting the deferred updates into a sorted carry list, ~10 us of every round).
-// Deferred updates now append THEMSELVES to the carry list (o_apply: one returning atomic per deferred update, on the counter of
-// the XCD it runs on), in no particular order: stream order is carried by the reservation keys, not by the slots, and the one
+// behind, so o_plan(r) evaluates it itself — wave 0 of every workgroup (round_begin: scalar arithmetic on words it loads with its
+// other control words; the other waves get what they need through LDS) — and wave 0 of workgroup 0 alone records the outcome
+// for the later launches and the host.  That replaced a launch of its own per round (o_compact: one workgroup compacting the
+// deferred updates into a sorted carry list, ~10 us of every round).  Deferred updates now append THEMSELVES to the carry list
+// (o_apply: one returning atomic per workgroup that has any, on the counter of the XCD it runs on), in no particular order: stream order is carried by the reservation keys, not by the slots, and the one
 // thing the sorted list guaranteed — everything not planned is later than everything planned — holds because a round always plans
 // the WHOLE carry list (the adapted width only limits how many fresh updates join it).
 // Words written during round r and read during round r+1 are indexed r % 3 where round r+1's wave 0 must be able to reset the

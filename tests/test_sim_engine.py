@@ -103,7 +103,7 @@ def test_sim_speculative_rounds(sim, name, region):
 
 @pytest.mark.parametrize("big_min,big_window", [(64, 131072), (128, 1024)])
 def test_sim_big_windows_inside_the_round(sim, big_min, big_window):
-    """windows above big_min slots are rebalanced by a workgroup (the extra workgroups of o_compact) instead of the update's
+    """windows above big_min slots are rebalanced by a workgroup of o_big instead of the update's
     own wave; windows above big_window make the update exclusive, and it runs in the middle of the epoch (stamp-validated,
     its slot commits as nothing).  A hub stream drives windows up to the whole array; its delete phase shrinks them again.
     (Every emulated workgroup is 1024 fibers, hence the short stream.)"""
