@@ -379,11 +379,14 @@ def test_seq_stress_edge_exists(pkg):
     assert not eng.edge_exists(0, 5)
 
 
-@pytest.mark.parametrize("variant,tile,batch", [(2, 0, 1), (2, 32, 1), (2, 256, 0), (1, 0, 1), (0, 0, 1)])
-def test_big_window_rebalance(pkg, streams, variant, tile, batch):
+@pytest.mark.parametrize("variant,tile,batch,defer", [(2, 0, 1, 1 << 22), (2, 32, 1, 1 << 22), (2, 256, 0, 1 << 22), (1, 0, 1, 1 << 22), (0, 0, 1, 1 << 22),
+                                                      (2, 0, 1, 64), (2, 32, 1, 4096), (2, 256, 0, 64)])
+def test_big_window_rebalance(pkg, streams, variant, tile, batch, defer):
     """multi-workgroup rebalance kernels on 2^21..2^15-slot windows vs the oracle's redistribute(): the default pipeline
     (tile sums + in-tile scan + four chunks in flight) at several tile sizes, and the two older scatter variants that stay
-    selectable for A/B measurements; array doublings go through the same pipeline (out of place)"""
+    selectable for A/B measurements; array doublings go through the same pipeline (out of place).  defer = 64 / 4096: windows
+    from slot 0 build their position table INSIDE the scatter launch (published segment by segment, tiles taken top-down) —
+    by default only windows of >= 2^22 slots do"""
     n = 1 << 16
     s, d = streams.rmat_edges(16, 500000, seed=4)
     ops = streams.adds(s, d)
@@ -391,6 +394,7 @@ def test_big_window_rebalance(pkg, streams, variant, tile, batch):
     e.set_option("scatter_variant", variant)
     e.set_option("rb_tile", tile)
     e.set_option("rb_prefetch", batch)
+    e.set_option("rb_defer_table", defer)
     e.apply(ops)
     o.apply(ops)
     _same(e, o, "load (with doublings)")
