@@ -1,6 +1,7 @@
-"""Workload for tools/sim_asan.sh: the real kernels under the CPU emulator built with AddressSanitizer (speculative rounds with\nrollbacks, a hub stream with the in-launch position table, strict rounds, whole-array rebalances), each compared with the oracle."""
+"""Workload for tools/sim_asan.sh: the real kernels under the CPU emulator built with AddressSanitizer (speculative rounds with
+rollbacks, a hub stream with the in-launch position table, strict rounds, whole-array rebalances), each compared with the oracle."""
 import os, sys
-sys.path.insert(0, "/root/repo/tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
 from helpers import load_pkg, load_streams
 from oracle_lib import Oracle
