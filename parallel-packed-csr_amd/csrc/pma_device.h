@@ -50,6 +50,14 @@ struct StatShard {
 
 namespace dev {
 
+PMA_DEV Edge load_stream(const Edge *p) {  // (see wv::load_stream_u32)
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+  Edge e;
+  e.src = wv::load_stream_u32(w);
+  e.dest = wv::load_stream_u32(w + 1);
+  e.value = wv::load_stream_u32(w + 2);
+  return e;
+}
 PMA_DEV uint32_t lanemask_lt_count(uint64_t m, int lane) { return (uint32_t)wv::popc64(m & ((1ull << lane) - 1ull)); }
 
 // sum of leafcnt[leaf_lo .. leaf_lo+nleaves)

@@ -683,7 +683,7 @@ PMA_KERNEL void k_rb_scatter(View v, const Edge *__restrict__ src, uint64_t src_
       for (int q = 0; q < kRbBatch; q++) {
         const uint64_t off = tile_slot0 + (uint64_t)(c0 + q) * 64 + (uint64_t)lane;
         e[q] = null_edge();
-        if (c0 + q < chunks && off < src_len) e[q] = src[src_lo + off];
+        if (c0 + q < chunks && off < src_len) e[q] = dev::load_stream(src + (src_lo + off));
       }
 #pragma unroll
       for (int q = 0; q < kRbBatch; q++) {
@@ -697,7 +697,7 @@ PMA_KERNEL void k_rb_scatter(View v, const Edge *__restrict__ src, uint64_t src_
       const uint64_t off = tile_slot0 + (uint64_t)c * 64 + (uint64_t)lane;
       if (off - lane >= src_len) break;
       Edge e = null_edge();
-      if (off < src_len) e = src[src_lo + off];
+      if (off < src_len) e = dev::load_stream(src + (src_lo + off));
       rb_scatter_chunk(v, e, base_rank + pre[c * lpc], &stb, j, wend, dst, dst_bias, dst_leafcnt, dst_sh, dst_leaf_bias, lane, lt_mask,
                        &hint, &hint2, &hint3);
     }
@@ -743,7 +743,7 @@ PMA_DEV void rb_inplace_body(const View &v, uint64_t wstart, uint64_t wlen, int 
     // (the window is a whole number of tiles — the engine checks — so the load needs no guard; a load under a branch makes the
     //  compiler wait for it on the spot, which turned these CPW requests into CPW / 2 round trips)
     const uint64_t off = tile_slot0 + (uint64_t)(w * CPW + q) * 64u + (uint64_t)lane;
-    e[q] = v.items[wstart + off];
+    e[q] = dev::load_stream(v.items + (wstart + off));
   }
   {
     const uint32_t *g = reinterpret_cast<const uint32_t *>(tb);

@@ -85,6 +85,7 @@ inline void flag_acquire() {}
 inline void store_agent_u64(unsigned long long *p, unsigned long long v) { *p = v; }
 inline unsigned long long load_agent_u64(const unsigned long long *p) { return *(const volatile unsigned long long *)p; }
 inline uint32_t xcc_id() { return (uint32_t)sim::cur_block() & 7u; }
+inline uint32_t load_stream_u32(const uint32_t *p) { return *p; }
 inline void spin_pause() {}
 inline int clz64(uint64_t m) { return m ? __builtin_clzll(m) : 64; }
 inline int popc64(uint64_t m) { return __builtin_popcountll(m); }
