@@ -149,7 +149,7 @@ PMA_KERNEL void k_scan_write(View v, const uint32_t *__restrict__ chunkcnt, uint
     for (int q = 0; q < K; q++) {
       const uint64_t s = (tile * tile_chunks + c0 + q) * 64 + (uint64_t)lane;
       e[q] = null_edge();
-      if (c0 + q < tile_chunks && s < N) e[q] = dev::load_stream(items + s);
+      if (c0 + q < tile_chunks && s < N) e[q] = items[s];
     }
 #pragma unroll
     for (int q = 0; q < K; q++) {

@@ -94,8 +94,9 @@ PMA_DEV void store_agent_u64(unsigned long long *p, unsigned long long v) { __hi
 PMA_DEV unsigned long long load_agent_u64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // which of the 8 XCDs this wave runs on (HW_REG_XCC_ID bits 3:0) — used for affinity only, never for correctness
 PMA_DEV uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }
-// a load of data that is read ONCE by the whole launch (the source of a rebalance / scan pass): the non-temporal hint keeps it from
-// displacing the lines the pass is still assembling in L2 (whole-array rebalance 118 -> 102 us with it on the source reads)
+// a load of data that is read ONCE by the whole launch (the source of a rebalance pass): the non-temporal hint keeps it from
+// displacing the lines the pass is still assembling in L2 (whole-array rebalance at 2^24 slots 115 -> 105 us with it on the
+// source reads; the neighbour scan, which writes little, got slower with it: 60 -> 65 us — plain loads there)
 PMA_DEV uint32_t load_stream_u32(const uint32_t *p) { return __builtin_nontemporal_load(p); }
 PMA_DEV void spin_pause() { __builtin_amdgcn_s_sleep(2); }
 PMA_DEV int clz64(uint64_t m) { return __clzll((long long)m); }
